@@ -1,0 +1,91 @@
+"""The oracle (C restatement) against the reference's own outputs.
+
+tests/golden/ref_goldens.npz was produced by the REAL liblcg native back-end
+(tests/golden/make_golden.py).  The restatement must reproduce it bit for bit:
+same return code, same iteration count, identical solution vector.  This is the
+pin that lets the oracle stand in for the reference on the GPU box.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+REAL_TAGS = ["cg_e6", "pcg_e6", "cgs_e6", "bicgstab_e6", "cg_e10", "pcg_e10", "cgs_e10",
+             "bicgstab_e10", "cg_e20", "pcg_e12", "cgs_e12", "bicgstab_e12", "cg_e12", "cg_max25"]
+CPLX_TAGS = ["bicgsym_1K", "cgs_1K", "tfqmr_1K", "bicgstab_1K", "bicgsym_10K", "cgs_10K", "tfqmr_10K"]
+
+
+@pytest.mark.parametrize("tag", REAL_TAGS)
+def test_real_solver_bit_exact(tag, port, goldens, case10k):
+    n, rp, ci, v, b, _ = case10k
+    ret, iters, sid, jac, ad, maxit = goldens[f"real/{tag}/meta"]
+    eps, resid = goldens[f"real/{tag}/fl"]
+    para = po.default_para(epsilon=float(eps), abs_diff=int(ad), max_iterations=int(maxit))
+    r = port.solve(int(sid), rp, ci, v, b, para=para, jacobi=bool(jac))
+    assert r["ret"] == ret
+    assert r["iters"] == iters
+    assert r["residual"] == resid
+    assert np.array_equal(r["x"], goldens[f"real/{tag}/x"])
+
+
+@pytest.mark.parametrize("tag", CPLX_TAGS)
+def test_complex_solver_bit_exact(tag, port, goldens, case1kc, case10kc):
+    n, rp, ci, v, b, _ = case1kc if tag.endswith("1K") else case10kc
+    ret, iters, sid, ad, maxit, seed = goldens[f"cplx/{tag}/meta"]
+    eps, resid = goldens[f"cplx/{tag}/fl"]
+    para = po.default_cpara(epsilon=float(eps), abs_diff=int(ad), max_iterations=int(maxit))
+    rbar0 = port.vecrnd(n, int(seed))      # replay of the reference's srand(time(0)) draw
+    r = port.csolve(int(sid), rp, ci, v, b, para=para, rbar0=rbar0)
+    assert r["ret"] == ret
+    assert r["iters"] == iters
+    assert r["residual"] == resid
+    assert np.array_equal(r["x"], goldens[f"cplx/{tag}/x"])
+
+
+def test_known_answer_case_10K(port, case10k):
+    """CG at eps=1e-20/abs_diff reaches the fp64 floor of case_10K_B."""
+    n, rp, ci, v, b, xs = case10k
+    r = port.solve(po.LCG_CG, rp, ci, v, b, para=po.default_para(epsilon=1e-20, abs_diff=1))
+    assert r["ret"] == 0 and r["iters"] == 367
+    assert np.linalg.norm(r["x"] - xs) < 1e-11
+
+
+def test_argument_checks(port, case10k):
+    """lcg.cpp:150-155: error codes, checked in this order."""
+    n, rp, ci, v, b, _ = case10k
+    assert port.solve(0, rp, ci, v, b, para=po.default_para(max_iterations=-1))["ret"] == -1022
+    assert port.solve(0, rp, ci, v, b, para=po.default_para(epsilon=0.0))["ret"] == -1021
+    assert port.solve(0, rp, ci, v, b, para=po.default_para(epsilon=1.0))["ret"] == -1021
+
+
+def test_already_optimized(port, case10k):
+    """lcg.cpp:186-203: a start vector that already meets the tolerance returns 2."""
+    n, rp, ci, v, b, xs = case10k
+    for sid in (po.LCG_CG, po.LCG_CGS, po.LCG_BICGSTAB):
+        r = port.solve(sid, rp, ci, v, b, m0=xs, para=po.default_para(epsilon=1e-6))
+        assert r["ret"] == 2 and r["iters"] == 0
+    assert port.solve(po.LCG_PCG, rp, ci, v, b, m0=xs, jacobi=True)["ret"] == 2
+
+
+def test_unknown_solver_runs_cgs(port, case10k):
+    """lcg.cpp:76-78: LCG_PCG/PG/SPG handed to lcg_solver silently run CGS."""
+    n, rp, ci, v, b, _ = case10k
+    a = port.solve(po.LCG_CGS, rp, ci, v, b)
+    for sid in (1, 5, 6):
+        c = port.solve(sid, rp, ci, v, b)
+        assert c["iters"] == a["iters"] and np.array_equal(c["x"], a["x"])
+
+
+def test_coo_matvec_equals_csr(port):
+    """algebra.cpp:195-221 on the row-sorted fixture equals the CSR product exactly."""
+    import os
+    from conftest import GOLDEN
+    from liblcg_amd.coo_io import coo_to_csr_host, read_coo_system
+    n, row, col, val, b = read_coo_system(os.path.join(GOLDEN, "case_10K_A"))
+    rp, ci, v = coo_to_csr_host(n, row, col, val)
+    x = np.random.default_rng(3).standard_normal(n)
+    assert np.array_equal(port.coo_matvec(row, col, val, x), port.csr_matvec(rp, ci, v, x))
+    rp2, perm = port.coo_to_csr(row, col, n)
+    assert np.array_equal(rp2, rp) and np.array_equal(col[perm], ci)
+    d = port.csr_diag(rp, ci, v)
+    assert set(np.unique(d)) <= {2.0, 3.0, 4.0}      # SURVEY.md section 4 fixture facts
