@@ -1,0 +1,232 @@
+/*
+ * lcg_hip.h -- C ABI of liblcg_hip.so: an MI355X (gfx950) implementation of the
+ * conjugate-gradient iteration hot path of liblcg, behind liblcg's own solver
+ * entry points and callback types.
+ *
+ * Every entry point names the reference interface (path:line under
+ * /root/reference/src/lib) it stands in for.  Plain C: opaque handles, POD
+ * structs, raw pointers and sizes; no C++/torch types cross this boundary.
+ * The C++ header include/lcg_dropin.hpp layers the reference's exact C++
+ * signatures (default arguments, std::complex) over these symbols.
+ *
+ * Memory convention.  The iteration is device resident.  `mem` says where the
+ * caller's m (in/out) and B (in) live:
+ *   LCG_HIP_MEM_HOST   host pointers; copied in, solved on the GPU, m copied back
+ *                      (the behaviour of lcg_solver_cuda, lcg_cuda.cu:103-111,210)
+ *   LCG_HIP_MEM_DEVICE device pointers; nothing is copied.
+ * Callbacks ALWAYS receive device pointers (as the reference's CUDA callbacks
+ * do, lcg_cuda.h:45-46) and must enqueue their work on lcg_hip_get_stream()
+ * without synchronising.  The progress callback receives the device m.
+ *
+ * All functions return 0 / a liblcg status code (util.h:69-90) unless noted;
+ * LCG_HIP_E_* (<= -2000) report runtime failures (HIP/RCCL errors, missing GPU).
+ * There is no CPU fallback: without a usable GPU every compute entry fails.
+ */
+#ifndef LCG_HIP_H
+#define LCG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ types */
+
+/* util.h:95-148 (bit-compatible, 64 bytes) */
+typedef struct lcg_para {
+    int    max_iterations;   /* 0 = until convergence */
+    double epsilon;          /* in (0,1) */
+    int    abs_diff;         /* 0: |g|^2/max(|m|^2,1)   1: |g|/N   (lcg.cpp:208-209) */
+    double restart_epsilon;  /* unused by the solvers provided here */
+    double step;
+    double sigma;
+    double beta;
+    int    maxi_m;
+} lcg_para;
+
+/* util.h:247-273 (24 bytes) */
+typedef struct clcg_para {
+    int    max_iterations;
+    double epsilon;
+    int    abs_diff;         /* complex residual is |<r,r>|^2/max(|<m,m>|^2,1): clcg.cpp:295-296 */
+} clcg_para;
+
+/* util.h:32-64 */
+enum { LCG_CG = 0, LCG_PCG = 1, LCG_CGS = 2, LCG_BICGSTAB = 3, LCG_BICGSTAB2 = 4, LCG_PG = 5, LCG_SPG = 6 };
+/* util.h:187-221 */
+enum { CLCG_BICG = 0, CLCG_BICG_SYM = 1, CLCG_CGS = 2, CLCG_BICGSTAB = 3, CLCG_TFQMR = 4,
+       CLCG_PCG = 5, CLCG_PBICG = 6 };
+/* util.h:69-90 */
+enum {
+    LCG_SUCCESS = 0, LCG_CONVERGENCE = 0, LCG_STOP = 1, LCG_ALREADY_OPTIMIZIED = 2,
+    LCG_UNKNOWN_ERROR = -1024, LCG_INVILAD_VARIABLE_SIZE = -1023, LCG_INVILAD_MAX_ITERATIONS = -1022,
+    LCG_INVILAD_EPSILON = -1021, LCG_INVILAD_RESTART_EPSILON = -1020,
+    LCG_REACHED_MAX_ITERATIONS = -1019, LCG_NULL_PRECONDITION_MATRIX = -1018, LCG_NAN_VALUE = -1017,
+    LCG_INVALID_POINTER = -1016, LCG_INVALID_LAMBDA = -1015, LCG_INVALID_SIGMA = -1014,
+    LCG_INVALID_BETA = -1013, LCG_INVALID_MAXIM = -1012, LCG_SIZE_NOT_MATCH = -1011
+};
+/* util.h:226-242.  NB the complex loops return LCG_REACHED_MAX_ITERATIONS (-1019) and
+ * LCG_ALREADY_OPTIMIZIED from the REAL enum (clcg.cpp:126,164); kept as is. */
+enum {
+    CLCG_SUCCESS = 0, CLCG_CONVERGENCE = 0, CLCG_STOP = 1, CLCG_ALREADY_OPTIMIZIED = 2,
+    CLCG_UNKNOWN_ERROR = -1024, CLCG_INVILAD_VARIABLE_SIZE = -1023, CLCG_INVILAD_MAX_ITERATIONS = -1022,
+    CLCG_INVILAD_EPSILON = -1021, CLCG_REACHED_MAX_ITERATIONS = -1020, CLCG_NAN_VALUE = -1019,
+    CLCG_INVALID_POINTER = -1018, CLCG_SIZE_NOT_MATCH = -1017, CLCG_UNKNOWN_SOLVER = -1016
+};
+enum {
+    LCG_HIP_E_RUNTIME = -2000,   /* a HIP call failed (lcg_hip_last_error() has the text) */
+    LCG_HIP_E_NO_DEVICE = -2001, /* no usable gfx950 device */
+    LCG_HIP_E_COMM = -2002,      /* RCCL missing or a collective failed */
+    LCG_HIP_E_ARG = -2003        /* bad handle / argument to a non-solver entry */
+};
+enum { LCG_HIP_MEM_HOST = 0, LCG_HIP_MEM_DEVICE = 1 };
+
+/* lcg.h:37-38.  x and prod_Ax are DEVICE pointers. Also the type of M^-1.x (lcg.h:90). */
+typedef void (*lcg_axfunc_ptr)(void *instance, const double *x, double *prod_Ax, const int n_size);
+/* lcg.h:53-54.  m is the DEVICE solution vector; non-zero return stops with LCG_STOP. */
+typedef int (*lcg_progress_ptr)(void *instance, const double *m, const double converge,
+                                const lcg_para *param, const int n_size, const int k);
+/* clcg.h:40-41.  Complex vectors are interleaved (re,im) doubles == std::complex<double>.
+ * layout: 0 MatNormal / 1 MatTranspose; conjugate: 0 NonConjugate / 1 Conjugate
+ * (algebra.h:31-50).  The solvers here only ever pass (0,0), as clcg.cpp:463,474,620,630,707,759,771. */
+typedef void (*clcg_hip_axfunc_ptr)(void *instance, const double *x, double *prod_Ax,
+                                    const int n_size, int layout, int conjugate);
+/* clcg.h:56-57 */
+typedef int (*clcg_hip_progress_ptr)(void *instance, const double *m, const double converge,
+                                     const clcg_para *param, const int n_size, const int k);
+
+/* ------------------------------------------------------- runtime / stream */
+int  lcg_hip_init(int device);                 /* selects the device; idempotent. */
+int  lcg_hip_set_stream(void *hip_stream);     /* NULL = the library's own stream */
+void *lcg_hip_get_stream(void);                /* stream callbacks must launch on */
+int  lcg_hip_synchronize(void);
+/* Blocking copy on the library stream.  kind: 1 host->device, 2 device->host, 3 device->device
+ * (the cudaMemcpy calls of the reference's GPU samples, e.g. sample8.cu:160-166). */
+int  lcg_hip_memcpy(void *dst, const void *src, uint64_t bytes, int kind);
+const char *lcg_hip_last_error(void);
+lcg_para  lcg_hip_default_parameters(void);    /* util.h:153,163 */
+clcg_para clcg_hip_default_parameters(void);   /* util.h:278,287 */
+/* Facts about the most recent solve on this thread (liblcg reports them only through Pfp). */
+int    lcg_hip_last_iterations(void);
+double lcg_hip_last_residual(void);
+/* Mean device time of the A.x callback over the last solve, in microseconds, from HIP
+ * events recorded on the solver stream around each call; 0 unless profiling was enabled. */
+int    lcg_hip_set_profiling(int on);
+double lcg_hip_last_ax_mean_us(void);
+int    lcg_hip_last_ax_calls(void);
+
+/* ----------------------------------------------------------- solver entry */
+/* lcg.h:71-72 lcg_solver() -> lcg.cpp:59-82.  solver_id: LCG_CG, LCG_CGS, LCG_BICGSTAB;
+ * anything else runs CGS exactly as the reference's default branch does. */
+int lcg_hip_solver(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B,
+                   int n_size, const lcg_para *param, void *instance, int solver_id, int mem);
+/* lcg.h:90-91 lcg_solver_preconditioned() -> lpcg, lcg.cpp:293-434 (solver_id ignored, :90). */
+int lcg_hip_solver_preconditioned(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pfp,
+                                  double *m, const double *B, int n_size, const lcg_para *param,
+                                  void *instance, int solver_id, int mem);
+/* lcg.h:135-137 lcg() with caller workspaces (DEVICE pointers or NULL), lcg.cpp:143-274. */
+int lcg_hip_lcg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B, int n_size,
+                const lcg_para *param, void *instance, double *Gk, double *Dk, double *ADk, int mem);
+/* lcg.h:166-169 lcgs() with caller workspaces (DEVICE pointers or NULL), lcg.cpp:437-612. */
+int lcg_hip_lcgs(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B, int n_size,
+                 const lcg_para *param, void *instance, double *RK, double *R0T, double *PK,
+                 double *AX, double *UK, double *QK, double *WK, int mem);
+/* clcg.h:74-76 clcg_solver() -> clcg.cpp:46-74.  solver_id: CLCG_BICG_SYM, CLCG_CGS,
+ * CLCG_BICGSTAB, CLCG_TFQMR; CLCG_BICG (needs A^H.x) and unknown ids run CGS like the
+ * reference's default branch.  The shadow residual of CGS/BiCGStab/TFQMR is drawn from
+ * lcg_hip_set_shadow_seed() (default 1) instead of srand(time(0)) (lcg_complex.cpp:118-127). */
+int clcg_hip_solver(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, double *m, const double *B,
+                    int n_size, const clcg_para *param, void *instance, int solver_id, int mem);
+int lcg_hip_set_shadow_seed(unsigned seed);
+/* Replace the drawn shadow residual by an explicit vector (n complex, host memory) for the
+ * next complex solve only; lets a test replay the reference's own rbar0. */
+int lcg_hip_set_shadow_vector(const double *rbar0_host, int n_size);
+
+/* --------------------------------------------------------------- matrices */
+/* A CSR matrix resident in HBM: int32 rowptr[n+1] / col[nnz] (base 0), fp64 or c128 val.
+ * This is what the reference's GPU samples assemble with cusparseXcoo2csr +
+ * cusparseCreateCsr (sample8.cu:169-173, sample10.cu:177-181). */
+typedef struct lcg_hip_csr *lcg_hip_csr_t;
+
+/* Copy (mem == HOST, or DEVICE with adopt == 0) or adopt without copying (DEVICE, adopt != 0;
+ * the caller keeps the arrays alive) a CSR matrix.  is_complex: val holds interleaved c128. */
+int lcg_hip_csr_create(lcg_hip_csr_t *A, int n_rows, int n_cols, int64_t nnz, const int *rowptr,
+                       const int *col, const double *val, int is_complex, int mem, int adopt);
+/* COO (row-sorted or not) -> CSR on the device: data/README:1-10 files, sample8.cu:30-64,169. */
+int lcg_hip_csr_from_coo(lcg_hip_csr_t *A, int n, int64_t nnz, const int *row, const int *col,
+                         const double *val, int is_complex, int mem);
+int lcg_hip_csr_destroy(lcg_hip_csr_t A);
+int lcg_hip_csr_rows(lcg_hip_csr_t A);
+int64_t lcg_hip_csr_nnz(lcg_hip_csr_t A);
+/* Device pointers of the arrays (for callers that want to inspect or reuse them). */
+int lcg_hip_csr_arrays(lcg_hip_csr_t A, const int **rowptr, const int **col, const double **val);
+/* Select the SpMV kernel: 0 auto, otherwise lanes per row (2,4,...,64) for the
+ * wavefront kernel, or -1 for the LDS-staged variant. */
+int lcg_hip_csr_set_kernel(lcg_hip_csr_t A, int variant);
+/* Extract the diagonal and keep its reciprocal for lcg_hip_jacobi_mx
+ * (lcg_smDcsr_get_diagonal algebra_cuda.cu:40-57,85-92; clcg_smZcsr_get_diagonal
+ * lcg_complex_cuda.cu:46-63).  diag_out (device, n values) may be NULL. */
+int lcg_hip_csr_build_jacobi(lcg_hip_csr_t A, double *diag_out);
+
+/* Ready-made callbacks; pass the lcg_hip_csr_t as `instance`. */
+void lcg_hip_csr_ax(void *instance, const double *x, double *prod_Ax, const int n_size);      /* cudaAx, sample8.cu:96-103 */
+void lcg_hip_jacobi_mx(void *instance, const double *x, double *prod_Mx, const int n_size);   /* sample1.cpp:55-62 (z = x/diag, reciprocal form) */
+void clcg_hip_csr_ax(void *instance, const double *x, double *prod_Ax, const int n_size,
+                     int layout, int conjugate);                                                /* sample10.cu:90-97 */
+
+/* ---------------------------------------------------------------- kernels */
+/* Stand-alone launches of the hot-path kernels on the current stream (device pointers).
+ * Scalar results are written to host memory after a stream synchronise. */
+int lcg_hip_spmv(lcg_hip_csr_t A, const double *x, double *y);                  /* y = A.x */
+int lcg_hip_dot(int n, const double *a, const double *b, double *result);      /* lcg_dot, algebra.cpp:154-163; cublasDdot lcg_cuda.cu:187 */
+int lcg_hip_nrm2(int n, const double *a, double *result);                      /* cublasDznrm2-style 2-norm */
+int lcg_hip_axpy(int n, double alpha, const double *x, double *y);             /* y += alpha*x, cublasDaxpy lcg_cuda.cu:190 */
+int lcg_hip_scal(int n, double alpha, double *x);                              /* cublasDscal lcg_cuda.cu:203 */
+int lcg_hip_vecmul(int n, const double *a, const double *b, double *c);        /* lcg_vecMvecD_element_wise, algebra_cuda.cu:59-67 */
+int lcg_hip_vecdiv(int n, const double *a, const double *b, double *c);        /* lcg_vecDvecD_element_wise, algebra_cuda.cu:69-77 */
+int clcg_hip_dot(int n, const double *a, const double *b, double *result2);    /* clcg_dot (unconjugated), lcg_complex.cpp:143-154 */
+int clcg_hip_inner(int n, const double *a, const double *b, double *result2);  /* clcg_inner (conj a), lcg_complex.cpp:156-167 */
+int clcg_hip_axpy(int n, const double *alpha2, const double *x, double *y);    /* cublasZaxpy clcg_cuda.cu */
+int clcg_hip_vecdiv(int n, const double *a, const double *b, double *c);       /* clcg_vecDvecZ_element_wise, lcg_complex_cuda.cu:95-103 */
+
+/* ----------------------------------------------------- synthetic systems */
+/* The benchmark family of BASELINE.json configs 2-5 (definition: DESIGN.md, CPU twin:
+ * oracle/csr_oracle.c).  Rows [r0,r1) of the n-row matrix are generated on the device with
+ * GLOBAL column indices. band > 0: banded variant, band == 0: scrambled affine maps. */
+int lcg_hip_csr_generate(lcg_hip_csr_t *A, int64_t n, int npairs, int64_t band, int symmetric,
+                         uint64_t seed, double diag_shift, int64_t r0, int64_t r1);
+int lcg_hip_gen_xtrue(int64_t n, uint64_t seed, int64_t r0, int64_t r1, double *x_dev);
+/* 5-point Laplacian on an nx x ny grid (BASELINE.json config 2), rows [r0,r1). */
+int lcg_hip_csr_laplace2d(lcg_hip_csr_t *A, int nx, int ny, int64_t r0, int64_t r1);
+
+/* ------------------------------------------------------------ multi-GPU */
+/* One process per GPU.  The row range [r0,r1) of every vector and of A lives on this rank;
+ * A.x all-gathers x over RCCL, every inner product is summed with an RCCL all-reduce
+ * (nothing comparable exists in the reference: SURVEY.md sections 2 #22-23, 8e).
+ * Rendezvous: rank 0 calls lcg_hip_comm_unique_id(), ships the 128 bytes to the other
+ * ranks by any means (e.g. a torch.distributed broadcast), then all call comm_init. */
+int lcg_hip_comm_unique_id(void *id128);
+int lcg_hip_comm_init(int nranks, int rank, const void *id128);
+int lcg_hip_comm_destroy(void);
+int lcg_hip_comm_rank(void);
+int lcg_hip_comm_size(void);
+/* Bind a row shard (created with GLOBAL column indices over n_global columns) to the
+ * communicator: splits it into local-column and remote-column parts and sizes the gather
+ * buffer.  rows_per_rank = ceil(n_global / nranks); rank r owns rows
+ * [r*rows_per_rank, min(n_global,(r+1)*rows_per_rank)).  mode: 0 all-gather, 1 neighbour
+ * (halo) exchange of only the referenced entries. */
+int lcg_hip_csr_distribute(lcg_hip_csr_t A, int64_t n_global, int mode);
+int lcg_hip_allreduce_sum(double *dev_values, int count);
+int lcg_hip_barrier(void);
+/* Test hooks for the sharded product on ONE GPU: split a shard as rank `rank` of `nranks`
+ * with no communicator; the caller fills the other ranks' slices of the gather buffer
+ * (lcg_hip_csr_xfull) itself and then calls lcg_hip_spmv. */
+int lcg_hip_csr_split_for_test(lcg_hip_csr_t A, int64_t n_global, int nranks, int rank);
+double *lcg_hip_csr_xfull(lcg_hip_csr_t A);
+int64_t lcg_hip_csr_local_nnz(lcg_hip_csr_t A);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCG_HIP_H */

@@ -1,0 +1,275 @@
+// comm.hip -- row-sharded operation over RCCL (one process per GPU, xGMI underneath).
+//
+// Nothing like this exists in the reference (SURVEY.md sections 2 #22-23, 8e).  Layout:
+// rank r owns rows [r*rpr, min(N,(r+1)*rpr)), rpr = ceil(N/P), of A and of every vector.
+//   A.x   : the local x slices are all-gathered into xfull (P*rpr doubles; only the tail of
+//           the last slice is padding, so GLOBAL column indices address xfull directly).
+//           The shard is split once into entries with locally-owned columns and the rest:
+//           y = A_loc.x_loc runs on the compute stream WHILE the gather runs on a second
+//           stream; y += A_rem.xfull follows when the gather's event fires.
+//   dots  : k_scal reduces the local partials into DevState::red, one ncclAllReduce (sum,
+//           <= MAXR doubles) makes them global, the scalar recurrence continues on device.
+// RCCL is bound at run time (dlopen) so that the library loads on machines without it and
+// shares the copy already mapped by the host program (e.g. PyTorch's).
+#include <dlfcn.h>
+
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "devcommon.hpp"
+
+namespace lcgh {
+
+int device_exclusive_scan(int n, const int *counts, int *rowptr, hipStream_t s, long *total);   // csr.hip
+void free_part(CsrPart &P);                                                                     // csr.hip
+
+struct Comm {
+    void *lib = nullptr;
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static Comm g_comm;     // function table (valid once lib != nullptr)
+
+static int comm_fail(const char *what, ncclResult_t r)
+{
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "%s: %s", what, g_comm.GetErrorString ? g_comm.GetErrorString(r) : "rccl error");
+    ctx().err = buf;
+    return LCG_HIP_E_COMM;
+}
+
+static int load_rccl()
+{
+    if (g_comm.lib) return 0;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", nullptr};
+    void *h = nullptr;
+    // prefer a copy that is already mapped (RTLD_NOLOAD), then a fresh load
+    for (int pass = 0; pass < 2 && !h; pass++)
+        for (int i = 0; names[i] && !h; i++)
+            h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+    if (!h) { ctx().err = std::string("cannot load librccl: ") + dlerror(); return LCG_HIP_E_COMM; }
+    g_comm.lib = h;
+#define SYM(field, name)                                                         \
+    g_comm.field = reinterpret_cast<decltype(g_comm.field)>(dlsym(h, name));    \
+    if (!g_comm.field) { ctx().err = "librccl lacks " name; g_comm.lib = nullptr; return LCG_HIP_E_COMM; }
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(AllReduce, "ncclAllReduce")
+    SYM(AllGather, "ncclAllGather")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    return 0;
+}
+
+bool comm_active() { return g_comm.comm != nullptr && g_comm.nranks > 1; }
+
+int comm_allreduce(double *dev, int count, hipStream_t s)
+{
+    if (!g_comm.comm) return 0;
+    ncclResult_t r = g_comm.AllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, g_comm.comm, s);
+    if (r != ncclSuccess) return comm_fail("ncclAllReduce", r);
+    return 0;
+}
+
+// local row count summed over ranks (the N of the stop rule, lcg.cpp:208)
+double global_rows(Ctx &c, int n)
+{
+    if (!comm_active()) return (double)n;
+    double v = (double)n;
+    if (hipMemcpyAsync(c.state->red, &v, sizeof v, hipMemcpyHostToDevice, c.stream) != hipSuccess) return (double)n;
+    if (comm_allreduce(c.state->red, 1, c.stream)) return (double)n;
+    if (hipMemcpyAsync(&v, c.state->red, sizeof v, hipMemcpyDeviceToHost, c.stream) != hipSuccess) return (double)n;
+    hipStreamSynchronize(c.stream);
+    return v;
+}
+
+// ---- shard split ------------------------------------------------------------------------------
+__global__ void k_split_count(int n, long lo, long hi, const int *rowptr, const int *col, int *cl, int *cr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int a = 0;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) a += (col[k] >= lo && col[k] < hi);
+    cl[i] = a; cr[i] = rowptr[i + 1] - rowptr[i] - a;
+}
+template <class V>
+__global__ void k_split_fill(int n, long lo, long hi, const int *rowptr, const int *col, const V *val,
+                             const int *rpl, int *coll, V *vall, const int *rpr, int *colr, V *valr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int a = rpl[i], b = rpr[i];
+    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) {
+        const int c = col[k];
+        if (c >= lo && c < hi) { coll[a] = (int)(c - lo); vall[a++] = val[k]; }
+        else { colr[b] = c; valr[b++] = val[k]; }
+    }
+}
+
+static int alloc_cols(CsrPart &P, int n, long nnz, bool cplx)
+{
+    P.n_rows = n; P.nnz = nnz; P.owned = true;
+    HIPCHK(hipMalloc(&P.col, sizeof(int) * (size_t)(nnz > 0 ? nnz : 1) + 16));
+    HIPCHK(hipMalloc(&P.val, sizeof(double) * (cplx ? 2 : 1) * (size_t)(nnz > 0 ? nnz : 1) + 16));
+    return 0;
+}
+
+void dist_free(lcg_hip_csr *A)
+{
+    if (!A->distributed) return;
+    free_part(A->loc); free_part(A->rem);
+    if (A->xfull) hipFree(A->xfull);
+    A->xfull = nullptr; A->distributed = false;
+}
+
+// Split `main` (global columns) of a shard whose rows are [row0, row0+n_rows) into loc/rem.
+// Usable without a communicator (nranks given explicitly) so the split and the two-part
+// product can be tested on one GPU.
+int dist_split(lcg_hip_csr *A, int64_t n_global, int nranks, int rank)
+{
+    Ctx &c = ctx();
+    const int n = A->n_rows;
+    const int64_t rpr = (n_global + nranks - 1) / nranks;
+    const int64_t row0 = (int64_t)rank * rpr;
+    const int64_t expect = std::max<int64_t>(0, std::min<int64_t>(n_global, row0 + rpr) - row0);
+    if (expect != n) { c.err = "shard row count does not match ceil(n_global/nranks) partition"; return LCG_HIP_E_ARG; }
+    dist_free(A);
+    A->n_global = n_global; A->row0 = row0; A->rows_per_rank = rpr;
+    int *cl = nullptr, *cr = nullptr;
+    HIPCHK(hipMalloc(&cl, sizeof(int) * (size_t)n));
+    HIPCHK(hipMalloc(&cr, sizeof(int) * (size_t)n));
+    const unsigned g = (unsigned)((n + VB - 1) / VB);
+    hipLaunchKernelGGL(k_split_count, dim3(g), dim3(VB), 0, c.stream, n, (long)row0, (long)(row0 + n), A->main.rowptr, A->main.col, cl, cr);
+    long nl = 0, nr = 0;
+    HIPCHK(hipMalloc(&A->loc.rowptr, sizeof(int) * ((size_t)n + 1)));
+    HIPCHK(hipMalloc(&A->rem.rowptr, sizeof(int) * ((size_t)n + 1)));
+    int rc = device_exclusive_scan(n, cl, A->loc.rowptr, c.stream, &nl);
+    if (!rc) rc = device_exclusive_scan(n, cr, A->rem.rowptr, c.stream, &nr);
+    hipFree(cl); hipFree(cr);
+    if (rc) return rc;
+    rc = alloc_cols(A->loc, n, nl, A->is_complex); if (rc) return rc;
+    rc = alloc_cols(A->rem, n, nr, A->is_complex); if (rc) return rc;
+    if (A->is_complex)
+        hipLaunchKernelGGL((k_split_fill<double2>), dim3(g), dim3(VB), 0, c.stream, n, (long)row0, (long)(row0 + n), A->main.rowptr,
+                           A->main.col, reinterpret_cast<const double2 *>(A->main.val), A->loc.rowptr, A->loc.col,
+                           reinterpret_cast<double2 *>(A->loc.val), A->rem.rowptr, A->rem.col, reinterpret_cast<double2 *>(A->rem.val));
+    else
+        hipLaunchKernelGGL((k_split_fill<double>), dim3(g), dim3(VB), 0, c.stream, n, (long)row0, (long)(row0 + n), A->main.rowptr,
+                           A->main.col, A->main.val, A->loc.rowptr, A->loc.col, A->loc.val, A->rem.rowptr, A->rem.col, A->rem.val);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMalloc(&A->xfull, sizeof(double) * (A->is_complex ? 2 : 1) * (size_t)(rpr * nranks)));
+    HIPCHK(hipMemsetAsync(A->xfull, 0, sizeof(double) * (A->is_complex ? 2 : 1) * (size_t)(rpr * nranks), c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    A->distributed = true;
+    return 0;
+}
+
+int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
+{
+    Ctx &c = ctx();
+    const size_t w = A->is_complex ? 2 : 1;
+    const int *done = c.in_solve ? &c.state->done : nullptr;
+    double *mine = A->xfull + w * (size_t)(A->row0);
+    // gather on the second stream ...
+    HIPCHK(hipEventRecord(c.ev_a, c.stream));
+    HIPCHK(hipStreamWaitEvent(c.comm_stream, c.ev_a, 0));
+    HIPCHK(hipMemcpyAsync(mine, x, sizeof(double) * w * (size_t)A->n_rows, hipMemcpyDeviceToDevice, c.comm_stream));
+    if (g_comm.comm) {
+        ncclResult_t r = g_comm.AllGather(mine, A->xfull, w * (size_t)A->rows_per_rank, ncclDouble, g_comm.comm, c.comm_stream);
+        if (r != ncclSuccess) return comm_fail("ncclAllGather", r);
+    }
+    HIPCHK(hipEventRecord(c.ev_b, c.comm_stream));
+    // ... while the locally-owned columns are multiplied
+    const double mean_l = A->n_rows ? (double)A->loc.nnz / A->n_rows : 0.0;
+    int rc = spmv_launch(A->loc, A->is_complex, A->variant, mean_l, x, y, false, c.stream, done);
+    if (rc) return rc;
+    HIPCHK(hipStreamWaitEvent(c.stream, c.ev_b, 0));
+    if (A->rem.nnz > 0) {
+        const double mean_r = (double)A->rem.nnz / A->n_rows;
+        rc = spmv_launch(A->rem, A->is_complex, A->variant, mean_r, A->xfull, y, true, c.stream, done);
+    }
+    return rc;
+}
+
+} // namespace lcgh
+
+using namespace lcgh;
+
+extern "C" {
+
+int lcg_hip_comm_unique_id(void *id128)
+{
+    int rc = load_rccl(); if (rc) return rc;
+    ncclUniqueId id;
+    ncclResult_t r = g_comm.GetUniqueId(&id);
+    if (r != ncclSuccess) return comm_fail("ncclGetUniqueId", r);
+    static_assert(sizeof(ncclUniqueId) == 128, "unique id size");
+    std::memcpy(id128, &id, 128);
+    return 0;
+}
+
+int lcg_hip_comm_init(int nranks, int rank, const void *id128)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    rc = load_rccl(); if (rc) return rc;
+    if (g_comm.comm) return 0;
+    ncclUniqueId id;
+    std::memcpy(&id, id128, 128);
+    ncclResult_t r = g_comm.CommInitRank(&g_comm.comm, nranks, id, rank);
+    if (r != ncclSuccess) { g_comm.comm = nullptr; return comm_fail("ncclCommInitRank", r); }
+    g_comm.nranks = nranks; g_comm.rank = rank;
+    return 0;
+}
+
+int lcg_hip_comm_destroy(void)
+{
+    if (g_comm.comm) { g_comm.CommDestroy(g_comm.comm); g_comm.comm = nullptr; }
+    g_comm.nranks = 1; g_comm.rank = 0;
+    return 0;
+}
+
+int lcg_hip_comm_rank(void) { return g_comm.rank; }
+int lcg_hip_comm_size(void) { return g_comm.nranks; }
+
+int lcg_hip_csr_distribute(lcg_hip_csr_t A, int64_t n_global, int mode)
+{
+    if (!A || n_global <= 0) return LCG_HIP_E_ARG;
+    A->dist_mode = mode;
+    return dist_split(A, n_global, g_comm.nranks, g_comm.rank);
+}
+
+// test hook: split a shard as rank `rank` of `nranks` without any communicator; the caller
+// fills the gather buffer itself through lcg_hip_csr_xfull()
+int lcg_hip_csr_split_for_test(lcg_hip_csr_t A, int64_t n_global, int nranks, int rank)
+{
+    if (!A) return LCG_HIP_E_ARG;
+    return dist_split(A, n_global, nranks, rank);
+}
+double *lcg_hip_csr_xfull(lcg_hip_csr_t A) { return A ? A->xfull : nullptr; }
+int64_t lcg_hip_csr_local_nnz(lcg_hip_csr_t A) { return A ? A->loc.nnz : 0; }
+
+int lcg_hip_allreduce_sum(double *dev_values, int count)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    return comm_allreduce(dev_values, count, ctx().stream);
+}
+
+int lcg_hip_barrier(void)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    Ctx &c = ctx();
+    if (g_comm.comm) { rc = comm_allreduce(c.state->red + MAXR - 1, 1, c.stream); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,765 @@
+// csr.hip -- CSR matrices in HBM: A.x kernels, Jacobi, ingest (COO -> CSR) and the
+// on-device generators of the benchmark systems.
+//
+// A.x is the kernel the whole path is judged on: >= 80 % of the bytes of a CG iteration.
+// It is HBM-bound (0.17 flop/byte): no MFMA.  Two kernels:
+//
+//  k_spmv_lds<R,T>  (default)  One 256-thread block owns R consecutive rows (R*T = 256).
+//      Stage 1: the block's contiguous slice of val/col streams from HBM into LDS with
+//      16-byte-per-lane coalesced loads (the CSR arrays are read exactly once, at full
+//      width, whatever the row lengths).  Stage 2: lane (row = tid % R, j = tid / R) walks
+//      its row's entries j, j+T, ... out of LDS and gathers x; consecutive lanes hold
+//      consecutive ROWS, so for matrices with diagonal / stencil structure the x gather of a
+//      wavefront is one contiguous run, and for arbitrary columns it is no worse than any
+//      other mapping.  The T partial sums of a row meet in LDS; y is written coalesced.
+//  k_spmv_wave<T>   T consecutive lanes share a row (T = 64: wavefront per row), partial
+//      sums folded with __shfl_down.  Better for long rows (> ~100 entries).
+//
+// Algorithmic bytes: 12*nnz + 4*(N+1) + 8*N (x) + 8*N (y), real.
+#include <algorithm>
+#include <cstring>
+#include <functional>
+#include <numeric>
+
+#include "devcommon.hpp"
+
+namespace lcgh {
+
+// ------------------------------------------------------------------------------ value ops
+__device__ __forceinline__ double vzero(double) { return 0.0; }
+__device__ __forceinline__ double2 vzero(double2) { return make_double2(0.0, 0.0); }
+__device__ __forceinline__ double mac(double a, double x, double acc) { return fma(a, x, acc); }
+__device__ __forceinline__ double2 mac(double2 a, double2 x, double2 acc) { return cfma(a, x, acc); }
+__device__ __forceinline__ double shfl_down_v(double v, int off, int w) { return __shfl_down(v, off, w); }
+__device__ __forceinline__ double2 shfl_down_v(double2 v, int off, int w)
+{
+    return make_double2(__shfl_down(v.x, off, w), __shfl_down(v.y, off, w));
+}
+
+// ------------------------------------------------------------------- wave-per-row family
+template <class V, int T, bool ACC>
+__global__ __launch_bounds__(VB) void k_spmv_wave(int n, const int *__restrict__ rowptr,
+                                                  const int *__restrict__ col, const V *__restrict__ val,
+                                                  const V *__restrict__ x, V *__restrict__ y,
+                                                  const int *done)
+{
+    if (done && *done) return;
+    const int sub = threadIdx.x % T;
+    const long row = ((long)blockIdx.x * VB + threadIdx.x) / T;
+    V acc = vzero(V());
+    if (row < n) {
+        const int s = rowptr[row], e = rowptr[row + 1];
+        int k = s + sub;
+        // two independent gathers in flight per lane
+        for (; k + T < e; k += 2 * T) {
+            const int c0 = col[k], c1 = col[k + T];
+            const V a0 = val[k], a1 = val[k + T];
+            acc = mac(a0, x[c0], acc);
+            acc = mac(a1, x[c1], acc);
+        }
+        if (k < e) acc = mac(val[k], x[col[k]], acc);
+    }
+#pragma unroll
+    for (int off = T / 2; off > 0; off >>= 1) acc = vadd(acc, shfl_down_v(acc, off, T));
+    if (sub == 0 && row < n) y[row] = ACC ? vadd(y[row], acc) : acc;
+}
+
+// ----------------------------------------------------------------------- LDS-staged family
+constexpr int LDS_CH = 2304;    // entries staged per window (multiple of 4)
+
+template <class V, int R, bool ACC>
+__global__ __launch_bounds__(VB) void k_spmv_lds(int n, long nnz, const int *__restrict__ rowptr,
+                                                 const int *__restrict__ col, const V *__restrict__ val,
+                                                 const V *__restrict__ x, V *__restrict__ y,
+                                                 const int *done)
+{
+    constexpr int T = VB / R;
+    __shared__ V sval[LDS_CH];
+    __shared__ int scol[LDS_CH];
+    __shared__ V sred[T > 1 ? T : 1][R];
+    if (done && *done) return;
+
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * R;
+    const int nrows = min(R, n - row0);
+    const int rl = tid % R, j0 = tid / R;
+    const int s = rowptr[row0], e = rowptr[row0 + nrows];
+    int rs = 0, re = 0;
+    if (rl < nrows) { rs = rowptr[row0 + rl]; re = rowptr[row0 + rl + 1]; }
+    V acc = vzero(V());
+
+    for (int base = s & ~3; base < e; base += LDS_CH) {
+        const int cnt = min(LDS_CH, e - base);      // entries [base, base+cnt)
+        // ---- stage 1: 4 entries (16 B of col, 32/64 B of val) per lane per step
+        for (int u = tid * 4; u < cnt; u += VB * 4) {
+            const long g = (long)base + u;
+            if (g + 3 < nnz) {
+                const int4 c4 = *reinterpret_cast<const int4 *>(col + g);
+                *reinterpret_cast<int4 *>(scol + u) = c4;
+                if constexpr (sizeof(V) == 8) {
+                    const double2 v0 = *reinterpret_cast<const double2 *>(val + g);
+                    const double2 v1 = *reinterpret_cast<const double2 *>(val + g + 2);
+                    *reinterpret_cast<double2 *>(sval + u) = v0;
+                    *reinterpret_cast<double2 *>(sval + u + 2) = v1;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) sval[u + q] = val[g + q];
+                }
+            } else {
+                for (int q = 0; q < 4 && g + q < nnz; q++) { scol[u + q] = col[g + q]; sval[u + q] = val[g + q]; }
+            }
+        }
+        __syncthreads();
+        // ---- stage 2: my row's entries that sit in this window, stride T from rs + j0
+        const int lo = max(rs, base), hi = min(re, base + cnt);
+        int k = rs + j0;
+        if (k < lo) k += ((lo - k + T - 1) / T) * T;
+        for (; k + T < hi; k += 2 * T) {
+            const int c0 = scol[k - base], c1 = scol[k + T - base];
+            const V a0 = sval[k - base], a1 = sval[k + T - base];
+            acc = mac(a0, x[c0], acc);
+            acc = mac(a1, x[c1], acc);
+        }
+        if (k < hi) acc = mac(sval[k - base], x[scol[k - base]], acc);
+        __syncthreads();
+    }
+    if (T > 1) {
+        sred[j0][rl] = acc;
+        __syncthreads();
+        if (j0 == 0 && rl < nrows) {
+            V v = sred[0][rl];
+#pragma unroll
+            for (int j = 1; j < T; j++) v = vadd(v, sred[j][rl]);
+            y[row0 + rl] = ACC ? vadd(y[row0 + rl], v) : v;
+        }
+    } else if (rl < nrows) {
+        y[row0 + rl] = ACC ? vadd(y[row0 + rl], acc) : acc;
+    }
+}
+
+template <class V, bool ACC>
+static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V *x, V *y, hipStream_t s,
+                         const int *done)
+{
+    const int n = P.n_rows;
+    if (n == 0) return 0;
+    const V *val = reinterpret_cast<const V *>(P.val);
+    const bool al16 = (((uintptr_t)P.val | (uintptr_t)P.col) & 15) == 0;
+    if (variant == 0) {
+        if (!al16 || mean_row > 160.0) variant = mean_row > 48 ? 64 : (mean_row > 24 ? 32 : (mean_row > 12 ? 16 : 8));
+        else variant = -1;
+    }
+    if (variant < 0) {
+        if (!al16) return fail(hipErrorInvalidValue, "LDS-staged A.x needs 16-byte aligned col/val", __FILE__, __LINE__);
+        // rows per block so that R*mean_row entries fit one LDS window
+        int R = variant < -1 ? -variant : (mean_row <= 8.5 ? 256 : mean_row <= 17 ? 128 : mean_row <= 35 ? 64 : mean_row <= 70 ? 32 : 16);
+#define LDS_CASE(RR)                                                                                   \
+    case RR:                                                                                           \
+        hipLaunchKernelGGL((k_spmv_lds<V, RR, ACC>), dim3((n + RR - 1) / RR), dim3(VB), 0, s, n, (long)P.nnz, \
+                           P.rowptr, P.col, val, x, y, done);                                          \
+        break;
+        switch (R) {
+            LDS_CASE(256) LDS_CASE(128) LDS_CASE(64) LDS_CASE(32) LDS_CASE(16)
+        default: return fail(hipErrorInvalidValue, "bad LDS A.x rows-per-block", __FILE__, __LINE__);
+        }
+#undef LDS_CASE
+    } else {
+#define WAVE_CASE(TT)                                                                                  \
+    case TT: {                                                                                         \
+        const long threads = (long)n * TT;                                                             \
+        hipLaunchKernelGGL((k_spmv_wave<V, TT, ACC>), dim3((unsigned)((threads + VB - 1) / VB)), dim3(VB), 0, s, \
+                           n, P.rowptr, P.col, val, x, y, done);                                       \
+    } break;
+        switch (variant) {
+            WAVE_CASE(1) WAVE_CASE(2) WAVE_CASE(4) WAVE_CASE(8) WAVE_CASE(16) WAVE_CASE(32) WAVE_CASE(64)
+        default: return fail(hipErrorInvalidValue, "bad A.x lanes-per-row", __FILE__, __LINE__);
+        }
+#undef WAVE_CASE
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int spmv_launch(const CsrPart &P, bool is_complex, int variant, double mean_row, const double *x, double *y,
+                bool accumulate, hipStream_t s, const int *done)
+{
+    if (is_complex) {
+        auto xv = reinterpret_cast<const double2 *>(x);
+        auto yv = reinterpret_cast<double2 *>(y);
+        return accumulate ? spmv_dispatch<double2, true>(P, variant, mean_row, xv, yv, s, done)
+                          : spmv_dispatch<double2, false>(P, variant, mean_row, xv, yv, s, done);
+    }
+    return accumulate ? spmv_dispatch<double, true>(P, variant, mean_row, x, y, s, done)
+                      : spmv_dispatch<double, false>(P, variant, mean_row, x, y, s, done);
+}
+
+// ------------------------------------------------------------------------- Jacobi / diagonal
+// algebra_cuda.cu:40-57: scan the row for col == row (here with the row's GLOBAL index).
+template <class V>
+__global__ void k_diag(int n, long row0, const int *rowptr, const int *col, const V *val, V *diag, V *inv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V d = vzero(V());
+    for (int k = rowptr[i]; k < rowptr[i + 1]; k++)
+        if (col[k] == row0 + i) { d = val[k]; break; }
+    if (diag) diag[i] = d;
+    if (inv) {
+        if constexpr (sizeof(V) == 8) inv[i] = 1.0 / d;
+        else inv[i] = cdiv(make_double2(1.0, 0.0), d);
+    }
+}
+
+struct OpMul {      // c = a .* b      (lcg_vecMvecD_element_wise, algebra_cuda.cu:59-67)
+    static constexpr int NR = 0, SKIP = SKIP_NEVER;
+    DevState *st; const double *a, *b; double *c;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *) { st_(c, i, vmul(ld<T>(a, i), ld<T>(b, i))); }
+};
+struct OpDiv {      // c = a ./ b      (lcg_vecDvecD_element_wise, algebra_cuda.cu:69-77)
+    static constexpr int NR = 0, SKIP = SKIP_NEVER;
+    DevState *st; const double *a, *b; double *c;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *);
+};
+template <> __device__ void OpDiv::apply<double>(long i, double *) { c[i] = a[i] / b[i]; }
+template <> __device__ void OpDiv::apply<double2>(long i, double *)
+{
+    const double2 x = ld<double2>(a, i), y = ld<double2>(b, i);
+    st_(c, i, make_double2(x.x / y.x, x.y / y.y));
+}
+__global__ void k_cmul(long n, const double2 *a, const double2 *b, double2 *c)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        c[i] = cmul(a[i], b[i]);
+}
+__global__ void k_cdiv(long n, const double2 *a, const double2 *b, double2 *c)
+{   // vecDvecZ_element_wise_device, lcg_complex_cuda.cu:95-103 (cuCdiv)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        c[i] = cdiv(a[i], b[i]);
+}
+
+template <class Op> static int launch_vec(Op op, long n, uintptr_t align_or, hipStream_t s, double *partials)
+{
+    const bool v2 = (align_or & 15) == 0;
+    const int g = grid_for(v2 ? (n + 1) / 2 : n);
+    if (v2) hipLaunchKernelGGL((k_vec<Op, true>), dim3(g), dim3(VB), 0, s, op, n, partials);
+    else hipLaunchKernelGGL((k_vec<Op, false>), dim3(g), dim3(VB), 0, s, op, n, partials);
+    HIPCHK(hipGetLastError());
+    return g;
+}
+
+int jacobi_launch(const lcg_hip_csr *A, const double *x, double *z, int n, hipStream_t s)
+{
+    if (!A->invdiag) return fail(hipErrorInvalidValue, "lcg_hip_csr_build_jacobi() was not called", __FILE__, __LINE__);
+    if (A->is_complex) {
+        hipLaunchKernelGGL(k_cmul, dim3(grid_for(n)), dim3(VB), 0, s, (long)n,
+                           reinterpret_cast<const double2 *>(A->invdiag), reinterpret_cast<const double2 *>(x),
+                           reinterpret_cast<double2 *>(z));
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    int g = launch_vec(OpMul{nullptr, A->invdiag, x, z}, n, (uintptr_t)A->invdiag | (uintptr_t)x | (uintptr_t)z, s, nullptr);
+    return g < 0 ? g : 0;
+}
+
+// ------------------------------------------------------------------------------ device scan
+// exclusive scan of int counts -> rowptr[n+1] (three passes, 4096 items per block)
+constexpr int SCAN_ITEMS = 16;
+__global__ __launch_bounds__(VB) void k_scan_local(int n, const int *in, int *out, int *block_sums)
+{
+    __shared__ int sh[VB];
+    const int base = blockIdx.x * VB * SCAN_ITEMS + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; q++) { v[q] = base + q < n ? in[base + q] : 0; sum += v[q]; }
+    sh[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < VB; off <<= 1) {
+        int t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = sh[threadIdx.x] - sum;
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; q++) { if (base + q < n) out[base + q] = run; run += v[q]; }
+    if (threadIdx.x == VB - 1) block_sums[blockIdx.x] = sh[VB - 1];
+}
+__global__ void k_scan_blocks(int nb, int *block_sums, int *total_out)
+{   // one thread: nb is at most a few thousand
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int run = 0;
+        for (int b = 0; b < nb; b++) { int v = block_sums[b]; block_sums[b] = run; run += v; }
+        *total_out = run;
+    }
+}
+__global__ __launch_bounds__(VB) void k_scan_add(int n, int *out, const int *block_sums, const int *total)
+{
+    const int base = blockIdx.x * VB * SCAN_ITEMS + threadIdx.x * SCAN_ITEMS;
+    const int add = block_sums[blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; q++) if (base + q < n) out[base + q] += add;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+}
+
+int device_exclusive_scan(int n, const int *counts, int *rowptr, hipStream_t s, long *total)
+{
+    const int nb = (n + VB * SCAN_ITEMS - 1) / (VB * SCAN_ITEMS);
+    int *bs = nullptr;
+    HIPCHK(hipMalloc(&bs, sizeof(int) * (nb + 1)));
+    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(VB), 0, s, n, counts, rowptr, bs);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1), 0, s, nb, bs, bs + nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(VB), 0, s, n, rowptr, bs, bs + nb);
+    int tot = 0;
+    hipError_t e = hipMemcpyAsync(&tot, bs + nb, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(bs);
+    if (e != hipSuccess) return fail(e, "scan", __FILE__, __LINE__);
+    *total = tot;
+    return 0;
+}
+
+// ------------------------------------------------------------------------ synthetic family
+// Bit-for-bit twin of oracle/csr_oracle.c (orc_gen_*): integer hashing, ascending columns,
+// diagonal = sum of |off-diagonals| in column order + shift.
+struct GenParams {
+    long n; int npairs; long a[16], ainv[16], c[16]; int banded, symmetric; unsigned long long seed; double shift;
+};
+
+__host__ __device__ inline unsigned long long splitmix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline unsigned long long mix3(unsigned long long a, unsigned long long b, unsigned long long seed)
+{
+    return splitmix64(splitmix64(a ^ seed) + b * 0xD6E8FEB86659FD93ull);
+}
+__host__ __device__ inline double unit_open0(unsigned long long h) { return (double)((h >> 11) + 1) * (1.0 / 9007199254740992.0); }
+__host__ __device__ inline double unit_open1(unsigned long long h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
+
+__device__ inline unsigned long long mulmod(unsigned long long a, unsigned long long b, unsigned long long n)
+{   // a, b < n < 2^31 in practice; stay exact for anything below 2^63 via 128-bit product
+    return (unsigned long long)(((unsigned __int128)a * b) % n);
+}
+
+__device__ int gen_row_cols(const GenParams &g, long i, long *out)
+{
+    int cnt = 0;
+    for (int k = 0; k < g.npairs; k++) {
+        long j[2];
+        if (g.banded) { j[0] = i + g.c[k]; j[1] = i - g.c[k]; }
+        else {
+            j[0] = (long)((mulmod((unsigned long long)g.a[k], (unsigned long long)i, (unsigned long long)g.n) + (unsigned long long)g.c[k]) % (unsigned long long)g.n);
+            long d = i - g.c[k]; if (d < 0) d += g.n;
+            j[1] = (long)mulmod((unsigned long long)g.ainv[k], (unsigned long long)d, (unsigned long long)g.n);
+        }
+        for (int e = 0; e < 2; e++) {
+            const long cc = j[e];
+            if (cc < 0 || cc >= g.n || cc == i) continue;
+            bool dup = false;
+            for (int t = 0; t < cnt; t++) if (out[t] == cc) { dup = true; break; }
+            if (dup) continue;
+            int pos = cnt;
+            while (pos > 0 && out[pos - 1] > cc) { out[pos] = out[pos - 1]; pos--; }
+            out[pos] = cc; cnt++;
+        }
+    }
+    return cnt;
+}
+
+__global__ void k_gen_count(GenParams g, long r0, long r1, int *counts)
+{
+    const long i = r0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r1) return;
+    long tmp[32];
+    counts[i - r0] = gen_row_cols(g, i, tmp) + 1;
+}
+
+__global__ void k_gen_fill(GenParams g, long r0, long r1, const int *rowptr, int *col, double *val)
+{
+    const long i = r0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r1) return;
+    long tmp[32];
+    const int cnt = gen_row_cols(g, i, tmp);
+    const int base = rowptr[i - r0];
+    int w = 0, dpos = -1;
+    double sum = 0.0;
+    for (int t = 0; t < cnt; t++) {
+        if (dpos < 0 && tmp[t] > i) { dpos = base + w; w++; }
+        const long j = tmp[t];
+        const unsigned long long h = g.symmetric ? mix3((unsigned long long)(i < j ? i : j), (unsigned long long)(i < j ? j : i), g.seed)
+                                                 : mix3((unsigned long long)i, (unsigned long long)j, g.seed);
+        const double v = -unit_open0(h);
+        col[base + w] = (int)j; val[base + w] = v; w++;
+        sum += -v;
+    }
+    if (dpos < 0) { dpos = base + w; w++; }
+    col[dpos] = (int)i;
+    val[dpos] = sum + g.shift;
+}
+
+__global__ void k_gen_xtrue(unsigned long long seed, long r0, long r1, double *x)
+{
+    const long i = r0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < r1) x[i - r0] = unit_open1(mix3((unsigned long long)i, 0x7265757274ull, seed));
+}
+
+static long gcd64(long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; }
+static long modinv(long a, long n)
+{
+    long t = 0, nt = 1, r = n, nr = a % n;
+    while (nr) { long q = r / nr, tmp = t - q * nt; t = nt; nt = tmp; tmp = r - q * nr; r = nr; nr = tmp; }
+    return t < 0 ? t + n : t;
+}
+
+static void gen_init(GenParams &g, long n, int npairs, long band, int symmetric, unsigned long long seed, double shift)
+{   // same draws as orc_gen_init
+    std::memset(&g, 0, sizeof g);
+    g.n = n; g.npairs = npairs > 16 ? 16 : npairs; g.banded = band > 0; g.symmetric = symmetric; g.seed = seed; g.shift = shift;
+    unsigned long long s = splitmix64(seed ^ 0xA5A5A5A55A5A5A5Aull);
+    if (band > n - 1) band = n - 1;
+    if (band < 1) band = 1;
+    for (int k = 0; k < g.npairs; k++) {
+        if (g.banded) {
+            long c = 1;
+            for (int tries = 0; tries < 64; tries++) {
+                s = splitmix64(s);
+                c = (k == 0 || band < 2) ? 1 : 2 + (long)(s % (unsigned long long)(band - 1));
+                bool dup = false;
+                for (int j = 0; j < k; j++) if (g.c[j] == c) dup = true;
+                if (!dup) break;
+            }
+            g.a[k] = 1; g.ainv[k] = 1; g.c[k] = c;
+        } else {
+            long a;
+            do { s = splitmix64(s); a = 2 + (long)(s % (unsigned long long)(n > 3 ? n - 2 : 1)); } while (gcd64(a, n) != 1);
+            s = splitmix64(s);
+            g.a[k] = a; g.ainv[k] = modinv(a, n); g.c[k] = (long)(s % (unsigned long long)n);
+        }
+    }
+}
+
+// 5-point Laplacian, grid nx*ny, row-major numbering, diag 4 / off-diag -1
+__global__ void k_lap_count(int nx, int ny, long r0, long r1, int *counts)
+{
+    const long i = r0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r1) return;
+    const int ix = (int)(i % nx), iy = (int)(i / nx);
+    counts[i - r0] = 1 + (ix > 0) + (ix < nx - 1) + (iy > 0) + (iy < ny - 1);
+}
+__global__ void k_lap_fill(int nx, int ny, long r0, long r1, const int *rowptr, int *col, double *val)
+{
+    const long i = r0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r1) return;
+    const int ix = (int)(i % nx), iy = (int)(i / nx);
+    int k = rowptr[i - r0];
+    if (iy > 0) { col[k] = (int)(i - nx); val[k++] = -1.0; }
+    if (ix > 0) { col[k] = (int)(i - 1); val[k++] = -1.0; }
+    col[k] = (int)i; val[k++] = 4.0;
+    if (ix < nx - 1) { col[k] = (int)(i + 1); val[k++] = -1.0; }
+    if (iy < ny - 1) { col[k] = (int)(i + nx); val[k++] = -1.0; }
+}
+
+// ------------------------------------------------------------------------------ COO ingest
+__global__ void k_coo_sorted(long nnz, const int *row, int *unsorted_flag)
+{
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k + 1 < nnz && row[k] > row[k + 1]) *unsorted_flag = 1;
+}
+__global__ void k_coo_rowptr(long nnz, int n, const int *row, int *rowptr)
+{   // row-sorted COO: rowptr[r] = first k with row[k] >= r
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nnz) return;
+    const int prev = k == 0 ? -1 : row[k - 1];
+    const int cur = k == nnz ? n : row[k];
+    for (int r = prev + 1; r <= cur; r++) rowptr[r] = (int)k;
+}
+
+static int alloc_part(CsrPart &P, int n_rows, long nnz, bool cplx)
+{
+    P.n_rows = n_rows; P.nnz = nnz; P.owned = true;
+    HIPCHK(hipMalloc(&P.rowptr, sizeof(int) * ((size_t)n_rows + 1)));
+    HIPCHK(hipMalloc(&P.col, sizeof(int) * (size_t)std::max<long>(nnz, 1) + 16));
+    HIPCHK(hipMalloc(&P.val, sizeof(double) * (cplx ? 2 : 1) * (size_t)std::max<long>(nnz, 1) + 16));
+    return 0;
+}
+
+void free_part(CsrPart &P)
+{
+    if (P.owned) { hipFree(P.rowptr); hipFree(P.col); hipFree(P.val); }
+    P = CsrPart();
+}
+
+} // namespace lcgh
+
+using namespace lcgh;
+
+namespace lcgh { void dist_free(lcg_hip_csr *A); }
+
+extern "C" {
+
+int lcg_hip_csr_create(lcg_hip_csr_t *out, int n_rows, int n_cols, int64_t nnz, const int *rowptr, const int *col,
+                       const double *val, int is_complex, int mem, int adopt)
+{
+    if (!out || n_rows <= 0 || nnz < 0 || nnz > 0x7fffffffLL || !rowptr || !col || !val) return LCG_HIP_E_ARG;
+    int rc = ensure_init(); if (rc) return rc;
+    Ctx &c = ctx();
+    lcg_hip_csr *A = new lcg_hip_csr();
+    A->n_rows = n_rows; A->n_cols = n_cols; A->is_complex = is_complex != 0;
+    A->mean_row = (double)nnz / n_rows;
+    if (mem == LCG_HIP_MEM_DEVICE && adopt) {
+        A->main.n_rows = n_rows; A->main.nnz = nnz; A->main.owned = false;
+        A->main.rowptr = const_cast<int *>(rowptr); A->main.col = const_cast<int *>(col); A->main.val = const_cast<double *>(val);
+    } else {
+        rc = alloc_part(A->main, n_rows, nnz, A->is_complex);
+        if (rc) { delete A; return rc; }
+        const hipMemcpyKind kind = mem == LCG_HIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        hipError_t e = hipMemcpyAsync(A->main.rowptr, rowptr, sizeof(int) * ((size_t)n_rows + 1), kind, c.stream);
+        if (e == hipSuccess && nnz) e = hipMemcpyAsync(A->main.col, col, sizeof(int) * (size_t)nnz, kind, c.stream);
+        if (e == hipSuccess && nnz) e = hipMemcpyAsync(A->main.val, val, sizeof(double) * (is_complex ? 2 : 1) * (size_t)nnz, kind, c.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+        if (e != hipSuccess) { free_part(A->main); delete A; return fail(e, "csr upload", __FILE__, __LINE__); }
+    }
+    *out = A;
+    return 0;
+}
+
+int lcg_hip_csr_from_coo(lcg_hip_csr_t *out, int n, int64_t nnz, const int *row, const int *col, const double *val,
+                         int is_complex, int mem)
+{
+    if (!out || n <= 0 || nnz <= 0 || nnz > 0x7fffffffLL || !row || !col || !val) return LCG_HIP_E_ARG;
+    int rc = ensure_init(); if (rc) return rc;
+    Ctx &c = ctx();
+    const size_t vw = is_complex ? 2 : 1;
+    lcg_hip_csr *A = new lcg_hip_csr();
+    A->n_rows = n; A->n_cols = n; A->is_complex = is_complex != 0; A->mean_row = (double)nnz / n;
+    rc = alloc_part(A->main, n, nnz, A->is_complex);
+    if (rc) { delete A; return rc; }
+    int *d_row = nullptr, *d_flag = nullptr;
+    const hipMemcpyKind kind = mem == LCG_HIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    auto bail = [&](int code) { if (d_row) hipFree(d_row); if (d_flag) hipFree(d_flag); free_part(A->main); delete A; return code; };
+    if (hipMalloc(&d_row, sizeof(int) * (size_t)nnz) != hipSuccess || hipMalloc(&d_flag, sizeof(int)) != hipSuccess)
+        return bail(fail(hipErrorOutOfMemory, "coo staging", __FILE__, __LINE__));
+    hipError_t e = hipMemcpyAsync(d_row, row, sizeof(int) * (size_t)nnz, kind, c.stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, sizeof(int), c.stream);
+    if (e != hipSuccess) return bail(fail(e, "coo upload", __FILE__, __LINE__));
+    const unsigned gb = (unsigned)((nnz + 1 + VB - 1) / VB);
+    hipLaunchKernelGGL(k_coo_sorted, dim3(gb), dim3(VB), 0, c.stream, (long)nnz, d_row, d_flag);
+    int unsorted = 0;
+    e = hipMemcpyAsync(&unsorted, d_flag, sizeof(int), hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    if (e != hipSuccess) return bail(fail(e, "coo sortedness", __FILE__, __LINE__));
+    if (!unsorted) {
+        // the bundled files are row-major sorted: entries stay in place
+        hipLaunchKernelGGL(k_coo_rowptr, dim3(gb), dim3(VB), 0, c.stream, (long)nnz, n, d_row, A->main.rowptr);
+        e = hipMemcpyAsync(A->main.col, col, sizeof(int) * (size_t)nnz, kind, c.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(A->main.val, val, sizeof(double) * vw * (size_t)nnz, kind, c.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+        if (e != hipSuccess) return bail(fail(e, "coo copy", __FILE__, __LINE__));
+    } else {
+        // unsorted input: stable counting sort by row on the host, then upload
+        std::vector<int> hrow((size_t)nnz), hcol((size_t)nnz);
+        std::vector<double> hval((size_t)nnz * vw);
+        const hipMemcpyKind back = mem == LCG_HIP_MEM_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyHostToHost;
+        e = hipMemcpy(hrow.data(), row, sizeof(int) * (size_t)nnz, back);
+        if (e == hipSuccess) e = hipMemcpy(hcol.data(), col, sizeof(int) * (size_t)nnz, back);
+        if (e == hipSuccess) e = hipMemcpy(hval.data(), val, sizeof(double) * vw * (size_t)nnz, back);
+        if (e != hipSuccess) return bail(fail(e, "coo fetch", __FILE__, __LINE__));
+        std::vector<int> rp((size_t)n + 1, 0), scol((size_t)nnz);
+        std::vector<double> sval((size_t)nnz * vw);
+        for (int64_t k = 0; k < nnz; k++) {
+            if (hrow[k] < 0 || hrow[k] >= n) return bail(LCG_HIP_E_ARG);
+            rp[hrow[k] + 1]++;
+        }
+        for (int i = 0; i < n; i++) rp[i + 1] += rp[i];
+        std::vector<int> next(rp.begin(), rp.end() - 1);
+        for (int64_t k = 0; k < nnz; k++) {
+            const int p = next[hrow[k]]++;
+            scol[p] = hcol[k];
+            for (size_t q = 0; q < vw; q++) sval[(size_t)p * vw + q] = hval[(size_t)k * vw + q];
+        }
+        e = hipMemcpy(A->main.rowptr, rp.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(A->main.col, scol.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(A->main.val, sval.data(), sizeof(double) * vw * (size_t)nnz, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return bail(fail(e, "coo sorted upload", __FILE__, __LINE__));
+    }
+    hipFree(d_row); hipFree(d_flag);
+    *out = A;
+    return 0;
+}
+
+int lcg_hip_csr_destroy(lcg_hip_csr_t A)
+{
+    if (!A) return 0;
+    dist_free(A);
+    free_part(A->main);
+    if (A->invdiag) hipFree(A->invdiag);
+    delete A;
+    return 0;
+}
+
+int lcg_hip_csr_rows(lcg_hip_csr_t A) { return A ? A->n_rows : 0; }
+int64_t lcg_hip_csr_nnz(lcg_hip_csr_t A) { return A ? A->main.nnz : 0; }
+int lcg_hip_csr_arrays(lcg_hip_csr_t A, const int **rowptr, const int **col, const double **val)
+{
+    if (!A) return LCG_HIP_E_ARG;
+    if (rowptr) *rowptr = A->main.rowptr;
+    if (col) *col = A->main.col;
+    if (val) *val = A->main.val;
+    return 0;
+}
+int lcg_hip_csr_set_kernel(lcg_hip_csr_t A, int variant)
+{
+    if (!A) return LCG_HIP_E_ARG;
+    A->variant = variant;
+    return 0;
+}
+
+int lcg_hip_csr_build_jacobi(lcg_hip_csr_t A, double *diag_out)
+{
+    if (!A) return LCG_HIP_E_ARG;
+    Ctx &c = ctx();
+    const size_t w = A->is_complex ? 2 : 1;
+    if (!A->invdiag) HIPCHK(hipMalloc(&A->invdiag, sizeof(double) * w * (size_t)A->n_rows));
+    const unsigned g = (unsigned)((A->n_rows + VB - 1) / VB);
+    if (A->is_complex)
+        hipLaunchKernelGGL((k_diag<double2>), dim3(g), dim3(VB), 0, c.stream, A->n_rows, (long)A->row0, A->main.rowptr, A->main.col,
+                           reinterpret_cast<const double2 *>(A->main.val), reinterpret_cast<double2 *>(diag_out),
+                           reinterpret_cast<double2 *>(A->invdiag));
+    else
+        hipLaunchKernelGGL((k_diag<double>), dim3(g), dim3(VB), 0, c.stream, A->n_rows, (long)A->row0, A->main.rowptr, A->main.col,
+                           A->main.val, diag_out, A->invdiag);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- callbacks -------------------------------------------------------------------------------
+void lcg_hip_csr_ax(void *instance, const double *x, double *y, const int n)
+{
+    lcg_hip_csr *A = static_cast<lcg_hip_csr *>(instance);
+    (void)n;
+    lcg_hip_spmv(A, x, y);
+}
+
+void clcg_hip_csr_ax(void *instance, const double *x, double *y, const int n, int layout, int conjugate)
+{
+    (void)layout; (void)conjugate; (void)n;
+    lcg_hip_spmv(static_cast<lcg_hip_csr *>(instance), x, y);
+}
+
+void lcg_hip_jacobi_mx(void *instance, const double *x, double *z, const int n)
+{
+    jacobi_launch(static_cast<lcg_hip_csr *>(instance), x, z, n, ctx().stream);
+}
+
+int lcg_hip_spmv(lcg_hip_csr_t A, const double *x, double *y)
+{
+    if (!A || !x || !y) return LCG_HIP_E_ARG;
+    Ctx &c = ctx();
+    if (A->distributed) return dist_spmv(A, x, y);
+    return spmv_launch(A->main, A->is_complex, A->variant, A->mean_row, x, y, false, c.stream,
+                       c.in_solve ? &c.state->done : nullptr);
+}
+
+int lcg_hip_vecmul(int n, const double *a, const double *b, double *out)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    int g = launch_vec(OpMul{nullptr, a, b, out}, n, (uintptr_t)a | (uintptr_t)b | (uintptr_t)out, ctx().stream, nullptr);
+    return g < 0 ? g : 0;
+}
+int lcg_hip_vecdiv(int n, const double *a, const double *b, double *out)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    int g = launch_vec(OpDiv{nullptr, a, b, out}, n, (uintptr_t)a | (uintptr_t)b | (uintptr_t)out, ctx().stream, nullptr);
+    return g < 0 ? g : 0;
+}
+int clcg_hip_vecdiv(int n, const double *a, const double *b, double *out)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    hipLaunchKernelGGL(k_cdiv, dim3(grid_for(n)), dim3(VB), 0, ctx().stream, (long)n, reinterpret_cast<const double2 *>(a),
+                       reinterpret_cast<const double2 *>(b), reinterpret_cast<double2 *>(out));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- generators ----------------------------------------------------------------------------------
+static int finish_generated(lcg_hip_csr *A, int nloc, long r0, int *counts, hipStream_t s,
+                            const std::function<void(const int *, int *, double *)> &fill)
+{
+    long total = 0;
+    int *rowptr = nullptr;
+    hipError_t e = hipMalloc(&rowptr, sizeof(int) * ((size_t)nloc + 1));
+    if (e != hipSuccess) { hipFree(counts); return fail(e, "rowptr", __FILE__, __LINE__); }
+    int rc = device_exclusive_scan(nloc, counts, rowptr, s, &total);
+    hipFree(counts);
+    if (rc) { hipFree(rowptr); return rc; }
+    A->main.n_rows = nloc; A->main.nnz = total; A->main.owned = true; A->main.rowptr = rowptr;
+    e = hipMalloc(&A->main.col, sizeof(int) * (size_t)total + 16);
+    if (e == hipSuccess) e = hipMalloc(&A->main.val, sizeof(double) * (size_t)total + 16);
+    if (e != hipSuccess) return fail(e, "generated arrays", __FILE__, __LINE__);
+    fill(rowptr, A->main.col, A->main.val);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    A->mean_row = (double)total / nloc;
+    A->row0 = r0;
+    return 0;
+}
+
+int lcg_hip_csr_generate(lcg_hip_csr_t *out, int64_t n, int npairs, int64_t band, int symmetric, uint64_t seed,
+                         double diag_shift, int64_t r0, int64_t r1)
+{
+    if (!out || n <= 1 || n > 0x7fffffffLL || r0 < 0 || r1 > n || r1 <= r0 || npairs < 1) return LCG_HIP_E_ARG;
+    int rc = ensure_init(); if (rc) return rc;
+    Ctx &c = ctx();
+    GenParams g; gen_init(g, n, npairs, band, symmetric, seed, diag_shift);
+    const int nloc = (int)(r1 - r0);
+    int *counts = nullptr;
+    HIPCHK(hipMalloc(&counts, sizeof(int) * (size_t)nloc));
+    const unsigned gb = (unsigned)((nloc + VB - 1) / VB);
+    hipLaunchKernelGGL(k_gen_count, dim3(gb), dim3(VB), 0, c.stream, g, (long)r0, (long)r1, counts);
+    lcg_hip_csr *A = new lcg_hip_csr();
+    A->n_rows = nloc; A->n_cols = (int)n; A->is_complex = false;
+    rc = finish_generated(A, nloc, r0, counts, c.stream, [&](const int *rp, int *col, double *val) {
+        hipLaunchKernelGGL(k_gen_fill, dim3(gb), dim3(VB), 0, c.stream, g, (long)r0, (long)r1, rp, col, val);
+    });
+    if (rc) { free_part(A->main); delete A; return rc; }
+    *out = A;
+    return 0;
+}
+
+int lcg_hip_gen_xtrue(int64_t n, uint64_t seed, int64_t r0, int64_t r1, double *x_dev)
+{
+    if (r0 < 0 || r1 > n || r1 <= r0 || !x_dev) return LCG_HIP_E_ARG;
+    int rc = ensure_init(); if (rc) return rc;
+    const unsigned gb = (unsigned)((r1 - r0 + VB - 1) / VB);
+    hipLaunchKernelGGL(k_gen_xtrue, dim3(gb), dim3(VB), 0, ctx().stream, (unsigned long long)seed, (long)r0, (long)r1, x_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int lcg_hip_csr_laplace2d(lcg_hip_csr_t *out, int nx, int ny, int64_t r0, int64_t r1)
+{
+    const int64_t n = (int64_t)nx * ny;
+    if (!out || nx < 1 || ny < 1 || n > 0x7fffffffLL || r0 < 0 || r1 > n || r1 <= r0) return LCG_HIP_E_ARG;
+    int rc = ensure_init(); if (rc) return rc;
+    Ctx &c = ctx();
+    const int nloc = (int)(r1 - r0);
+    int *counts = nullptr;
+    HIPCHK(hipMalloc(&counts, sizeof(int) * (size_t)nloc));
+    const unsigned gb = (unsigned)((nloc + VB - 1) / VB);
+    hipLaunchKernelGGL(k_lap_count, dim3(gb), dim3(VB), 0, c.stream, nx, ny, (long)r0, (long)r1, counts);
+    lcg_hip_csr *A = new lcg_hip_csr();
+    A->n_rows = nloc; A->n_cols = (int)n; A->is_complex = false;
+    rc = finish_generated(A, nloc, r0, counts, c.stream, [&](const int *rp, int *col, double *val) {
+        hipLaunchKernelGGL(k_lap_fill, dim3(gb), dim3(VB), 0, c.stream, nx, ny, (long)r0, (long)r1, rp, col, val);
+    });
+    if (rc) { free_part(A->main); delete A; return rc; }
+    *out = A;
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,201 @@
+// devcommon.hpp -- device-side building blocks shared by the real and complex kernels.
+//
+// Shape of the BLAS-1 side of the iteration (all HBM-bound, no MFMA):
+//   * k_vec<Op>: one fused element-wise pass over the vectors an iteration step touches,
+//     16 B per lane per access, grid-stride over <= MAXG blocks, with up to MAXR running sums
+//     reduced wave (shuffle) -> block (LDS) -> one partial per block in a fixed table.
+//   * k_scal<Fin>: one block that sums the partials in a fixed order (bit-reproducible, no
+//     atomics), then a single lane runs the solver's scalar recurrence on DevState.  When
+//     the rows are sharded over ranks the same kernel runs in two halves around an RCCL
+//     all-reduce of DevState::red.
+// Coefficients (alpha, beta, ...) are read by the vector kernels from DevState, so the host
+// never waits for a scalar inside the loop.
+#pragma once
+
+#include "internal.hpp"
+
+namespace lcgh {
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Reduce NR per-thread accumulators over the block; thread r (< NR) ends up with sum r and
+// writes it to partials[r*MAXG + blockIdx.x].
+template <int NR>
+__device__ __forceinline__ void block_reduce_store(double *acc, double *partials)
+{
+    __shared__ double sh[NR][VB / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        double v = wave_sum(acc[r]);
+        if (lane == 0) sh[r][w] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NR) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < VB / 64; k++) v += sh[threadIdx.x][k];
+        partials[threadIdx.x * MAXG + blockIdx.x] = v;
+    }
+}
+
+// skip rules shared by every kernel of the loop
+//  SKIP_DONE: no-op once the stop flag is set
+//  SKIP_DIR : the direction update that closes an iteration still runs in the iteration that
+//             converged (as the reference does before it re-tests at the loop head), but not
+//             after a NaN stop and not in later, already-void iterations
+enum { SKIP_NEVER = 0, SKIP_DONE = 1, SKIP_DIR = 2 };
+
+__device__ __forceinline__ bool should_skip(const DevState *st, int mode)
+{
+    if (mode == SKIP_NEVER) return false;
+    const int done = st->done;
+    if (mode == SKIP_DONE) return done != 0;
+    if (!done) return false;
+    return st->status == ST_NAN || st->it != st->t;
+}
+
+// ---- generic fused vector pass ----------------------------------------------------------
+// Op provides:  static constexpr int NR, SKIP;  DevState *st;  void prep();  (loads scalars)
+//               template<class T> void apply(long i, double *acc);   T = double2 (two reals /
+//               one complex) or double (scalar tail, real only)
+template <class Op, bool VEC2>
+__global__ __launch_bounds__(VB) void k_vec(Op op, long n, double *partials)
+{
+    if (should_skip(op.st, Op::SKIP)) return;
+    constexpr int NRA = Op::NR > 0 ? Op::NR : 1;
+    double acc[NRA];
+#pragma unroll
+    for (int r = 0; r < NRA; r++) acc[r] = 0.0;
+    op.prep();
+    const long stride = (long)gridDim.x * VB;
+    const long tid = (long)blockIdx.x * VB + threadIdx.x;
+    if (VEC2) {
+        const long n2 = n >> 1;
+        for (long i = tid; i < n2; i += stride) op.template apply<double2>(i, acc);
+        if ((n & 1) && tid == 0) op.template apply<double>(n - 1, acc);
+    } else {
+        for (long i = tid; i < n; i += stride) op.template apply<double>(i, acc);
+    }
+    if (Op::NR > 0) block_reduce_store<NRA>(acc, partials);
+}
+
+template <class T> __device__ __forceinline__ T ld(const double *p, long i);
+template <> __device__ __forceinline__ double ld<double>(const double *p, long i) { return p[i]; }
+template <> __device__ __forceinline__ double2 ld<double2>(const double *p, long i)
+{
+    return reinterpret_cast<const double2 *>(p)[i];
+}
+__device__ __forceinline__ void st_(double *p, long i, double v) { p[i] = v; }
+__device__ __forceinline__ void st_(double *p, long i, double2 v) { reinterpret_cast<double2 *>(p)[i] = v; }
+
+// real helpers on 1 or 2 packed values
+__device__ __forceinline__ double dotp(double a, double b) { return a * b; }
+__device__ __forceinline__ double dotp(double2 a, double2 b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ double nanflag(double a) { return a != a ? 1.0 : 0.0; }
+__device__ __forceinline__ double nanflag(double2 a) { return (a.x != a.x || a.y != a.y) ? 1.0 : 0.0; }
+__device__ __forceinline__ double2 operator*(double s, double2 v) { return make_double2(s * v.x, s * v.y); }
+__device__ __forceinline__ double2 vadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 vsub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double vadd(double a, double b) { return a + b; }
+__device__ __forceinline__ double vsub(double a, double b) { return a - b; }
+__device__ __forceinline__ double2 vmul(double2 a, double2 b) { return make_double2(a.x * b.x, a.y * b.y); }
+__device__ __forceinline__ double vmul(double a, double b) { return a * b; }
+__device__ __forceinline__ double2 vneg(double2 a) { return make_double2(-a.x, -a.y); }
+__device__ __forceinline__ double vneg(double a) { return -a; }
+
+// complex helpers (double2 = re, im)
+__device__ __forceinline__ double2 cmul(double2 a, double2 b)
+{
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cfma(double2 a, double2 b, double2 c)   // a*b + c
+{
+    return make_double2(fma(a.x, b.x, fma(-a.y, b.y, c.x)), fma(a.x, b.y, fma(a.y, b.x, c.y)));
+}
+// robust complex division (Smith's algorithm): avoids the overflow of |b|^2
+__device__ __forceinline__ double2 cdiv(double2 a, double2 b)
+{
+    if (fabs(b.x) >= fabs(b.y)) {
+        const double r = b.y / b.x, d = b.x + b.y * r;
+        return make_double2((a.x + a.y * r) / d, (a.y - a.x * r) / d);
+    }
+    const double r = b.x / b.y, d = b.x * r + b.y;
+    return make_double2((a.x * r + a.y) / d, (a.y * r - a.x) / d);
+}
+__device__ __forceinline__ double cnorm(double2 a) { return a.x * a.x + a.y * a.y; }
+
+// ---- scalar step ----------------------------------------------------------------------------
+// mode 0: reduce partials and run fin (single GPU)   1: reduce only -> st->red
+// mode 2: fin only, sums taken from st->red (after the all-reduce)
+enum { SC_FUSED = 0, SC_REDUCE = 1, SC_FIN = 2 };
+
+__device__ __forceinline__ void publish(DevState *st)
+{
+    HostStatus *h = st->host;
+    h->residual = st->residual;
+    h->t = st->t;
+    h->done = st->done;
+    h->status = st->status;
+    __threadfence_system();
+    h->it = st->it;
+}
+
+// stop rule evaluated for the NEXT loop head (lcg.cpp:208-222): g2, m2 as the solver defines them
+__device__ __forceinline__ void stop_rule(DevState *st, double g2, double m2)
+{
+    const double r = st->abs_diff ? sqrt(g2) / st->n_global : g2 / m2;
+    st->residual = r;
+    if (r <= st->eps) { st->done = 1; st->status = ST_CONVERGED; }
+}
+
+template <class Fin>
+__global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, int G, DevState *st, int mode)
+{
+    constexpr int NRA = Fin::NR > 0 ? Fin::NR : 1;
+    __shared__ double sums[NRA];
+    if (mode != SC_FIN && Fin::NR > 0) {
+        double acc[NRA];
+#pragma unroll
+        for (int r = 0; r < NRA; r++) {
+            double v = 0.0;
+            for (int j = threadIdx.x; j < G; j += VB) v += partials[r * MAXG + j];
+            acc[r] = v;
+        }
+        __shared__ double sh[NRA][VB / 64];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int r = 0; r < NRA; r++) {
+            double v = wave_sum(acc[r]);
+            if (lane == 0) sh[r][w] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < NRA) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < VB / 64; k++) v += sh[threadIdx.x][k];
+            sums[threadIdx.x] = v;
+            if (mode == SC_REDUCE) st->red[threadIdx.x] = v;
+        }
+        __syncthreads();
+    } else if (Fin::NR > 0) {
+        if (threadIdx.x < NRA) sums[threadIdx.x] = st->red[threadIdx.x];
+        __syncthreads();
+    }
+    if (mode != SC_REDUCE && threadIdx.x == 0) fin(st, sums);
+}
+
+inline int grid_for(long n_items)
+{
+    long g = (n_items + VB - 1) / VB;
+    if (g < 1) g = 1;
+    if (g > MAXG) g = MAXG;
+    return (int)g;
+}
+
+} // namespace lcgh

@@ -1,0 +1,224 @@
+// driver.hpp -- host side of a device-resident Krylov loop.
+//
+// The host only enqueues: every coefficient lives in DevState, the stop test runs in the
+// scalar kernels, and once it fires the remaining enqueued kernels fall through.  Without a
+// progress callback the host therefore never blocks on the stream; it watches the
+// host-mapped HostStatus to (a) stop enqueuing soon after convergence and (b) stay at most
+// `inflight` iterations ahead.  With a progress callback the reference's contract (residual
+// and live m handed over before every iteration, lcg.cpp:211-217) forces one stream
+// synchronisation per iteration.
+#pragma once
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include "devcommon.hpp"
+
+namespace lcgh {
+
+struct Driver {
+    Ctx &c;
+    long n;            // local vector length (reals: elements, complex: complex elements)
+    bool cplx;
+    int max_it, abs_diff;
+    double eps;
+    int enq = 0;       // iteration bodies enqueued
+
+    Driver(Ctx &c_, long n_, bool cplx_, int max_it_, double eps_, int abs_diff_)
+        : c(c_), n(n_), cplx(cplx_), max_it(max_it_), abs_diff(abs_diff_), eps(eps_) { c.in_solve = true; }
+    ~Driver() { c.in_solve = false; }
+    Driver(const Driver &) = delete;
+
+    // ---- launches ------------------------------------------------------------------------
+    template <class Op> int vec(Op op, uintptr_t align_or = 0)
+    {
+        // complex vectors are naturally 16-byte elements; reals use the 2-wide path when
+        // every pointer is 16-byte aligned
+        const bool v2 = cplx || ((align_or & 15) == 0);
+        const long items = cplx ? n : (v2 ? (n + 1) / 2 : n);
+        const int g = grid_for(items);
+        if (cplx) {
+            hipLaunchKernelGGL((k_vec<Op, false>), dim3(g), dim3(VB), 0, c.stream, op, n, c.partials);
+        } else if (v2) {
+            hipLaunchKernelGGL((k_vec<Op, true>), dim3(g), dim3(VB), 0, c.stream, op, n, c.partials);
+        } else {
+            hipLaunchKernelGGL((k_vec<Op, false>), dim3(g), dim3(VB), 0, c.stream, op, n, c.partials);
+        }
+        last_g = g;
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    int last_g = 1;
+
+    // scalar step after the most recent reducing vec()
+    template <class Fin> int scal(Fin fin) { return scal_g(fin, last_g); }
+    template <class Fin> int scal_g(Fin fin, int g)
+    {
+        if (comm_active() && Fin::NR > 0) {
+            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_REDUCE);
+            int rc = comm_allreduce(c.state->red, Fin::NR, c.stream);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FIN);
+        } else {
+            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FUSED);
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+
+    // ---- state -------------------------------------------------------------------------------
+    int init_state(double n_global)
+    {
+        DevState h;
+        std::memset(&h, 0, sizeof h);
+        h.eps = eps; h.abs_diff = abs_diff; h.n_global = n_global; h.host = c.hstat_dev;
+        c.hstat->it = 0; c.hstat->done = 0; c.hstat->status = 0; c.hstat->t = 0; c.hstat->residual = 0.0;
+        HIPCHK(hipMemcpyAsync(c.state, &h, sizeof h, hipMemcpyHostToDevice, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
+        return 0;
+    }
+    int read_state(DevState &h)
+    {
+        HIPCHK(hipMemcpyAsync(&h, c.state, sizeof h, hipMemcpyDeviceToHost, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
+        return 0;
+    }
+
+    // A.x callback with optional event timing
+    template <class F> int timed_ax(F &&call)
+    {
+        if (c.profile && c.prof_used + 2 <= (int)c.prof_ev.size()) {
+            HIPCHK(hipEventRecord(c.prof_ev[c.prof_used], c.stream));
+            call();
+            HIPCHK(hipEventRecord(c.prof_ev[c.prof_used + 1], c.stream));
+            c.prof_used += 2;
+        } else {
+            call();
+        }
+        return 0;
+    }
+
+    // ---- the loop --------------------------------------------------------------------------
+    // body(): enqueue one counted iteration.  pfp(residual, t): progress callback or nullptr
+    // semantics via `has_pfp`.  Returns the liblcg status code.
+    template <class Body, class Pfp>
+    int run(Body &&body, bool has_pfp, Pfp &&pfp, int code_max_it, int code_nan)
+    {
+        DevState h;
+        int rc = read_state(h);
+        if (rc) return rc;
+        if (h.status == ST_ALREADY) {                       // lcg.cpp:186-203
+            if (has_pfp) pfp(h.residual, 0);
+            finish(h);
+            return LCG_ALREADY_OPTIMIZIED;
+        }
+        if (has_pfp) {
+            for (;;) {                                      // lcg.cpp:206-230, one sync per iteration
+                if (pfp(h.residual, h.t)) { finish(h); return LCG_STOP; }
+                if (h.residual <= eps) { finish(h); return LCG_CONVERGENCE; }
+                if (max_it > 0 && h.t + 1 > max_it) { finish(h); return code_max_it; }
+                rc = body(); if (rc) return rc;
+                enq++;
+                rc = read_state(h); if (rc) return rc;
+                if (h.status == ST_NAN) { finish(h); return code_nan; }
+            }
+        }
+        // asynchronous path
+        const long work = cplx ? 2 * n : n;
+        int inflight = work >= (1 << 20) ? 6 : 24;
+        if (const char *e = std::getenv("LCG_HIP_INFLIGHT")) inflight = std::max(1, atoi(e));
+        for (;;) {
+            if (max_it > 0 && enq >= max_it) break;
+            rc = body(); if (rc) return rc;
+            enq++;
+            if (c.hstat->done) break;
+            // stay at most `inflight` bodies ahead of the device
+            int spins = 0;
+            while (c.hstat->it < enq - inflight && !c.hstat->done) {
+                if (++spins > 2000) { std::this_thread::sleep_for(std::chrono::microseconds(20)); }
+                if (spins > 200000) {   // backstop: the mapped mirror is not advancing
+                    rc = read_state(h); if (rc) return rc;
+                    if (h.done || h.it >= enq - inflight) break;
+                    spins = 0;
+                }
+            }
+            if ((enq & 255) == 0) {     // authoritative check now and then
+                rc = read_state(h); if (rc) return rc;
+                if (h.done) break;
+            }
+        }
+        rc = read_state(h); if (rc) return rc;
+        finish(h);
+        if (h.status == ST_NAN) return code_nan;
+        if (h.done && h.status == ST_CONVERGED) return LCG_CONVERGENCE;
+        return code_max_it;
+    }
+
+    void finish(const DevState &h)
+    {
+        c.last_iters = h.t;
+        c.last_residual = h.residual;
+        c.last_ax_calls = c.prof_used / 2;
+        c.last_ax_mean_us = 0.0;
+        if (c.profile && c.prof_used >= 2) {
+            hipStreamSynchronize(c.stream);
+            double tot = 0.0;
+            for (int i = 0; i + 1 < c.prof_used; i += 2) {
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, c.prof_ev[i], c.prof_ev[i + 1]);
+                tot += ms;
+            }
+            c.last_ax_mean_us = 1e3 * tot / (c.prof_used / 2);
+        }
+        c.prof_used = 0;
+    }
+};
+
+// copy-in / copy-out of caller vectors when mem == HOST
+struct HostBridge {
+    double *dm = nullptr, *dB = nullptr;
+    double *hm = nullptr;
+    size_t bytes = 0;
+    bool active = false;
+    int open(int mem, double *&m, const double *&B, size_t nbytes, hipStream_t s)
+    {
+        if (mem == LCG_HIP_MEM_DEVICE) return 0;
+        active = true; bytes = nbytes; hm = m;
+        HIPCHK(hipMalloc(&dm, nbytes));
+        HIPCHK(hipMalloc(&dB, nbytes));
+        HIPCHK(hipMemcpyAsync(dm, m, nbytes, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dB, B, nbytes, hipMemcpyHostToDevice, s));
+        m = dm; B = dB;
+        return 0;
+    }
+    int close(hipStream_t s)
+    {
+        if (!active) return 0;
+        hipError_t e = hipMemcpyAsync(hm, dm, bytes, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        hipFree(dm); hipFree(dB);
+        active = false;
+        if (e != hipSuccess) return fail(e, "copy back m", __FILE__, __LINE__);
+        return 0;
+    }
+    ~HostBridge() { if (active) { hipFree(dm); hipFree(dB); } }
+};
+
+// device scratch vectors of one solve (freed on scope exit); caller-provided pointers win
+struct Workspace {
+    std::vector<double *> mine;
+    int get(double *&out, double *given, size_t bytes)
+    {
+        if (given) { out = given; return 0; }
+        double *p = nullptr;
+        HIPCHK(hipMalloc(&p, bytes));
+        mine.push_back(p);
+        out = p;
+        return 0;
+    }
+    ~Workspace() { for (double *p : mine) hipFree(p); }
+};
+
+} // namespace lcgh

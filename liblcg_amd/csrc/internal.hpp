@@ -1,0 +1,129 @@
+// internal.hpp -- shared declarations of liblcg_hip (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "lcg_hip.h"
+
+namespace lcgh {
+
+constexpr int VB = 256;     // threads per block of every vector / scalar kernel
+constexpr int MAXG = 2048;  // most blocks a reducing kernel launches = stride of the partial-sum table
+constexpr int MAXR = 8;     // most simultaneous reductions of one kernel
+
+enum { ST_RUNNING = 0, ST_CONVERGED = 1, ST_NAN = 2, ST_ALREADY = 3 };
+
+// Mirror of the stop state in host-mapped pinned memory; written by the scalar kernels,
+// polled by the host without touching the stream.
+struct HostStatus {
+    volatile double residual;
+    volatile int t;
+    volatile int done;
+    volatile int status;
+    volatile int it;        // written last
+};
+
+// Everything the iteration carries between kernels.  Lives in device memory; kernels read
+// their coefficients from here so no scalar ever has to visit the host inside the loop.
+struct DevState {
+    double red[MAXR];   // reduced sums of the latest reduction (all-reduce buffer when sharded)
+    double s[32];       // solver scalars (indices: enum in each solver)
+    double residual;    // value the next loop head tests (lcg.cpp:208-209)
+    double eps;
+    double n_global;
+    int abs_diff;
+    int it;             // iteration bodies started
+    int t;              // completed iterations (the reference's t)
+    int done;           // set once: every later kernel becomes a no-op
+    int status;         // ST_*
+    HostStatus *host;
+};
+
+struct Comm;            // comm.cpp
+
+struct Ctx {
+    bool inited = false;
+    int device = 0;
+    hipStream_t stream = nullptr;      // stream in use
+    hipStream_t own_stream = nullptr;  // created by the library
+    hipStream_t comm_stream = nullptr; // second stream for gather/compute overlap
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    double *partials = nullptr;        // [MAXR][MAXG]
+    DevState *state = nullptr;
+    HostStatus *hstat = nullptr;       // pinned, mapped
+    HostStatus *hstat_dev = nullptr;   // device alias of hstat
+    double *scratch_host = nullptr;    // pinned, 64 doubles
+    Comm *comm = nullptr;
+    int last_iters = 0;
+    double last_residual = 0.0;
+    bool in_solve = false;             // a Driver is alive: A.x may honour DevState::done
+    bool profile = false;
+    std::vector<hipEvent_t> prof_ev;   // pairs
+    int prof_used = 0;
+    double last_ax_mean_us = 0.0;
+    int last_ax_calls = 0;
+    unsigned shadow_seed = 1;
+    std::vector<double> shadow_vec;    // explicit rbar0 for the next complex solve
+    std::string err;
+};
+
+Ctx &ctx();
+int ensure_init();
+int fail(hipError_t e, const char *what, const char *file, int line);
+
+#define HIPCHK(call)                                                        \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) return ::lcgh::fail(e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// ---- CSR handle ------------------------------------------------------------------------
+struct CsrPart {
+    int n_rows = 0;
+    int64_t nnz = 0;
+    int *rowptr = nullptr;
+    int *col = nullptr;
+    double *val = nullptr;
+    bool owned = false;
+};
+
+} // namespace lcgh
+
+struct lcg_hip_csr {
+    int n_rows = 0;         // local rows
+    int n_cols = 0;         // columns addressed by `main` (global when sharded)
+    bool is_complex = false;
+    lcgh::CsrPart main;     // the whole shard (global columns)
+    double *invdiag = nullptr;  // reciprocal diagonal (1 or 2 doubles per row)
+    int variant = 0;        // SpMV kernel choice (0 auto)
+    double mean_row = 0.0;
+    // --- sharded operation (comm.cpp) ---
+    bool distributed = false;
+    int dist_mode = 0;
+    int64_t n_global = 0;
+    int64_t row0 = 0;           // first global row of this shard
+    int64_t rows_per_rank = 0;
+    lcgh::CsrPart loc;          // entries whose column is owned by this rank (LOCAL column index)
+    lcgh::CsrPart rem;          // the others (column index into xfull / halo buffer)
+    double *xfull = nullptr;    // gather buffer
+    void *halo = nullptr;       // neighbour-exchange plan (comm.cpp)
+};
+
+namespace lcgh {
+
+// kernels_real.hip / kernels_cplx.hip
+int spmv_launch(const CsrPart &P, bool is_complex, int variant, double mean_row, const double *x,
+                double *y, bool accumulate, hipStream_t s, const int *done_flag);
+int jacobi_launch(const lcg_hip_csr *A, const double *x, double *z, int n, hipStream_t s);
+
+// comm.cpp
+int comm_allreduce(double *dev, int count, hipStream_t s);
+bool comm_active();
+int dist_spmv(lcg_hip_csr *A, const double *x, double *y);
+
+} // namespace lcgh

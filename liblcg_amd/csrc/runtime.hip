@@ -1,0 +1,250 @@
+// runtime.hip -- library context (stream, reduction workspace, device state), error text,
+// and the stand-alone BLAS-1 entry points of the C ABI.
+#include <cmath>
+#include <cstdarg>
+
+#include "devcommon.hpp"
+
+namespace lcgh {
+
+Ctx &ctx()
+{
+    static Ctx c;   // one context per process, like the reference (no re-entrancy promised)
+    return c;
+}
+
+int fail(hipError_t e, const char *what, const char *file, int line)
+{
+    char buf[512];
+    std::snprintf(buf, sizeof buf, "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    ctx().err = buf;
+    (void)hipGetLastError();
+    return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? LCG_HIP_E_NO_DEVICE : LCG_HIP_E_RUNTIME;
+}
+
+int ensure_init()
+{
+    Ctx &c = ctx();
+    if (c.inited) return 0;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        c.err = "no HIP device: liblcg_hip has no CPU fallback";
+        return LCG_HIP_E_NO_DEVICE;
+    }
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    c.device = dev;
+    HIPCHK(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c.comm_stream, hipStreamNonBlocking));
+    if (!c.stream) c.stream = c.own_stream;
+    HIPCHK(hipEventCreateWithFlags(&c.ev_a, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c.ev_b, hipEventDisableTiming));
+    HIPCHK(hipMalloc(&c.partials, sizeof(double) * MAXR * MAXG));
+    HIPCHK(hipMalloc(&c.state, sizeof(DevState)));
+    HIPCHK(hipMemset(c.state, 0, sizeof(DevState)));
+    HIPCHK(hipHostMalloc((void **)&c.hstat, sizeof(HostStatus), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void **)&c.hstat_dev, c.hstat, 0));
+    HIPCHK(hipHostMalloc((void **)&c.scratch_host, sizeof(double) * 64, hipHostMallocDefault));
+    c.inited = true;
+    return 0;
+}
+
+// ---- stand-alone reductions -------------------------------------------------------------------
+struct OpDotPlain {
+    static constexpr int NR = 1, SKIP = SKIP_NEVER;
+    DevState *st; const double *a, *b;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc) { acc[0] += dotp(ld<T>(a, i), ld<T>(b, i)); }
+};
+template <bool CONJ>
+struct OpCDot {      // complex: sum a_i b_i (CONJ = false) or sum conj(a_i) b_i
+    static constexpr int NR = 2, SKIP = SKIP_NEVER;
+    DevState *st; const double *a, *b;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const double2 x = ld<double2>(a, i), y = ld<double2>(b, i);
+        if (CONJ) { acc[0] += x.x * y.x + x.y * y.y; acc[1] += x.x * y.y - x.y * y.x; }
+        else { acc[0] += x.x * y.x - x.y * y.y; acc[1] += x.x * y.y + x.y * y.x; }
+    }
+};
+struct OpAxpy {
+    static constexpr int NR = 0, SKIP = SKIP_NEVER;
+    DevState *st; double alpha; const double *x; double *y;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *) { st_(y, i, vadd(ld<T>(y, i), alpha * ld<T>(x, i))); }
+};
+struct OpScal {
+    static constexpr int NR = 0, SKIP = SKIP_NEVER;
+    DevState *st; double alpha; double *x;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *) { st_(x, i, alpha * ld<T>(x, i)); }
+};
+struct OpCAxpy {
+    static constexpr int NR = 0, SKIP = SKIP_NEVER;
+    DevState *st; double2 alpha; const double *x; double *y;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *) { st_(y, i, cfma(alpha, ld<double2>(x, i), ld<double2>(y, i))); }
+};
+template <int NRR> struct FinCopy {
+    static constexpr int NR = NRR;
+    double *out;    // device-visible (pinned host) destination
+    __device__ void operator()(DevState *, const double *sum) const
+    {
+        for (int r = 0; r < NRR; r++) out[r] = sum[r];
+    }
+};
+
+template <class Op, int NRR>
+static int reduce_to_host(Op op, long n, bool cplx, uintptr_t align_or, double *result)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    Ctx &c = ctx();
+    const bool v2 = !cplx && (align_or & 15) == 0;
+    const int g = grid_for(cplx ? n : (v2 ? (n + 1) / 2 : n));
+    if (v2) hipLaunchKernelGGL((k_vec<Op, true>), dim3(g), dim3(VB), 0, c.stream, op, n, c.partials);
+    else hipLaunchKernelGGL((k_vec<Op, false>), dim3(g), dim3(VB), 0, c.stream, op, n, c.partials);
+    double *dst = nullptr;
+    HIPCHK(hipMalloc(&dst, sizeof(double) * NRR));
+    FinCopy<NRR> fin{dst};
+    hipLaunchKernelGGL((k_scal<FinCopy<NRR>>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FUSED);
+    if (comm_active()) { rc = comm_allreduce(dst, NRR, c.stream); if (rc) { hipFree(dst); return rc; } }
+    hipError_t e = hipMemcpyAsync(c.scratch_host, dst, sizeof(double) * NRR, hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    hipFree(dst);
+    if (e != hipSuccess) return fail(e, "reduction", __FILE__, __LINE__);
+    for (int r = 0; r < NRR; r++) result[r] = c.scratch_host[r];
+    return 0;
+}
+
+template <class Op> static int plain_vec(Op op, long n, bool cplx, uintptr_t align_or)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    Ctx &c = ctx();
+    const bool v2 = !cplx && (align_or & 15) == 0;
+    const int g = grid_for(cplx ? n : (v2 ? (n + 1) / 2 : n));
+    if (v2) hipLaunchKernelGGL((k_vec<Op, true>), dim3(g), dim3(VB), 0, c.stream, op, n, c.partials);
+    else hipLaunchKernelGGL((k_vec<Op, false>), dim3(g), dim3(VB), 0, c.stream, op, n, c.partials);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+} // namespace lcgh
+
+using namespace lcgh;
+
+extern "C" {
+
+int lcg_hip_init(int device)
+{
+    if (device >= 0) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return fail(e, "hipSetDevice", __FILE__, __LINE__);
+    }
+    return ensure_init();
+}
+
+int lcg_hip_set_stream(void *s)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    Ctx &c = ctx();
+    c.stream = s ? static_cast<hipStream_t>(s) : c.own_stream;
+    return 0;
+}
+
+void *lcg_hip_get_stream(void) { return ensure_init() ? nullptr : ctx().stream; }
+
+int lcg_hip_synchronize(void)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx().stream));
+    return 0;
+}
+
+int lcg_hip_memcpy(void *dst, const void *src, uint64_t bytes, int kind)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, k, ctx().stream));
+    HIPCHK(hipStreamSynchronize(ctx().stream));
+    return 0;
+}
+
+const char *lcg_hip_last_error(void) { return ctx().err.c_str(); }
+
+lcg_para lcg_hip_default_parameters(void)
+{
+    lcg_para p = {0, 1e-6, 0, 1e-6, 1.0, 0.95, 0.9, 10};   // util.h:153
+    return p;
+}
+clcg_para clcg_hip_default_parameters(void)
+{
+    clcg_para p = {0, 1e-6, 0};                             // util.h:278
+    return p;
+}
+
+int lcg_hip_last_iterations(void) { return ctx().last_iters; }
+double lcg_hip_last_residual(void) { return ctx().last_residual; }
+double lcg_hip_last_ax_mean_us(void) { return ctx().last_ax_mean_us; }
+int lcg_hip_last_ax_calls(void) { return ctx().last_ax_calls; }
+
+int lcg_hip_set_profiling(int on)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    Ctx &c = ctx();
+    c.profile = on != 0;
+    if (c.profile && c.prof_ev.empty()) {
+        c.prof_ev.resize(2 * 4096);
+        for (auto &ev : c.prof_ev) HIPCHK(hipEventCreate(&ev));
+    }
+    c.prof_used = 0;
+    return 0;
+}
+
+int lcg_hip_set_shadow_seed(unsigned seed) { ctx().shadow_seed = seed; return 0; }
+int lcg_hip_set_shadow_vector(const double *v, int n)
+{
+    if (!v || n <= 0) { ctx().shadow_vec.clear(); return 0; }
+    ctx().shadow_vec.assign(v, v + 2 * (size_t)n);
+    return 0;
+}
+
+int lcg_hip_dot(int n, const double *a, const double *b, double *result)
+{
+    if (n <= 0 || !a || !b || !result) return LCG_HIP_E_ARG;
+    return reduce_to_host<OpDotPlain, 1>(OpDotPlain{nullptr, a, b}, n, false, (uintptr_t)a | (uintptr_t)b, result);
+}
+int lcg_hip_nrm2(int n, const double *a, double *result)
+{
+    int rc = lcg_hip_dot(n, a, a, result);
+    if (!rc) *result = std::sqrt(*result);
+    return rc;
+}
+int clcg_hip_dot(int n, const double *a, const double *b, double *result2)
+{
+    if (n <= 0 || !a || !b || !result2) return LCG_HIP_E_ARG;
+    return reduce_to_host<OpCDot<false>, 2>(OpCDot<false>{nullptr, a, b}, n, true, 0, result2);
+}
+int clcg_hip_inner(int n, const double *a, const double *b, double *result2)
+{
+    if (n <= 0 || !a || !b || !result2) return LCG_HIP_E_ARG;
+    return reduce_to_host<OpCDot<true>, 2>(OpCDot<true>{nullptr, a, b}, n, true, 0, result2);
+}
+int lcg_hip_axpy(int n, double alpha, const double *x, double *y)
+{
+    if (n <= 0 || !x || !y) return LCG_HIP_E_ARG;
+    return plain_vec(OpAxpy{nullptr, alpha, x, y}, n, false, (uintptr_t)x | (uintptr_t)y);
+}
+int lcg_hip_scal(int n, double alpha, double *x)
+{
+    if (n <= 0 || !x) return LCG_HIP_E_ARG;
+    return plain_vec(OpScal{nullptr, alpha, x}, n, false, (uintptr_t)x);
+}
+int clcg_hip_axpy(int n, const double *alpha2, const double *x, double *y)
+{
+    if (n <= 0 || !alpha2 || !x || !y) return LCG_HIP_E_ARG;
+    return plain_vec(OpCAxpy{nullptr, make_double2(alpha2[0], alpha2[1]), x, y}, n, true, 0);
+}
+
+} // extern "C"

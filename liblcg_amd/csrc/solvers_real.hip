@@ -1,0 +1,509 @@
+// solvers_real.hip -- device-resident CG, PCG, CGS and BiCGStab (fp64).
+//
+// Each solver is liblcg's algorithm (lcg.cpp) re-expressed as a short chain of fused HIP
+// passes per iteration.  What is fused and why (bytes are per row of N, 8-byte words):
+//
+//   CG   (lcg.cpp:206-264)  A.d | d.Ad | m+=a d, g+=a Ad, m.m, g.g, NaN | d = b d - g
+//        reference: 13 words + serial NaN scan        here: 2 + 6 + 3 = 11 words, 3 passes
+//   PCG  (lcg.cpp:361-423)  A.d | d.Ad | m+=a d, r-=a Ad | M^-1 r | m.m, r.r, z.r, NaN | d = z + b d
+//        reference: 18 words                          here: 2 + 6 + 3(M) + 3 + 3 = 17 words
+//        (built-in Jacobi: M^-1 r and the three dots ride in the update pass: 12 words)
+//   CGS  (lcg.cpp:520-598)  A.p | Ap.r0 | q,w | A.w | m,r update + m.m, r.r, r.r0, NaN | u,p
+//   BiCGStab (lcg.cpp:692-781) A.p | Ap.r0 | s | A.s | As.s, As.As | m,r update + dots | p
+//
+// The scalar recurrences (alpha, beta, omega, the stop rule) run in one-block kernels on
+// DevState; see devcommon.hpp / driver.hpp for the mechanics.
+#include <functional>
+
+#include "driver.hpp"
+
+namespace lcgh {
+
+// DevState::s slots shared by the real solvers
+enum { S_AK = 0, S_BK, S_WK, S_RHO /* g.g | z.r | r.r0 */, S_M2, S_G2 /* residual numerator */ };
+
+__device__ __forceinline__ double clamp1(double v) { return v < 1.0 ? 1.0 : v; }
+
+// ---- generic passes -------------------------------------------------------------------------
+struct OpDot1 {     // acc0 = a.b
+    static constexpr int NR = 1, SKIP = SKIP_DONE;
+    DevState *st; const double *a, *b;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc) { acc[0] += dotp(ld<T>(a, i), ld<T>(b, i)); }
+};
+struct OpDot2 {     // acc0 = a.b, acc1 = a.a     (BiCGStab: As.s and As.As, lcg.cpp:735-740)
+    static constexpr int NR = 2, SKIP = SKIP_DONE;
+    DevState *st; const double *a, *b;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const T x = ld<T>(a, i);
+        acc[0] += dotp(x, ld<T>(b, i));
+        acc[1] += dotp(x, x);
+    }
+};
+
+// first scalar step of every body: counts the body, then forms alpha = rho / (sum)
+struct FinAlpha {
+    static constexpr int NR = 1;
+    __device__ void operator()(DevState *st, const double *sum) const
+    {
+        st->it++;
+        if (st->done) return;
+        st->s[S_AK] = st->s[S_RHO] / sum[0];               // lcg.cpp:235,390,553,725
+    }
+};
+struct FinOmega {   // BiCGStab: omega = As.s / As.As (lcg.cpp:741)
+    static constexpr int NR = 2;
+    __device__ void operator()(DevState *st, const double *sum) const
+    {
+        if (st->done) return;
+        st->s[S_WK] = sum[0] / sum[1];
+    }
+};
+
+// setup scalar step: |m|^2 (clamped), residual numerator, rho; decides "already optimised"
+// (lcg.cpp:178-203: in abs_diff mode BOTH criteria are tried, in this order)
+struct FinInit {
+    static constexpr int NR = 3;    // m.m, g.g, rho
+    __device__ void operator()(DevState *st, const double *sum) const
+    {
+        const double m2 = clamp1(sum[0]), g2 = sum[1];
+        st->s[S_M2] = m2; st->s[S_G2] = g2; st->s[S_RHO] = sum[2];
+        double r;
+        bool already = false;
+        if (st->abs_diff && sqrt(g2) / st->n_global <= st->eps) { r = sqrt(g2) / st->n_global; already = true; }
+        else if (g2 / m2 <= st->eps) { r = g2 / m2; already = true; }
+        else r = st->abs_diff ? sqrt(g2) / st->n_global : g2 / m2;
+        st->residual = r;
+        if (already) { st->done = 1; st->status = ST_ALREADY; }
+        publish(st);
+    }
+};
+
+// closing scalar step of a body.  sums: m.m, g2 (r.r or g.g), rho_new, NaN count.
+// BICG selects the BiCGStab beta (lcg.cpp:773) instead of rho_new/rho (lcg.cpp:256,415,589).
+template <bool BICG>
+struct FinClose {
+    static constexpr int NR = 4;
+    __device__ void operator()(DevState *st, const double *sum) const
+    {
+        if (!st->done) {
+            st->s[S_M2] = clamp1(sum[0]);
+            if (sum[3] > 0.0 || sum[0] != sum[0]) {         // lcg.cpp:247-253
+                st->t++;
+                st->done = 1; st->status = ST_NAN;
+            } else {
+                const double rho_new = sum[2];
+                st->s[S_BK] = BICG ? (st->s[S_AK] / st->s[S_WK]) * rho_new / st->s[S_RHO]
+                                   : rho_new / st->s[S_RHO];
+                st->s[S_RHO] = rho_new;
+                st->s[S_G2] = sum[1];
+                st->t++;
+                stop_rule(st, sum[1], st->s[S_M2]);
+            }
+        }
+        publish(st);
+    }
+};
+
+// ---- CG -------------------------------------------------------------------------------------
+struct OpCgInit {   // g = Ad - B; d = -g; m.m, g.g (x2: rho = g.g)      lcg.cpp:171-183
+    static constexpr int NR = 3, SKIP = SKIP_NEVER;
+    DevState *st; const double *Ad, *B, *m; double *g, *d;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const T gv = vsub(ld<T>(Ad, i), ld<T>(B, i));
+        const T mv = ld<T>(m, i);
+        st_(g, i, gv); st_(d, i, vneg(gv));
+        acc[0] += dotp(mv, mv);
+        const double gg = dotp(gv, gv);
+        acc[1] += gg; acc[2] += gg;
+    }
+};
+struct OpCgUpdate { // m += a d; g += a Ad; m.m, g.g (x2), NaN           lcg.cpp:237-255
+    static constexpr int NR = 4, SKIP = SKIP_DONE;
+    DevState *st; double *m, *g; const double *d, *Ad; double ak;
+    __device__ void prep() { ak = st->s[S_AK]; }
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const T mv = vadd(ld<T>(m, i), ak * ld<T>(d, i));
+        const T gv = vadd(ld<T>(g, i), ak * ld<T>(Ad, i));
+        st_(m, i, mv); st_(g, i, gv);
+        acc[0] += dotp(mv, mv);
+        const double gg = dotp(gv, gv);
+        acc[1] += gg; acc[2] += gg;
+        acc[3] += nanflag(mv);
+    }
+};
+struct OpCgDir {    // d = b d - g                                         lcg.cpp:259-263
+    static constexpr int NR = 0, SKIP = SKIP_DIR;
+    DevState *st; double *d; const double *g; double bk;
+    __device__ void prep() { bk = st->s[S_BK]; }
+    template <class T> __device__ void apply(long i, double *)
+    {
+        st_(d, i, vsub(bk * ld<T>(d, i), ld<T>(g, i)));
+    }
+};
+
+// ---- PCG ------------------------------------------------------------------------------------
+struct OpResidual { // r = B - Ax   (also the start of CGS/BiCGStab with extra copies)
+    static constexpr int NR = 0, SKIP = SKIP_NEVER;
+    DevState *st; const double *Ax, *B; double *r;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *) { st_(r, i, vsub(ld<T>(B, i), ld<T>(Ax, i))); }
+};
+struct OpPcgInit2 { // d = z; m.m, r.r, z.r                               lcg.cpp:325-339
+    static constexpr int NR = 3, SKIP = SKIP_NEVER;
+    DevState *st; const double *z, *m, *r; double *d;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const T zv = ld<T>(z, i), mv = ld<T>(m, i), rv = ld<T>(r, i);
+        st_(d, i, zv);
+        acc[0] += dotp(mv, mv); acc[1] += dotp(rv, rv); acc[2] += dotp(zv, rv);
+    }
+};
+struct OpPcgUpdate {    // m += a d; r -= a Ad                            lcg.cpp:392-397
+    static constexpr int NR = 0, SKIP = SKIP_DONE;
+    DevState *st; double *m, *r; const double *d, *Ad; double ak;
+    __device__ void prep() { ak = st->s[S_AK]; }
+    template <class T> __device__ void apply(long i, double *)
+    {
+        st_(m, i, vadd(ld<T>(m, i), ak * ld<T>(d, i)));
+        st_(r, i, vsub(ld<T>(r, i), ak * ld<T>(Ad, i)));
+    }
+};
+struct OpPcgDots {      // m.m, r.r, z.r, NaN                             lcg.cpp:401-414
+    static constexpr int NR = 4, SKIP = SKIP_DONE;
+    DevState *st; const double *m, *r, *z;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const T mv = ld<T>(m, i), rv = ld<T>(r, i), zv = ld<T>(z, i);
+        acc[0] += dotp(mv, mv); acc[1] += dotp(rv, rv); acc[2] += dotp(zv, rv); acc[3] += nanflag(mv);
+    }
+};
+struct OpPcgUpdateJacobi {  // built-in Jacobi: update, z = r .* invdiag and all dots in one pass
+    static constexpr int NR = 4, SKIP = SKIP_DONE;
+    DevState *st; double *m, *r, *z; const double *d, *Ad, *invdiag; double ak;
+    __device__ void prep() { ak = st->s[S_AK]; }
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const T mv = vadd(ld<T>(m, i), ak * ld<T>(d, i));
+        const T rv = vsub(ld<T>(r, i), ak * ld<T>(Ad, i));
+        const T zv = vmul(ld<T>(invdiag, i), rv);
+        st_(m, i, mv); st_(r, i, rv); st_(z, i, zv);
+        acc[0] += dotp(mv, mv); acc[1] += dotp(rv, rv); acc[2] += dotp(zv, rv); acc[3] += nanflag(mv);
+    }
+};
+struct OpPcgDir {       // d = z + b d                                    lcg.cpp:418-422
+    static constexpr int NR = 0, SKIP = SKIP_DIR;
+    DevState *st; double *d; const double *z; double bk;
+    __device__ void prep() { bk = st->s[S_BK]; }
+    template <class T> __device__ void apply(long i, double *) { st_(d, i, vadd(ld<T>(z, i), bk * ld<T>(d, i))); }
+};
+
+// ---- CGS / BiCGStab ---------------------------------------------------------------------------
+template <bool WITH_U>
+struct OpShadowInit {   // p = (u =) r0 = r = B - Ax; m.m, r.r, r.r0      lcg.cpp:480-497 / 650-667
+    static constexpr int NR = 3, SKIP = SKIP_NEVER;
+    DevState *st; const double *Ax, *B, *m; double *r, *r0, *p, *u;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const T rv = vsub(ld<T>(B, i), ld<T>(Ax, i));
+        const T mv = ld<T>(m, i);
+        st_(r, i, rv); st_(r0, i, rv); st_(p, i, rv);
+        if (WITH_U) st_(u, i, rv);
+        acc[0] += dotp(mv, mv);
+        const double rr = dotp(rv, rv);
+        acc[1] += rr; acc[2] += rr;
+    }
+};
+struct OpCgsQW {        // q = u - a Ax; w = u + q                        lcg.cpp:556-560
+    static constexpr int NR = 0, SKIP = SKIP_DONE;
+    DevState *st; const double *u, *Ax; double *q, *w; double ak;
+    __device__ void prep() { ak = st->s[S_AK]; }
+    template <class T> __device__ void apply(long i, double *)
+    {
+        const T uv = ld<T>(u, i);
+        const T qv = vsub(uv, ak * ld<T>(Ax, i));
+        st_(q, i, qv); st_(w, i, vadd(uv, qv));
+    }
+};
+struct OpCgsUpdate {    // m += a w; r -= a Ax; m.m, r.r, r.r0, NaN       lcg.cpp:565-588
+    static constexpr int NR = 4, SKIP = SKIP_DONE;
+    DevState *st; double *m, *r; const double *w, *Ax, *r0; double ak;
+    __device__ void prep() { ak = st->s[S_AK]; }
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const T mv = vadd(ld<T>(m, i), ak * ld<T>(w, i));
+        const T rv = vsub(ld<T>(r, i), ak * ld<T>(Ax, i));
+        st_(m, i, mv); st_(r, i, rv);
+        acc[0] += dotp(mv, mv); acc[1] += dotp(rv, rv); acc[2] += dotp(rv, ld<T>(r0, i)); acc[3] += nanflag(mv);
+    }
+};
+struct OpCgsDir {       // u = r + b q; p = u + b (q + b p)               lcg.cpp:593-597
+    static constexpr int NR = 0, SKIP = SKIP_DIR;
+    DevState *st; double *u, *p; const double *r, *q; double bk;
+    __device__ void prep() { bk = st->s[S_BK]; }
+    template <class T> __device__ void apply(long i, double *)
+    {
+        const T qv = ld<T>(q, i);
+        const T uv = vadd(ld<T>(r, i), bk * qv);
+        st_(u, i, uv);
+        st_(p, i, vadd(uv, bk * vadd(qv, bk * ld<T>(p, i))));
+    }
+};
+struct OpBicgS {        // s = r - a Ap                                   lcg.cpp:727-731
+    static constexpr int NR = 0, SKIP = SKIP_DONE;
+    DevState *st; const double *r, *Ap; double *s; double ak;
+    __device__ void prep() { ak = st->s[S_AK]; }
+    template <class T> __device__ void apply(long i, double *) { st_(s, i, vsub(ld<T>(r, i), ak * ld<T>(Ap, i))); }
+};
+struct OpBicgUpdate {   // m += a p + w s; r = s - w Ax; m.m, r.r, r.r0, NaN   lcg.cpp:743-772
+    static constexpr int NR = 4, SKIP = SKIP_DONE;
+    DevState *st; double *m, *r; const double *p, *s, *Ax, *r0; double ak, wk;
+    __device__ void prep() { ak = st->s[S_AK]; wk = st->s[S_WK]; }
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const T sv = ld<T>(s, i);
+        const T mv = vadd(ld<T>(m, i), vadd(ak * ld<T>(p, i), wk * sv));
+        const T rv = vsub(sv, wk * ld<T>(Ax, i));
+        st_(m, i, mv); st_(r, i, rv);
+        acc[0] += dotp(mv, mv); acc[1] += dotp(rv, rv); acc[2] += dotp(rv, ld<T>(r0, i)); acc[3] += nanflag(mv);
+    }
+};
+struct OpBicgDir {      // p = r + b (p - w Ap)                           lcg.cpp:776-780
+    static constexpr int NR = 0, SKIP = SKIP_DIR;
+    DevState *st; double *p; const double *r, *Ap; double bk, wk;
+    __device__ void prep() { bk = st->s[S_BK]; wk = st->s[S_WK]; }
+    template <class T> __device__ void apply(long i, double *)
+    {
+        st_(p, i, vadd(ld<T>(r, i), bk * vsub(ld<T>(p, i), wk * ld<T>(Ap, i))));
+    }
+};
+
+// ---- host drivers -------------------------------------------------------------------------------
+static inline uintptr_t al(const void *p) { return (uintptr_t)p; }
+
+struct RealCommon {
+    Ctx &c; Driver drv; lcg_para para; void *inst; lcg_axfunc_ptr Afp; lcg_progress_ptr Pfp;
+    double *m; int n;
+    RealCommon(Ctx &c_, int n_, const lcg_para &p, void *inst_, lcg_axfunc_ptr A, lcg_progress_ptr P, double *m_)
+        : c(c_), drv(c_, n_, false, p.max_iterations, p.epsilon, p.abs_diff), para(p), inst(inst_),
+          Afp(A), Pfp(P), m(m_), n(n_) {}
+    int ax(const double *x, double *y) { return drv.timed_ax([&] { Afp(inst, x, y, n); }); }
+    int run_loop(const std::function<int()> &body)
+    {
+        auto pfp = [&](double resid, int t) -> int { return Pfp(inst, m, resid, &para, n, t); };
+        return drv.run(body, Pfp != nullptr, pfp, LCG_REACHED_MAX_ITERATIONS, LCG_NAN_VALUE);
+    }
+};
+
+static int check_args(const lcg_para &p, int n, const double *m, const double *B)
+{   // lcg.cpp:150-155
+    if (n <= 0) return LCG_INVILAD_VARIABLE_SIZE;
+    if (p.max_iterations < 0) return LCG_INVILAD_MAX_ITERATIONS;
+    if (p.epsilon <= 0.0 || p.epsilon >= 1.0) return LCG_INVILAD_EPSILON;
+    if (m == nullptr || B == nullptr) return LCG_INVALID_POINTER;
+    return 0;
+}
+
+double global_rows(Ctx &c, int n);   // comm.cpp: n summed over ranks (n itself when single)
+
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B, int n,
+                    const lcg_para *param, void *inst, double *Gk, double *Dk, double *ADk, int mem)
+{
+    const lcg_para p = param ? *param : lcg_hip_default_parameters();
+    TRY(check_args(p, n, m, B));
+    TRY(ensure_init());
+    Ctx &c = ctx();
+    HostBridge hb; TRY(hb.open(mem, m, B, sizeof(double) * n, c.stream));
+    Workspace ws; double *g, *d, *Ad;
+    TRY(ws.get(g, Gk, sizeof(double) * n)); TRY(ws.get(d, Dk, sizeof(double) * n)); TRY(ws.get(Ad, ADk, sizeof(double) * n));
+    RealCommon k(c, n, p, inst, Afp, Pfp, m);
+    TRY(k.drv.init_state(global_rows(c, n)));
+    DevState *st = c.state;
+
+    TRY(k.ax(m, Ad));                                                            // lcg.cpp:168
+    TRY(k.drv.vec(OpCgInit{st, Ad, B, m, g, d}, al(Ad) | al(B) | al(m) | al(g) | al(d)));
+    TRY(k.drv.scal(FinInit{}));
+    const uintptr_t a_upd = al(m) | al(g) | al(d) | al(Ad);
+    int rc = k.run_loop([&]() -> int {
+        TRY(k.ax(d, Ad));                                                        // :232
+        TRY(k.drv.vec(OpDot1{st, d, Ad}, al(d) | al(Ad)));                       // :234
+        TRY(k.drv.scal(FinAlpha{}));                                             // :235
+        TRY(k.drv.vec(OpCgUpdate{st, m, g, d, Ad, 0.0}, a_upd));                 // :237-255
+        TRY(k.drv.scal(FinClose<false>{}));                                      // :244-257
+        TRY(k.drv.vec(OpCgDir{st, d, g, 0.0}, al(d) | al(g)));                   // :259-263
+        return 0;
+    });
+    int rc2 = hb.close(c.stream);
+    return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
+}
+
+static int solve_pcg(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pfp, double *m, const double *B,
+                     int n, const lcg_para *param, void *inst, int mem)
+{
+    const lcg_para p = param ? *param : lcg_hip_default_parameters();
+    TRY(check_args(p, n, m, B));
+    if (Mfp == nullptr) return LCG_NULL_PRECONDITION_MATRIX;
+    TRY(ensure_init());
+    Ctx &c = ctx();
+    HostBridge hb; TRY(hb.open(mem, m, B, sizeof(double) * n, c.stream));
+    Workspace ws; double *r, *z, *d, *Ad;
+    TRY(ws.get(r, nullptr, sizeof(double) * n)); TRY(ws.get(z, nullptr, sizeof(double) * n));
+    TRY(ws.get(d, nullptr, sizeof(double) * n)); TRY(ws.get(Ad, nullptr, sizeof(double) * n));
+    RealCommon k(c, n, p, inst, Afp, Pfp, m);
+    TRY(k.drv.init_state(global_rows(c, n)));
+    DevState *st = c.state;
+    // built-in Jacobi on a handle that owns its reciprocal diagonal: fold M^-1 into the update
+    const double *invdiag = nullptr;
+    if (Mfp == lcg_hip_jacobi_mx && inst) {
+        const lcg_hip_csr *A = static_cast<const lcg_hip_csr *>(inst);
+        if (!A->is_complex && A->n_rows == n) invdiag = A->invdiag;
+    }
+
+    TRY(k.ax(m, Ad));                                                            // lcg.cpp:314
+    TRY(k.drv.vec(OpResidual{st, Ad, B, r}, al(Ad) | al(B) | al(r)));            // :317-321
+    Mfp(inst, r, z, n);                                                          // :323
+    TRY(k.drv.vec(OpPcgInit2{st, z, m, r, d}, al(z) | al(m) | al(r) | al(d)));   // :325-339
+    TRY(k.drv.scal(FinInit{}));
+    const uintptr_t a_all = al(m) | al(r) | al(z) | al(d) | al(Ad) | al(invdiag);
+    int rc = k.run_loop([&]() -> int {
+        TRY(k.ax(d, Ad));                                                        // :387
+        TRY(k.drv.vec(OpDot1{st, d, Ad}, al(d) | al(Ad)));                       // :389
+        TRY(k.drv.scal(FinAlpha{}));                                             // :390
+        if (invdiag) {
+            TRY(k.drv.vec(OpPcgUpdateJacobi{st, m, r, z, d, Ad, invdiag, 0.0}, a_all));   // :392-414
+        } else {
+            TRY(k.drv.vec(OpPcgUpdate{st, m, r, d, Ad, 0.0}, a_all));            // :392-397
+            Mfp(inst, r, z, n);                                                  // :399
+            TRY(k.drv.vec(OpPcgDots{st, m, r, z}, a_all));                       // :401-414
+        }
+        TRY(k.drv.scal(FinClose<false>{}));                                      // :415-416
+        TRY(k.drv.vec(OpPcgDir{st, d, z, 0.0}, al(d) | al(z)));                  // :418-422
+        return 0;
+    });
+    int rc2 = hb.close(c.stream);
+    return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
+}
+
+static int solve_cgs(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B, int n,
+                     const lcg_para *param, void *inst, double *RK, double *R0T, double *PK, double *AX,
+                     double *UK, double *QK, double *WK, int mem)
+{
+    const lcg_para p = param ? *param : lcg_hip_default_parameters();
+    TRY(check_args(p, n, m, B));
+    TRY(ensure_init());
+    Ctx &c = ctx();
+    HostBridge hb; TRY(hb.open(mem, m, B, sizeof(double) * n, c.stream));
+    Workspace ws; double *r, *r0, *pk, *Ax, *u, *q, *w;
+    const size_t nb = sizeof(double) * n;
+    TRY(ws.get(r, RK, nb)); TRY(ws.get(r0, R0T, nb)); TRY(ws.get(pk, PK, nb)); TRY(ws.get(Ax, AX, nb));
+    TRY(ws.get(u, UK, nb)); TRY(ws.get(q, QK, nb)); TRY(ws.get(w, WK, nb));
+    RealCommon k(c, n, p, inst, Afp, Pfp, m);
+    TRY(k.drv.init_state(global_rows(c, n)));
+    DevState *st = c.state;
+    const uintptr_t a_all = al(m) | al(B) | al(r) | al(r0) | al(pk) | al(Ax) | al(u) | al(q) | al(w);
+
+    TRY(k.ax(m, Ax));                                                            // lcg.cpp:476
+    TRY(k.drv.vec(OpShadowInit<true>{st, Ax, B, m, r, r0, pk, u}, a_all));       // :480-497
+    TRY(k.drv.scal(FinInit{}));
+    int rc = k.run_loop([&]() -> int {
+        TRY(k.ax(pk, Ax));                                                       // :546
+        TRY(k.drv.vec(OpDot1{st, Ax, r0}, a_all));                               // :548-552
+        TRY(k.drv.scal(FinAlpha{}));                                             // :553
+        TRY(k.drv.vec(OpCgsQW{st, u, Ax, q, w, 0.0}, a_all));                    // :556-560
+        TRY(k.ax(w, Ax));                                                        // :562
+        TRY(k.drv.vec(OpCgsUpdate{st, m, r, w, Ax, r0, 0.0}, a_all));            // :565-588
+        TRY(k.drv.scal(FinClose<false>{}));                                      // :589-590
+        TRY(k.drv.vec(OpCgsDir{st, u, pk, r, q, 0.0}, a_all));                   // :593-597
+        return 0;
+    });
+    int rc2 = hb.close(c.stream);
+    return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
+}
+
+static int solve_bicgstab(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B, int n,
+                          const lcg_para *param, void *inst, int mem)
+{
+    const lcg_para p = param ? *param : lcg_hip_default_parameters();
+    TRY(check_args(p, n, m, B));
+    TRY(ensure_init());
+    Ctx &c = ctx();
+    HostBridge hb; TRY(hb.open(mem, m, B, sizeof(double) * n, c.stream));
+    Workspace ws; double *r, *r0, *pk, *Ax, *s, *Ap;
+    const size_t nb = sizeof(double) * n;
+    TRY(ws.get(r, nullptr, nb)); TRY(ws.get(r0, nullptr, nb)); TRY(ws.get(pk, nullptr, nb));
+    TRY(ws.get(Ax, nullptr, nb)); TRY(ws.get(s, nullptr, nb)); TRY(ws.get(Ap, nullptr, nb));
+    RealCommon k(c, n, p, inst, Afp, Pfp, m);
+    TRY(k.drv.init_state(global_rows(c, n)));
+    DevState *st = c.state;
+    const uintptr_t a_all = al(m) | al(B) | al(r) | al(r0) | al(pk) | al(Ax) | al(s) | al(Ap);
+
+    TRY(k.ax(m, Ax));                                                            // lcg.cpp:648
+    TRY(k.drv.vec(OpShadowInit<false>{st, Ax, B, m, r, r0, pk, nullptr}, a_all)); // :650-667
+    TRY(k.drv.scal(FinInit{}));
+    int rc = k.run_loop([&]() -> int {
+        TRY(k.ax(pk, Ap));                                                       // :718
+        TRY(k.drv.vec(OpDot1{st, Ap, r0}, a_all));                               // :720-724
+        TRY(k.drv.scal(FinAlpha{}));                                             // :725
+        TRY(k.drv.vec(OpBicgS{st, r, Ap, s, 0.0}, a_all));                       // :727-731
+        TRY(k.ax(s, Ax));                                                        // :733
+        TRY(k.drv.vec(OpDot2{st, Ax, s}, a_all));                                // :735-740
+        TRY(k.drv.scal(FinOmega{}));                                             // :741
+        TRY(k.drv.vec(OpBicgUpdate{st, m, r, pk, s, Ax, r0, 0.0, 0.0}, a_all));  // :743-772
+        TRY(k.drv.scal(FinClose<true>{}));                                       // :773-774
+        TRY(k.drv.vec(OpBicgDir{st, pk, r, Ap, 0.0, 0.0}, a_all));               // :776-780
+        return 0;
+    });
+    int rc2 = hb.close(c.stream);
+    return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
+}
+
+} // namespace lcgh
+
+using namespace lcgh;
+
+extern "C" {
+
+int lcg_hip_solver(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B, int n,
+                   const lcg_para *param, void *instance, int solver_id, int mem)
+{
+    switch (solver_id) {                                                        // lcg.cpp:59-82
+    case LCG_CG: return solve_cg(Afp, Pfp, m, B, n, param, instance, nullptr, nullptr, nullptr, mem);
+    case LCG_BICGSTAB: return solve_bicgstab(Afp, Pfp, m, B, n, param, instance, mem);
+    case LCG_CGS:
+    default: return solve_cgs(Afp, Pfp, m, B, n, param, instance, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, nullptr, nullptr, mem);
+    }
+}
+
+int lcg_hip_solver_preconditioned(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pfp, double *m,
+                                  const double *B, int n, const lcg_para *param, void *instance,
+                                  int solver_id, int mem)
+{
+    (void)solver_id;                                                            // lcg.cpp:87-91
+    return solve_pcg(Afp, Mfp, Pfp, m, B, n, param, instance, mem);
+}
+
+int lcg_hip_lcg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B, int n,
+                const lcg_para *param, void *instance, double *Gk, double *Dk, double *ADk, int mem)
+{
+    return solve_cg(Afp, Pfp, m, B, n, param, instance, Gk, Dk, ADk, mem);
+}
+
+int lcg_hip_lcgs(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B, int n,
+                 const lcg_para *param, void *instance, double *RK, double *R0T, double *PK, double *AX,
+                 double *UK, double *QK, double *WK, int mem)
+{
+    return solve_cgs(Afp, Pfp, m, B, n, param, instance, RK, R0T, PK, AX, UK, QK, WK, mem);
+}
+
+} // extern "C"
