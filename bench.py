@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CG iterations/s on the synthetic 10M-row, ~33 nnz/row fp64 SPD CSR.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" is one CG iteration (lcg.cpp:206-264: A.d, three inner products, three vector
+updates, stop test) executed by lcg_hip_lcg() through the C ABI with inputs resident in HBM.
+N > 1: the same 10M-row system is row-partitioned over the ranks (strong scaling), x is
+all-gathered and the inner products all-reduced over RCCL inside the library.
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def spmv_bytes(n, nnz):     # 12*nnz + 4*(N+1) + 8*N (x) + 8*N (y)
+    return 12 * nnz + 4 * (n + 1) + 16 * n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--band", type=int, default=131072, help="0 = scrambled (random-column) variant")
+    ap.add_argument("--npairs", type=int, default=16)
+    ap.add_argument("--solver", default="cg", choices=["cg", "pcg", "cgs", "bicgstab"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from liblcg_amd import _lib, api, partition
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    lib = _lib.load()
+    rc = lib.lcg_hip_init(local_rank)
+    if rc:
+        raise SystemExit(f"lcg_hip_init failed: {lib.lcg_hip_last_error().decode()}")
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        partition.init_comm_from_torch(lib)
+
+    n = args.rows
+    r0, r1 = partition.shard_range(n, world, rank)
+    nloc = r1 - r0
+    symmetric = args.solver in ("cg", "pcg")
+    A = api.CsrMatrix.generate(n, args.npairs, args.band, symmetric, 1, 0.01, r0, r1)
+    if world > 1:
+        A.distribute(n)
+    nnz_local = A.nnz
+    if args.solver == "pcg":
+        A.build_jacobi()
+    xt = torch.empty(nloc, dtype=torch.float64, device="cuda")
+    api.gen_xtrue(n, 1, r0, r1, xt)
+    b = torch.empty_like(xt)
+    A.spmv(xt, b)
+    api.synchronize()
+    nnz = nnz_local
+    if world > 1:
+        t = torch.tensor([nnz_local], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        nnz = int(t.item())
+
+    m = torch.zeros_like(xt)
+    ws = [torch.empty_like(xt) for _ in range(7)]
+
+    def solve(iters):
+        m.zero_()
+        torch.cuda.synchronize()
+        p = api.lcg_default_parameters(epsilon=1e-300, max_iterations=iters)
+        if args.solver == "cg":
+            return api.lcg("lcg_hip_csr_ax", None, m, b, nloc, p, A, ws[0], ws[1], ws[2])
+        if args.solver == "pcg":
+            return api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, b, nloc, p, A)
+        if args.solver == "cgs":
+            return api.lcgs("lcg_hip_csr_ax", None, m, b, nloc, p, A, *ws)
+        return api.lcg_solver("lcg_hip_csr_ax", None, m, b, nloc, p, A, api.LCG_BICGSTAB)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        solve(args.warmup)
+    lib.lcg_hip_set_profiling(1)
+    barrier()
+    t0 = time.perf_counter()
+    info = solve(args.steps)
+    api.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ax_us = lib.lcg_hip_last_ax_mean_us()
+    ax_calls = lib.lcg_hip_last_ax_calls()
+    lib.lcg_hip_set_profiling(0)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if info.iterations != args.steps:
+        raise SystemExit(f"timed solve ran {info.iterations} iterations, expected {args.steps} (ret={info.ret})")
+
+    # accuracy after the timed iterations (the system is solved to the fp64 floor well before 200)
+    err = torch.tensor([(m - xt).pow(2).sum().item(), xt.pow(2).sum().item()], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(err)
+    rel_err = float((err[0] / err[1]).sqrt().item())
+
+    ax_per_it = {"cg": 1, "pcg": 1, "cgs": 2, "bicgstab": 2}[args.solver]
+    blas1_words = {"cg": 13, "pcg": 18, "cgs": 21, "bicgstab": 22}[args.solver]
+    iter_bytes = ax_per_it * spmv_bytes(n, nnz) + 8 * blas1_words * n
+    out = {
+        "metric": "cg_iterations_per_sec", "value": args.steps / elapsed, "unit": "iter/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"synthetic SPD CSR, {'banded-random W=%d' % args.band if args.band else 'scrambled affine maps'}, "
+                               f"plain {args.solver.upper()} via lcg_hip_lcg (BASELINE configs[2]/[3])",
+                   "rows": n, "nnz": nnz, "nnz_per_row": nnz / n, "solver": args.solver, "index": "int32",
+                   "partition": "single" if world == 1 else f"row-block x{world}, RCCL all-gather(x) + all-reduce(dots)"},
+        "whole_iteration_algorithmic_GBs": iter_bytes / (elapsed / args.steps) / 1e9,
+        "frac_of_hbm_peak_whole_iteration": iter_bytes / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
+        "rel_err_vs_x_true": rel_err,
+    }
+    # dominant kernel: the CSR A.x.  Duration from HIP events on the solver stream around every
+    # A.x of the timed region; bytes = algorithmic bytes of this rank's shard.
+    if ax_calls > 0 and ax_us > 0:
+        shard_bytes = spmv_bytes(nloc, nnz_local) if world == 1 else 12 * nnz_local + 4 * (nloc + 1) + 8 * n + 8 * nloc
+        achieved = shard_bytes / (ax_us * 1e-6) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if world == 1 and os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("spmv_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": "k_spmv_lds (CSR A.x)" if world == 1 else "A.x (local + gather + remote)",
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": traffic, "bytes_per_launch": shard_bytes, "avg_launch_us": ax_us, "launches": ax_calls}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(A, b, n, args, np)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        lib.lcg_hip_comm_destroy()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(A, b, n, args, np):
+    """liblcg's own CPU loop on the same matrix, on this box's host cores (bounded sample).
+    kind 'reference' = the real liblcg native/OpenMP back-end (oracle/_ref, built from
+    /root/reference in the build container); 'port' = the C restatement (oracle/)."""
+    from oracle import pyoracle as po
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    kind = "reference" if po.have_ref() else "port"
+    orc = po.Oracle(kind)
+    rp, ci, v = A.arrays_to_host()
+    bh = b.cpu().numpy()
+    sid = {"cg": po.LCG_CG, "pcg": po.LCG_PCG, "cgs": po.LCG_CGS, "bicgstab": po.LCG_BICGSTAB}[args.solver]
+    jac = args.solver == "pcg"
+
+    def run(iters):
+        t0 = time.perf_counter()
+        r = orc.solve(sid, rp, ci, v, bh, para=po.default_para(epsilon=1e-300, max_iterations=iters), jacobi=jac,
+                      threads=cores if kind == "reference" else 1)
+        return time.perf_counter() - t0, r
+    t_probe, _ = run(3)
+    iters = int(max(5, min(400, args.cpu_seconds / max(t_probe / 3, 1e-3))))
+    t, r = run(iters)
+    return {"value": iters / t, "unit": "iter/s", "cores": cores if kind == "reference" else 1, "kind": kind,
+            "sample": f"{iters} {args.solver.upper()} iterations of the same {n}-row system "
+                      f"({'liblcg lcg_solver + OpenMP CSR callback' if kind == 'reference' else 'serial C restatement'}), {t:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,85 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and
+exports exactly what include/lcg_hip.h declares; struct layouts match liblcg's; without a GPU
+every compute entry fails loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "lcg_hip.h")
+
+
+@pytest.fixture(scope="module")
+def so_path():
+    from liblcg_amd import _lib
+    return _lib.build()
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b((?:c?lcg_hip|clcg_hip)_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(n for n in names if not n.endswith("_ptr")))
+
+
+def test_header_symbols_exported(so_path):
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", so_path], text=True)
+    exported = set(re.findall(r" T (\S+)", syms))
+    declared = _declared_functions()
+    assert len(declared) >= 55
+    missing = [f for f in declared if f not in exported]
+    assert not missing, missing
+
+
+def test_python_prototypes_cover_header():
+    from liblcg_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared_functions()
+
+
+def test_struct_layouts_match_liblcg():
+    """util.h:95-148 / :247-273: 64- and 24-byte PODs."""
+    from liblcg_amd import _lib
+    assert C.sizeof(_lib.LcgPara) == 64 and C.sizeof(_lib.ClcgPara) == 24
+    assert _lib.LcgPara.epsilon.offset == 8 and _lib.LcgPara.abs_diff.offset == 16
+    assert _lib.LcgPara.restart_epsilon.offset == 24 and _lib.LcgPara.maxi_m.offset == 56
+
+
+def test_loads_and_fails_loudly_without_gpu(so_path):
+    import torch
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    p = lib.lcg_hip_default_parameters()
+    assert (p.max_iterations, p.epsilon, p.abs_diff, p.maxi_m) == (0, 1e-6, 0, 10)
+    cp = lib.clcg_hip_default_parameters()
+    assert (cp.max_iterations, cp.epsilon, cp.abs_diff) == (0, 1e-6, 0)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the no-device path cannot be exercised")
+    buf = (C.c_double * 8)()
+    pp = lib.lcg_hip_default_parameters()
+    rc = lib.lcg_hip_solver(_lib.fnptr(lib, "lcg_hip_csr_ax"), None, buf, buf, 8, C.byref(pp), None, 0, 0)
+    assert rc == -2001, rc                  # LCG_HIP_E_NO_DEVICE, not a silent CPU result
+    assert b"no" in lib.lcg_hip_last_error().lower()
+    out = C.c_double()
+    assert lib.lcg_hip_dot(8, buf, buf, C.byref(out)) == -2001
+    h = C.c_void_p()
+    assert lib.lcg_hip_csr_generate(C.byref(h), 1000, 16, 0, 1, 1, 0.01, 0, 1000) == -2001
+    # argument validation still follows lcg.cpp:150-155 before any device work
+    pp.epsilon = 2.0
+    assert lib.lcg_hip_solver(_lib.fnptr(lib, "lcg_hip_csr_ax"), None, buf, buf, 8, C.byref(pp), None, 0, 0) == -1021
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may reach into oracle/."""
+    pkg = os.path.join(ROOT, "liblcg_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pyoracle" not in text and "liblcg_oracle" not in text and "lcg_oracle.h" not in text, f
+                assert "/root/reference" not in text, f
+    ldd = subprocess.check_output(["ldd", os.path.join(pkg, "lib", "liblcg_hip.so")], text=True)
+    assert "oracle" not in ldd and "liblcg_ref" not in ldd

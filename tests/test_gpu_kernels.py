@@ -1,0 +1,231 @@
+"""-m gpu: kernel-level parity through the C ABI -- A.x (every variant, ragged/empty/long rows),
+BLAS-1, Jacobi, COO ingest, generators, the sharded product, and size-independent properties
+at the full 10M-row benchmark size."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def api():
+    from liblcg_amd import api as a
+    assert torch.cuda.is_available()
+    return a
+
+
+def _ragged(rng, n, ncols, max_len, long_rows=()):
+    lens = rng.integers(0, max_len + 1, n)
+    lens[rng.integers(0, n, n // 10)] = 0                  # empty rows
+    for r, ln in long_rows:
+        lens[r] = ln
+    rp = np.zeros(n + 1, np.int32); np.cumsum(lens, out=rp[1:])
+    col = rng.integers(0, ncols, rp[-1]).astype(np.int32)
+    return rp, col
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_spmv_all_variants_ragged(api, port, cplx):
+    rng = np.random.default_rng(11)
+    n = 3001
+    rp, col = _ragged(rng, n, n, 40, long_rows=[(5, 5000), (2999, 2500), (3000, 7)])
+    val = rng.standard_normal(rp[-1]) + (1j * rng.standard_normal(rp[-1]) if cplx else 0)
+    x = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)
+    ref = port.csr_matvec(rp, col, val, x)
+    A = api.CsrMatrix.from_csr(rp, col, val)
+    xd = torch.from_numpy(x).cuda(); yd = torch.empty_like(xd)
+    scale = np.abs(ref).max()
+    for var in (0, -1, -16, -32, -64, -128, -256, 1, 2, 4, 8, 16, 32, 64):
+        yd.zero_()
+        A.set_kernel(var)
+        A.spmv(xd, yd); api.synchronize()
+        assert np.abs(yd.cpu().numpy() - ref).max() <= 1e-12 * scale, var
+
+
+def test_spmv_edge_shapes(api, port):
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 63, 64, 65, 255, 256, 257):
+        rp, col = _ragged(rng, n, n, 9)
+        val = rng.standard_normal(rp[-1])
+        if rp[-1] == 0:
+            continue
+        x = rng.standard_normal(n)
+        A = api.CsrMatrix.from_csr(rp, col, val)
+        xd = torch.from_numpy(x).cuda(); yd = torch.full_like(xd, 7.0)
+        for var in (0, -64, 8):
+            A.set_kernel(var); A.spmv(xd, yd); api.synchronize()
+            assert np.allclose(yd.cpu().numpy(), port.csr_matvec(rp, col, val, x), rtol=0, atol=1e-13), (n, var)
+
+
+def test_blas1(api, port):
+    rng = np.random.default_rng(5)
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    for n in (1, 2, 3, 1000, 1001, 524289, 3_000_001):
+        a = rng.standard_normal(n); b = rng.standard_normal(n)
+        ad, bd = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        exact = float(np.dot(a.astype(np.longdouble), b.astype(np.longdouble)))
+        tol = 1e-13 * float(np.dot(np.abs(a), np.abs(b))) + 1e-300
+        assert abs(api.dot(ad, bd) - exact) <= tol
+        assert abs(api.dot(ad, bd) - port.dot(a, b)) <= 50 * tol * max(1, np.log2(n + 1))
+        assert abs(api.nrm2(ad) - np.linalg.norm(a)) <= 1e-13 * np.linalg.norm(a)
+        # unaligned (odd offset) views take the scalar path
+        if n > 3:
+            assert abs(api.dot(ad[1:], bd[1:]) - float(np.dot(a[1:], b[1:]))) <= 100 * tol
+        yd = bd.clone()
+        lib.lcg_hip_axpy(n, 0.75, ad.data_ptr(), yd.data_ptr()); api.synchronize()
+        assert np.allclose(yd.cpu().numpy(), b + 0.75 * a, rtol=1e-15, atol=1e-15)
+        lib.lcg_hip_scal(n, -2.0, yd.data_ptr()); api.synchronize()
+        assert np.allclose(yd.cpu().numpy(), -2.0 * (b + 0.75 * a), rtol=1e-15, atol=1e-15)
+        cd = torch.empty_like(ad)
+        lib.lcg_hip_vecmul(n, ad.data_ptr(), bd.data_ptr(), cd.data_ptr()); api.synchronize()
+        assert np.array_equal(cd.cpu().numpy(), a * b)
+        lib.lcg_hip_vecdiv(n, ad.data_ptr(), bd.data_ptr(), cd.data_ptr()); api.synchronize()
+        assert np.allclose(cd.cpu().numpy(), a / b, rtol=2e-16, atol=0)
+
+
+def test_complex_blas1(api):
+    rng = np.random.default_rng(6)
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    n = 100_003
+    a = rng.standard_normal(n) + 1j * rng.standard_normal(n); b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    ad, bd = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    assert abs(api.cdot(ad, bd) - np.sum(a * b)) <= 1e-10                  # clcg_dot: no conjugate
+    assert abs(api.cdot(ad, bd, conj=True) - np.vdot(a, b)) <= 1e-10       # clcg_inner: conj(a).b
+    yd = bd.clone(); alpha = (C.c_double * 2)(0.5, -1.25)
+    lib.clcg_hip_axpy(n, alpha, ad.data_ptr(), yd.data_ptr()); api.synchronize()
+    assert np.allclose(yd.cpu().numpy(), b + (0.5 - 1.25j) * a, rtol=1e-14, atol=1e-14)
+    cd = torch.empty_like(ad)
+    lib.clcg_hip_vecdiv(n, ad.data_ptr(), bd.data_ptr(), cd.data_ptr()); api.synchronize()
+    assert np.allclose(cd.cpu().numpy(), a / b, rtol=1e-14, atol=0)
+
+
+def test_jacobi_and_diagonal(api, port, case10k, case1kc):
+    n, rp, ci, v, b, _ = case10k
+    A = api.CsrMatrix.from_csr(rp, ci, v)
+    d = torch.empty(n, dtype=torch.float64, device="cuda")
+    A.build_jacobi(d); api.synchronize()
+    assert np.array_equal(d.cpu().numpy(), port.csr_diag(rp, ci, v))       # algebra_cuda.cu:40-57
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    r = torch.from_numpy(b).cuda(); z = torch.empty_like(r)
+    lib.lcg_hip_jacobi_mx(A.h, r.data_ptr(), z.data_ptr(), n); api.synchronize()
+    assert np.allclose(z.cpu().numpy(), b * (1.0 / port.csr_diag(rp, ci, v)), rtol=1e-16, atol=0)
+    n, rp, ci, v, b, _ = case1kc
+    A = api.CsrMatrix.from_csr(rp, ci, v)
+    d = torch.empty(n, dtype=torch.complex128, device="cuda")
+    A.build_jacobi(d); api.synchronize()
+    assert np.array_equal(d.cpu().numpy(), port.csr_diag(rp, ci, v))       # lcg_complex_cuda.cu:46-63
+
+
+def test_coo_ingest(api, port, case10k):
+    import os
+    from conftest import GOLDEN
+    from liblcg_amd.coo_io import read_coo_system
+    n, row, col, val, b = read_coo_system(os.path.join(GOLDEN, "case_10K_A"))
+    rp, perm = port.coo_to_csr(row, col, n)
+    A = api.CsrMatrix.from_coo(n, row, col, val)                            # row-sorted file: device path
+    rp2, ci2, v2 = A.arrays_to_host()
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, col[perm]) and np.array_equal(v2, val[perm])
+    sh = np.random.default_rng(1).permutation(len(row))                     # unsorted: stable host sort
+    A = api.CsrMatrix.from_coo(n, row[sh], col[sh], val[sh])
+    rp3, ci3, v3 = A.arrays_to_host()
+    rp4, perm4 = port.coo_to_csr(row[sh], col[sh], n)
+    assert np.array_equal(rp3, rp4) and np.array_equal(ci3, col[sh][perm4]) and np.array_equal(v3, val[sh][perm4])
+    x = np.random.default_rng(2).standard_normal(n)
+    xd = torch.from_numpy(x).cuda(); yd = torch.empty_like(xd)
+    A.spmv(xd, yd); api.synchronize()
+    assert np.allclose(yd.cpu().numpy(), port.coo_matvec(row, col, val, x), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("band,sym", [(64, True), (0, True), (1000, False), (0, False), (3, True)])
+def test_generator_twin_is_bit_identical(api, port, band, sym):
+    n = 7777
+    g = port.gen_init(n, 16, band, sym, 5, 0.01)
+    for r0, r1 in ((0, n), (1234, 4321), (n - 100, n)):
+        rp, ci, v = port.gen_rows(g, r0, r1)
+        A = api.CsrMatrix.generate(n, 16, band, sym, 5, 0.01, r0, r1)
+        rp2, ci2, v2 = A.arrays_to_host()
+        assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2) and np.array_equal(v, v2)
+    xt = torch.empty(n, dtype=torch.float64, device="cuda")
+    api.gen_xtrue(n, 5, 0, n, xt); api.synchronize()
+    assert np.array_equal(xt.cpu().numpy(), port.gen_xtrue(g))
+    if sym:     # symmetric and strictly diagonally dominant => SPD
+        import scipy.sparse as sp
+        rp, ci, v = port.gen_rows(g)
+        M = sp.csr_matrix((v, ci, rp), shape=(n, n))
+        assert abs(M - M.T).max() == 0.0
+        off = abs(M).sum(axis=1).A1 - M.diagonal()
+        assert np.all(M.diagonal() - off > 0.0099)
+
+
+def test_laplace2d_generator(api):
+    import scipy.sparse as sp
+    nx, ny = 37, 23
+    A = api.CsrMatrix.laplace2d(nx, ny)
+    rp, ci, v = A.arrays_to_host()
+    M = sp.csr_matrix((v, ci, rp), shape=(nx * ny, nx * ny))
+    T = sp.kron(sp.eye(ny), sp.diags([-1, 2, -1], [-1, 0, 1], shape=(nx, nx))) + \
+        sp.kron(sp.diags([-1, 2, -1], [-1, 0, 1], shape=(ny, ny)), sp.eye(nx))
+    assert abs(M - T.tocsr()).max() == 0.0
+    assert np.all(np.diff(ci[rp[5]:rp[6]]) > 0)
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_sharded_product_on_one_gpu(api, port, nranks):
+    """Row shards split into local-/remote-column parts (comm.hip) reproduce the full A.x."""
+    from liblcg_amd import _lib, partition
+    lib = _lib.load()
+    n = 10007
+    for band in (50, 0):
+        g = port.gen_init(n, 16, band, True, 9, 0.01)
+        rp, ci, v = port.gen_rows(g)
+        x = np.random.default_rng(4).standard_normal(n)
+        ref = port.csr_matvec(rp, ci, v, x)
+        glen = partition.gathered_length(n, nranks)
+        xpad = np.zeros(glen); xpad[:n] = x
+        for r in range(nranks):
+            r0, r1 = partition.shard_range(n, nranks, r)
+            A = api.CsrMatrix.generate(n, 16, band, True, 9, 0.01, r0, r1)
+            assert lib.lcg_hip_csr_split_for_test(A.h, n, nranks, r) == 0
+            xf = lib.lcg_hip_csr_xfull(A.h)
+            assert lib.lcg_hip_memcpy(xf, xpad.ctypes.data, xpad.nbytes, 1) == 0
+            xl = torch.from_numpy(x[r0:r1].copy()).cuda(); yl = torch.empty_like(xl)
+            A.spmv(xl, yl); api.synchronize()
+            assert np.abs(yl.cpu().numpy() - ref[r0:r1]).max() <= 1e-12 * np.abs(ref).max()
+            if band:
+                assert lib.lcg_hip_csr_local_nnz(A.h) > 0.9 * A.nnz
+
+
+def test_full_size_properties(api):
+    """BASELINE.json configs[2] size (10M rows, ~33 nnz/row): linearity, symmetry and a CG solve
+    back to x_true -- properties that need no CPU reference."""
+    n = 10_000_000
+    A = api.CsrMatrix.generate(n, 16, 131072, True, 1, 0.01)
+    assert 32.5 * n < A.nnz <= 33 * n
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    y = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    Ax, Ay, Az = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    A.spmv(x, Ax); A.spmv(y, Ay); api.synchronize()
+    z = x + 2.0 * y
+    A.spmv(z, Az); api.synchronize()
+    assert (Az - (Ax + 2.0 * Ay)).abs().max().item() <= 1e-12 * Az.abs().max().item()     # linearity
+    assert abs(api.dot(x, Ay) - api.dot(y, Ax)) <= 1e-12 * abs(api.dot(x, Ay))             # A = A^T
+    assert api.dot(x, Ax) > 0                                                               # positive
+    for var in (8, -32):    # other kernels agree at full size
+        A.set_kernel(var); A.spmv(x, Az); api.synchronize()
+        assert (Az - Ax).abs().max().item() <= 1e-12 * Ax.abs().max().item()
+    A.set_kernel(0)
+    xt = torch.empty_like(x); api.gen_xtrue(n, 1, 0, n, xt)
+    b = torch.empty_like(x); A.spmv(xt, b); api.synchronize()
+    m = torch.zeros_like(x)
+    info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=1e-10, abs_diff=1), A, api.LCG_CG)
+    assert info.ret == 0 and info.residual <= 1e-10
+    assert ((m - xt).norm() / xt.norm()).item() <= 1e-5
+    A.spmv(m, Ax); api.synchronize()
+    assert ((Ax - b).norm().item() / n) <= 1.01e-10                       # the monitored quantity, recomputed
