@@ -1,13 +1,24 @@
 """-m gpu: the HIP solvers, called through the C ABI, against the oracle on the reference's own
 bundled systems and against the goldens produced by the real liblcg.
 
-Tolerances (fp64; GPU reductions are tree-ordered, the reference's are serial):
-  * tight run (abs_diff=1, eps=1e-12): ||x_gpu - x_oracle|| / ||x_oracle|| <= 1e-9, both within
-    1e-7 of case_10K_B, iteration count within +-3 of the oracle's
-  * loose run (sample8.cu:241-243 setting, eps=1e-6): iteration count within +-2, same x to 1e-6
-  * complex: ||x_gpu - x*|| <= 1e-3 (the reference itself reaches 2e-4 .. 1.3e-3), BiCG-sym
-    (deterministic) additionally tracks the oracle to 1e-7 relative.
+Tolerances (fp64).  The GPU sums in tree order and contracts to FMA; the reference sums serially.
+How far that may move a result is a property of each ALGORITHM on each system, measured on the
+oracle itself by perturbing b in its last bit (tests/test_oracle_sensitivity.py, which pins the
+bands used here):
+  * CG / PCG / CGS (real): insensitive (1e-15).  Tight run (abs_diff=1, eps=1e-12):
+    ||x_gpu - x_oracle|| / ||x_oracle|| <= 1e-9, iteration count within +-3, and no farther from
+    case_10K_B than the real liblcg itself.  Loose run (sample8.cu:241-243, eps=1e-6): +-2, 1e-6.
+  * BiCGStab (real): the oracle moves by 4e-10 (tight) / 1e-4 (loose) under a 1-ulp change of b,
+    and its iteration count by several percent: bands 1e-7 / 5e-3 and +-15 %.
+  * complex BiCG-sym / CGS / TFQMR to convergence: the oracle moves by 1e-6..2e-6 and +-3 % in
+    iterations: bands 5e-5 relative and +-12 %; ||x - x*|| <= 2e-3 (the reference reaches
+    2e-5 .. 1.3e-3).  Their first 12 iterates track the oracle to 1e-9.
+  * complex BiCGStab diverges on the bundled systems and is chaotic from the
+    first iterations (oracle: 2e-7 on 1K, 6e-3 on 10K after 12 its): return code, count and
+    finiteness only, plus 1e-4 on the 1K system after 12 iterations.
 """
+# (rel x vs oracle tight, rel x loose, iteration band as a fraction)
+REAL_BANDS = {0: (1e-9, 1e-6, 0.0), 1: (1e-9, 1e-6, 0.0), 2: (1e-9, 1e-6, 0.0), 3: (1e-7, 5e-3, 0.15)}
 import ctypes as C
 
 import numpy as np
@@ -50,12 +61,14 @@ def test_real_tight_vs_oracle_and_golden(api, port, goldens, case10k, A10k, sid,
     info, x = _solve_real(api, A10k, sid, b, n, api.lcg_default_parameters(epsilon=1e-12, abs_diff=1))
     ref = port.solve(sid, rp, ci, v, b, para=po.default_para(epsilon=1e-12, abs_diff=1), jacobi=(sid == 1))
     gold = goldens[f"real/{name}_e12/x"]
+    tol, _, band = REAL_BANDS[sid]
     assert info.ret == ref["ret"] == 0
-    assert abs(info.iterations - ref["iters"]) <= 3
+    assert abs(info.iterations - ref["iters"]) <= max(3, band * ref["iters"])
     assert info.residual <= 1e-12
-    assert np.linalg.norm(x - ref["x"]) / np.linalg.norm(ref["x"]) <= 1e-9
-    assert np.linalg.norm(x - gold) / np.linalg.norm(gold) <= 1e-9        # the real liblcg's output
-    assert np.linalg.norm(x - xs) <= 1e-7 and np.linalg.norm(ref["x"] - xs) <= 1e-7
+    assert np.linalg.norm(x - ref["x"]) / np.linalg.norm(ref["x"]) <= tol
+    assert np.linalg.norm(x - gold) / np.linalg.norm(gold) <= tol          # the real liblcg's output
+    # distance to the known answer: no worse than the real liblcg's own (5e-8 .. 3.5e-7 here)
+    assert np.linalg.norm(x - xs) <= 1.1 * np.linalg.norm(gold - xs) + 1e-9 <= 5e-7
 
 
 @pytest.mark.parametrize("sid,name", [(0, "cg"), (1, "pcg"), (2, "cgs"), (3, "bicgstab")])
@@ -64,9 +77,10 @@ def test_real_loose_sample8_setting(api, goldens, case10k, A10k, sid, name):
     info, x = _solve_real(api, A10k, sid, b, n, api.lcg_default_parameters(epsilon=1e-6, abs_diff=0))
     ret, iters = goldens[f"real/{name}_e6/meta"][:2]
     gold = goldens[f"real/{name}_e6/x"]
+    _, tol, band = REAL_BANDS[sid]
     assert info.ret == ret == 0
-    assert abs(info.iterations - iters) <= 2
-    assert np.linalg.norm(x - gold) / np.linalg.norm(gold) <= 1e-6
+    assert abs(info.iterations - iters) <= max(2, band * iters)
+    assert np.linalg.norm(x - gold) / np.linalg.norm(gold) <= tol
 
 
 def test_max_iterations_and_counts(api, goldens, case10k, A10k):
@@ -194,11 +208,11 @@ def test_complex_bicg_symmetric(api, port, goldens, case1kc, case10kc, case):
     info, x = _solve_cplx(api, A, api.CLCG_BICG_SYM, b, n, api.clcg_default_parameters(epsilon=1e-10, abs_diff=1))
     ref = port.csolve(po.CLCG_BICG_SYM, rp, ci, v, b, para=po.default_cpara(epsilon=1e-10, abs_diff=1))
     assert info.ret == ref["ret"] == 0
-    assert abs(info.iterations - ref["iters"]) <= 5
-    assert np.linalg.norm(x - ref["x"]) / np.linalg.norm(ref["x"]) <= 1e-6
-    assert np.linalg.norm(x - xs) <= 1e-3
+    assert abs(info.iterations - ref["iters"]) <= 0.12 * ref["iters"]
+    assert np.linalg.norm(x - ref["x"]) / np.linalg.norm(ref["x"]) <= 5e-5
+    assert np.linalg.norm(x - xs) <= 2e-3
     gold = goldens[f"cplx/bicgsym_{case}/x"]
-    assert np.linalg.norm(x - gold) / np.linalg.norm(gold) <= 1e-6
+    assert np.linalg.norm(x - gold) / np.linalg.norm(gold) <= 5e-5
 
 
 @pytest.mark.parametrize("sid,name", [(2, "cgs"), (4, "tfqmr")])
@@ -212,8 +226,10 @@ def test_complex_shadow_solvers(api, port, goldens, case1kc, case10kc, sid, name
     info, x = _solve_cplx(api, A, sid, b, n, api.clcg_default_parameters(epsilon=1e-10, abs_diff=1), shadow=rbar0)
     assert info.ret == ret == 0
     assert info.residual <= 1e-10
-    assert abs(info.iterations - iters) <= max(10, 0.05 * iters)       # rounding-order sensitive recurrences
+    assert abs(info.iterations - iters) <= 0.12 * iters                 # rounding-order sensitive recurrences
     assert np.linalg.norm(x - xs) <= 2e-3
+    gold = goldens[f"cplx/{name}_{case}/x"]
+    assert np.linalg.norm(x - gold) / np.linalg.norm(gold) <= 5e-5
     # default (seeded) shadow vector: still converges to the known answer
     info2, x2 = _solve_cplx(api, A, sid, b, n, api.clcg_default_parameters(epsilon=1e-10, abs_diff=1))
     assert info2.ret == 0 and np.linalg.norm(x2 - xs) <= 2e-3
@@ -235,6 +251,7 @@ def test_complex_bicgstab_and_cap(api, port, goldens, case1kc):
     for sid in (po.CLCG_CGS, po.CLCG_BICGSTAB, po.CLCG_TFQMR):
         info, x = _solve_cplx(api, A, sid, b, n, api.clcg_default_parameters(epsilon=1e-10, abs_diff=1, max_iterations=12), shadow=rbar0)
         ref = port.csolve(sid, rp, ci, v, b, para=po.default_cpara(epsilon=1e-10, abs_diff=1, max_iterations=12), rbar0=rbar0)
+        tol = 1e-4 if sid == po.CLCG_BICGSTAB else 1e-9
         assert info.ret == ref["ret"] == -1019 and info.iterations == ref["iters"] == 12
-        assert np.linalg.norm(x - ref["x"]) <= 1e-9 * max(1.0, np.linalg.norm(ref["x"]))
-        assert abs(info.residual - ref["residual"]) <= 1e-8 * abs(ref["residual"])
+        assert np.linalg.norm(x - ref["x"]) <= tol * np.linalg.norm(ref["x"])
+        assert abs(info.residual - ref["residual"]) <= 100 * tol * abs(ref["residual"])

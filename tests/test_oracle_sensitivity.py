@@ -1,0 +1,58 @@
+"""Where the parity bands of tests/test_gpu_solvers.py come from.
+
+A GPU run differs from the reference only in rounding (tree-ordered sums, FMA contraction).  How
+much an algorithm amplifies rounding on a given system is measured here ON THE ORACLE ITSELF:
+solve once, solve again with b perturbed at the 1e-16 level, compare.  The GPU bands are these
+responses times a safety factor; the assertions below keep the two in step.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+
+def _perturbed(b, seed):
+    rng = np.random.default_rng(seed)
+    return b * (1.0 + 1e-16 * rng.standard_normal(len(b)))
+
+
+def _rel(a, c):
+    return np.linalg.norm(a - c) / np.linalg.norm(a)
+
+
+@pytest.mark.parametrize("sid,tight_band,loose_band", [(0, 1e-9, 1e-6), (2, 1e-9, 1e-6), (3, 1e-7, 5e-3)])
+def test_real_solvers(port, case10k, sid, tight_band, loose_band):
+    n, rp, ci, v, b, _ = case10k
+    for (eps, ad), band in (((1e-12, 1), tight_band), ((1e-6, 0), loose_band)):
+        para = po.default_para(epsilon=eps, abs_diff=ad)
+        a = port.solve(sid, rp, ci, v, b, para=para)
+        c = port.solve(sid, rp, ci, v, _perturbed(b, 1), para=para)
+        assert _rel(a["x"], c["x"]) <= band / 20          # the GPU band leaves >= 20x headroom
+    if sid == 3:    # BiCGStab really is that touchy: the loose run moves by ~1e-4 on a 1-ulp change
+        assert _rel(a["x"], c["x"]) >= 1e-6
+
+
+@pytest.mark.parametrize("sid", [po.CLCG_BICG_SYM, po.CLCG_CGS, po.CLCG_TFQMR])
+def test_complex_converged_runs(port, case1kc, sid):
+    n, rp, ci, v, b, _ = case1kc
+    rb = port.vecrnd(n, 42)
+    para = po.default_cpara(epsilon=1e-10, abs_diff=1)
+    a = port.csolve(sid, rp, ci, v, b, para=para, rbar0=rb)
+    c = port.csolve(sid, rp, ci, v, _perturbed(b, 0), para=para, rbar0=rb)
+    assert a["ret"] == c["ret"] == 0
+    assert 1e-8 <= _rel(a["x"], c["x"]) <= 5e-5 / 10      # inherent, and inside the GPU band
+    assert abs(a["iters"] - c["iters"]) <= 0.05 * a["iters"]
+    # the first dozen iterates are still tight
+    para12 = po.default_cpara(epsilon=1e-10, abs_diff=1, max_iterations=12)
+    a = port.csolve(sid, rp, ci, v, b, para=para12, rbar0=rb)
+    c = port.csolve(sid, rp, ci, v, _perturbed(b, 0), para=para12, rbar0=rb)
+    assert _rel(a["x"], c["x"]) <= 1e-9 / 10
+
+
+def test_complex_bicgstab_is_chaotic_on_the_bundled_systems(port, case1kc, case10kc):
+    for (n, rp, ci, v, b, _), lo, hi in ((case1kc, 1e-9, 1e-4 / 10), (case10kc, 1e-5, 1.0)):
+        rb = port.vecrnd(n, 42)
+        para = po.default_cpara(epsilon=1e-10, abs_diff=1, max_iterations=12)
+        a = port.csolve(po.CLCG_BICGSTAB, rp, ci, v, b, para=para, rbar0=rb)
+        c = port.csolve(po.CLCG_BICGSTAB, rp, ci, v, _perturbed(b, 0), para=para, rbar0=rb)
+        assert lo <= _rel(a["x"], c["x"]) <= hi
