@@ -178,10 +178,15 @@ def cpu_baseline(A, b, n, args, np):
     kind 'reference' = the real liblcg native/OpenMP back-end (oracle/_ref, built from
     /root/reference in the build container); 'port' = the C restatement (oracle/)."""
     from oracle import pyoracle as po
-    cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    # a one-GPU box is entitled to 16 host cores (the node shows all of them)
+    cores = min(16, len(os.sched_getaffinity(0)))
     kind = "reference" if po.have_ref() else "port"
     orc = po.Oracle(kind)
+    try:    # libgomp is already initialised (torch loaded it): set the team size at run time
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
     rp, ci, v = A.arrays_to_host()
     bh = b.cpu().numpy()
     sid = {"cg": po.LCG_CG, "pcg": po.LCG_PCG, "cgs": po.LCG_CGS, "bicgstab": po.LCG_BICGSTAB}[args.solver]

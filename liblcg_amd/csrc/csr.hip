@@ -80,7 +80,14 @@ __global__ __launch_bounds__(VB) void k_spmv_lds(int n, long nnz, const int *__r
     if (done && *done) return;
 
     const int tid = threadIdx.x;
-    const int row0 = blockIdx.x * R;
+    // XCD-aware placement: the dispatcher deals consecutive block ids round-robin over the 8
+    // XCDs, each with its own L2.  Handing XCD k the k-th CONTIGUOUS eighth of the row blocks
+    // lets every L2 keep one moving window of x instead of all eight holding the same one
+    // (measured: x refetch 6.4x -> ~1x of its size).  Pure speed; any placement is correct.
+    const int per_xcd = gridDim.x >> 3;                 // grid is a multiple of 8
+    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int row0 = lb * R;
+    if (row0 >= n) return;
     const int nrows = min(R, n - row0);
     const int rl = tid % R, j0 = tid / R;
     const int s = rowptr[row0], e = rowptr[row0 + nrows];
@@ -155,7 +162,7 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
         int R = variant < -1 ? -variant : (mean_row <= 8.5 ? 256 : mean_row <= 17 ? 128 : mean_row <= 35 ? 64 : mean_row <= 70 ? 32 : 16);
 #define LDS_CASE(RR)                                                                                   \
     case RR:                                                                                           \
-        hipLaunchKernelGGL((k_spmv_lds<V, RR, ACC>), dim3((n + RR - 1) / RR), dim3(VB), 0, s, n, (long)P.nnz, \
+        hipLaunchKernelGGL((k_spmv_lds<V, RR, ACC>), dim3((((n + RR - 1) / RR + 7) / 8) * 8), dim3(VB), 0, s, n, (long)P.nnz, \
                            P.rowptr, P.col, val, x, y, done);                                          \
         break;
         switch (R) {

@@ -138,11 +138,13 @@ enum { SC_FUSED = 0, SC_REDUCE = 1, SC_FIN = 2 };
 __device__ __forceinline__ void publish(DevState *st)
 {
     HostStatus *h = st->host;
+    // posted writes over PCIe; no fence: the host only uses `it` to pace itself and `done`
+    // to stop enqueuing early, and re-reads DevState with a real copy before it returns
+    // (a system-scope fence here costs ~10 us per iteration)
     h->residual = st->residual;
     h->t = st->t;
     h->done = st->done;
     h->status = st->status;
-    __threadfence_system();
     h->it = st->it;
 }
 
