@@ -150,7 +150,9 @@ int lcg_hip_set_shadow_vector(const double *rbar0_host, int n_size);
 typedef struct lcg_hip_csr *lcg_hip_csr_t;
 
 /* Copy (mem == HOST, or DEVICE with adopt == 0) or adopt without copying (DEVICE, adopt != 0;
- * the caller keeps the arrays alive) a CSR matrix.  is_complex: val holds interleaved c128. */
+ * the caller keeps the arrays alive) a CSR matrix.  is_complex: val holds interleaved c128.
+ * adopt == 2 additionally promises >= 64 readable bytes after col[nnz] and val[nnz], which
+ * admits the fastest A.x kernel (copied matrices always have that slack). */
 int lcg_hip_csr_create(lcg_hip_csr_t *A, int n_rows, int n_cols, int64_t nnz, const int *rowptr,
                        const int *col, const double *val, int is_complex, int mem, int adopt);
 /* COO (row-sorted or not) -> CSR on the device: data/README:1-10 files, sample8.cu:30-64,169. */

@@ -118,8 +118,9 @@ __global__ void k_split_fill(int n, long lo, long hi, const int *rowptr, const i
 static int alloc_cols(CsrPart &P, int n, long nnz, bool cplx)
 {
     P.n_rows = n; P.nnz = nnz; P.owned = true;
-    HIPCHK(hipMalloc(&P.col, sizeof(int) * (size_t)(nnz > 0 ? nnz : 1) + 16));
-    HIPCHK(hipMalloc(&P.val, sizeof(double) * (cplx ? 2 : 1) * (size_t)(nnz > 0 ? nnz : 1) + 16));
+    HIPCHK(hipMalloc(&P.col, sizeof(int) * (size_t)(nnz > 0 ? nnz : 1) + 64));
+    HIPCHK(hipMalloc(&P.val, sizeof(double) * (cplx ? 2 : 1) * (size_t)(nnz > 0 ? nnz : 1) + 64));
+    P.padded = true;
     return 0;
 }
 

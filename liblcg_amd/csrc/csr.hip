@@ -6,8 +6,8 @@
 //
 //  k_spmv_lds<R,T>  (default)  One 256-thread block owns R consecutive rows (R*T = 256).
 //      Stage 1: the block's contiguous slice of val/col streams from HBM into LDS with
-//      16-byte-per-lane coalesced loads (the CSR arrays are read exactly once, at full
-//      width, whatever the row lengths).  Stage 2: lane (row = tid % R, j = tid / R) walks
+//      16-byte-per-lane coalesced loads, ALL issued before the first LDS store (the CSR
+//      arrays are read exactly once, at full width, whatever the row lengths).  Stage 2: lane (row = tid % R, j = tid / R) walks
 //      its row's entries j, j+T, ... out of LDS and gathers x; consecutive lanes hold
 //      consecutive ROWS, so for matrices with diagonal / stencil structure the x gather of a
 //      wavefront is one contiguous run, and for arbitrary columns it is no worse than any
@@ -65,59 +65,145 @@ __global__ __launch_bounds__(VB) void k_spmv_wave(int n, const int *__restrict__
 }
 
 // ----------------------------------------------------------------------- LDS-staged family
-constexpr int LDS_CH = 2304;    // entries staged per window (multiple of 4)
+// LDS budget per block: 26,880 B of staging (6 blocks fit a CU's 160 KiB; registers currently
+// admit 5).  The row-sum exchange buffer aliases the staging buffer.
+template <class V> struct LdsCfg { static constexpr int CH = sizeof(V) == 8 ? 2240 : 1344; };
+// native vector types: arrays of these stay in registers (arrays of HIP's struct-wrapped int4 /
+// double2 were demoted to scratch here: 2x slower)
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
 
+// largest slice (entries from the 4-aligned start of a block's first row to the end of its last
+// row) over all blocks of R rows: decides once per matrix whether every block fits one window
+__global__ void k_max_slice(int n, int R, const int *rowptr, int *out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const long row0 = (long)b * R;
+    if (row0 >= n) return;
+    const int r1 = (int)min((long)n, row0 + R);
+    atomicMax(out, rowptr[r1] - (rowptr[row0] & ~3));
+}
+
+// ---- one-window kernel: the host has verified (k_max_slice) that every block's slice fits one
+// LDS window.  ALL of the block's HBM loads are issued before the first LDS store, 16 B per
+// lane per access (~25 KB in flight per block); then every lane keeps UNR gathers of x in flight.
 template <class V, int R, bool ACC>
-__global__ __launch_bounds__(VB) void k_spmv_lds(int n, long nnz, const int *__restrict__ rowptr,
-                                                 const int *__restrict__ col, const V *__restrict__ val,
-                                                 const V *__restrict__ x, V *__restrict__ y,
-                                                 const int *done)
+__global__ __launch_bounds__(VB) void k_spmv_lds1(int n, long nnz, const int *__restrict__ rowptr,
+                                                  const int *__restrict__ col, const V *__restrict__ val,
+                                                  const V *__restrict__ x, V *__restrict__ y,
+                                                  const int *done)
 {
     constexpr int T = VB / R;
-    __shared__ V sval[LDS_CH];
-    __shared__ int scol[LDS_CH];
-    __shared__ V sred[T > 1 ? T : 1][R];
+    constexpr int CH = LdsCfg<V>::CH;                       // entries per LDS window (multiple of 4)
+    constexpr int NRND = (CH + VB * 4 - 1) / (VB * 4);      // 4-entry units per lane
+    constexpr int VU = sizeof(V) / 4;                       // 16-byte pieces of val per 4 entries
+    constexpr int UNR = 4;                                  // x gathers in flight per lane
+    static_assert(T * R <= CH, "row-sum exchange must fit the staging buffer");
+    __shared__ __attribute__((aligned(16))) V sval[CH];
+    __shared__ __attribute__((aligned(16))) int scol[CH];
+    V(*sred)[R] = reinterpret_cast<V(*)[R]>(sval);
     if (done && *done) return;
 
     const int tid = threadIdx.x;
-    // XCD-aware placement: the dispatcher deals consecutive block ids round-robin over the 8
-    // XCDs, each with its own L2.  Handing XCD k the k-th CONTIGUOUS eighth of the row blocks
-    // lets every L2 keep one moving window of x instead of all eight holding the same one
-    // (measured: x refetch 6.4x -> ~1x of its size).  Pure speed; any placement is correct.
-    const int per_xcd = gridDim.x >> 3;                 // grid is a multiple of 8
-    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int row0 = lb * R;
-    if (row0 >= n) return;
+    const int row0 = blockIdx.x * R;
+    const int nrows = min(R, n - row0);
+    const int rl = tid % R, j0 = tid / R;
+    const int base = rowptr[row0] & ~3;
+    const int cnt = rowptr[row0 + nrows] - base;
+
+    v4i pc[NRND]; v2d pv[NRND * VU];
+#pragma unroll
+    for (int r = 0; r < NRND; r++) {
+        const int u = tid * 4 + r * VB * 4;
+        // branch-free: lanes past the slice re-read its first unit (an L1 hit) instead of being
+        // masked off -- a conditional load makes the compiler drain vmcnt at every join, which
+        // serialises the rounds.  col/val carry >= 64 B of slack (CsrPart::padded): no tail case.
+        const long g = (long)base + (u < cnt ? u : 0);
+        pc[r] = *reinterpret_cast<const v4i *>(col + g);
+#pragma unroll
+        for (int q = 0; q < VU; q++) pv[r * VU + q] = reinterpret_cast<const v2d *>(val + g)[q];
+    }
+    // keep every load above every LDS store below: without this fence the scheduler pairs each
+    // load with its store to save registers and the block has a third of the bytes in flight
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < NRND; r++) {
+        const int u = tid * 4 + r * VB * 4;
+        if (u < cnt) {
+            *reinterpret_cast<v4i *>(scol + u) = pc[r];
+#pragma unroll
+            for (int q = 0; q < VU; q++) reinterpret_cast<v2d *>(sval + u)[q] = pv[r * VU + q];
+        }
+    }
+    int rs = 0, re = 0;
+    if (rl < nrows) { rs = rowptr[row0 + rl]; re = rowptr[row0 + rl + 1]; }
+    __syncthreads();
+    // lane (row rl, slot j0) takes entries rs+j0, rs+j0+T, ... of its row
+    V acc = vzero(V());
+    int k = rs + j0;
+    for (; k + (UNR - 1) * T < re; k += UNR * T) {
+        int c[UNR]; V a[UNR], xv[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; q++) { c[q] = scol[k + q * T - base]; a[q] = sval[k + q * T - base]; }
+#pragma unroll
+        for (int q = 0; q < UNR; q++) xv[q] = x[c[q]];
+#pragma unroll
+        for (int q = 0; q < UNR; q++) acc = mac(a[q], xv[q], acc);
+    }
+    for (; k < re; k += T) acc = mac(sval[k - base], x[scol[k - base]], acc);
+    __syncthreads();
+    // the T partial sums of a row meet in LDS (staging buffer reused); y written coalesced
+    if (T > 1) {
+        sred[j0][rl] = acc;
+        __syncthreads();
+        if (j0 == 0 && rl < nrows) {
+            V v = sred[0][rl];
+#pragma unroll
+            for (int j = 1; j < T; j++) v = vadd(v, sred[j][rl]);
+            y[row0 + rl] = ACC ? vadd(y[row0 + rl], v) : v;
+        }
+    } else if (rl < nrows) {
+        y[row0 + rl] = ACC ? vadd(y[row0 + rl], acc) : acc;
+    }
+}
+
+// ---- windowed kernel: some block's rows are too long for one window; the slice is walked
+// window by window (same mapping, general row clipping)
+template <class V, int R, bool ACC>
+__global__ __launch_bounds__(VB) void k_spmv_ldsw(int n, long nnz, const int *__restrict__ rowptr,
+                                                  const int *__restrict__ col, const V *__restrict__ val,
+                                                  const V *__restrict__ x, V *__restrict__ y,
+                                                  const int *done)
+{
+    constexpr int T = VB / R;
+    constexpr int CH = LdsCfg<V>::CH;
+    constexpr int VU = sizeof(V) / 4;
+    __shared__ __attribute__((aligned(16))) V sval[CH];
+    __shared__ __attribute__((aligned(16))) int scol[CH];
+    V(*sred)[R] = reinterpret_cast<V(*)[R]>(sval);
+    if (done && *done) return;
+
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * R;
     const int nrows = min(R, n - row0);
     const int rl = tid % R, j0 = tid / R;
     const int s = rowptr[row0], e = rowptr[row0 + nrows];
     int rs = 0, re = 0;
     if (rl < nrows) { rs = rowptr[row0 + rl]; re = rowptr[row0 + rl + 1]; }
     V acc = vzero(V());
-
-    for (int base = s & ~3; base < e; base += LDS_CH) {
-        const int cnt = min(LDS_CH, e - base);      // entries [base, base+cnt)
-        // ---- stage 1: 4 entries (16 B of col, 32/64 B of val) per lane per step
+    for (int base = s & ~3; base < e; base += CH) {
+        const int cnt = min(CH, e - base);
         for (int u = tid * 4; u < cnt; u += VB * 4) {
             const long g = (long)base + u;
             if (g + 3 < nnz) {
-                const int4 c4 = *reinterpret_cast<const int4 *>(col + g);
-                *reinterpret_cast<int4 *>(scol + u) = c4;
-                if constexpr (sizeof(V) == 8) {
-                    const double2 v0 = *reinterpret_cast<const double2 *>(val + g);
-                    const double2 v1 = *reinterpret_cast<const double2 *>(val + g + 2);
-                    *reinterpret_cast<double2 *>(sval + u) = v0;
-                    *reinterpret_cast<double2 *>(sval + u + 2) = v1;
-                } else {
+                *reinterpret_cast<v4i *>(scol + u) = *reinterpret_cast<const v4i *>(col + g);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) sval[u + q] = val[g + q];
-                }
+                for (int q = 0; q < VU; q++) reinterpret_cast<v2d *>(sval + u)[q] = reinterpret_cast<const v2d *>(val + g)[q];
             } else {
                 for (int q = 0; q < 4 && g + q < nnz; q++) { scol[u + q] = col[g + q]; sval[u + q] = val[g + q]; }
             }
         }
         __syncthreads();
-        // ---- stage 2: my row's entries that sit in this window, stride T from rs + j0
         const int lo = max(rs, base), hi = min(re, base + cnt);
         int k = rs + j0;
         if (k < lo) k += ((lo - k + T - 1) / T) * T;
@@ -159,11 +245,32 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
     if (variant < 0) {
         if (!al16) return fail(hipErrorInvalidValue, "LDS-staged A.x needs 16-byte aligned col/val", __FILE__, __LINE__);
         // rows per block so that R*mean_row entries fit one LDS window
-        int R = variant < -1 ? -variant : (mean_row <= 8.5 ? 256 : mean_row <= 17 ? 128 : mean_row <= 35 ? 64 : mean_row <= 70 ? 32 : 16);
+        // (blocks whose slice exceeds the window take the kernel's window-by-window path)
+        const double cap = LdsCfg<V>::CH - 64;
+        int R = variant < -1 ? -variant
+                             : (256 * mean_row <= cap ? 256 : 128 * mean_row <= cap ? 128 : 64 * mean_row <= cap ? 64
+                                : 32 * mean_row <= cap ? 32 : 16);
+        if (P.slice_R != R) {       // once per (matrix, R): does every block fit one window?
+            int *d = nullptr, h = 0;
+            HIPCHK(hipMalloc(&d, sizeof(int)));
+            HIPCHK(hipMemsetAsync(d, 0, sizeof(int), s));
+            const int nb = (n + R - 1) / R;
+            hipLaunchKernelGGL(k_max_slice, dim3((nb + VB - 1) / VB), dim3(VB), 0, s, n, R, P.rowptr, d);
+            hipError_t e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            hipFree(d);
+            if (e != hipSuccess) return fail(e, "slice scan", __FILE__, __LINE__);
+            P.slice_R = R; P.max_slice = h;
+        }
+        const bool onewin = P.padded && P.max_slice <= LdsCfg<V>::CH;
 #define LDS_CASE(RR)                                                                                   \
     case RR:                                                                                           \
-        hipLaunchKernelGGL((k_spmv_lds<V, RR, ACC>), dim3((((n + RR - 1) / RR + 7) / 8) * 8), dim3(VB), 0, s, n, (long)P.nnz, \
-                           P.rowptr, P.col, val, x, y, done);                                          \
+        if (onewin)                                                                                    \
+            hipLaunchKernelGGL((k_spmv_lds1<V, RR, ACC>), dim3((n + RR - 1) / RR), dim3(VB), 0, s, n,    \
+                               (long)P.nnz, P.rowptr, P.col, val, x, y, done);                         \
+        else                                                                                           \
+            hipLaunchKernelGGL((k_spmv_ldsw<V, RR, ACC>), dim3((n + RR - 1) / RR), dim3(VB), 0, s, n,   \
+                               (long)P.nnz, P.rowptr, P.col, val, x, y, done);                         \
         break;
         switch (R) {
             LDS_CASE(256) LDS_CASE(128) LDS_CASE(64) LDS_CASE(32) LDS_CASE(16)
@@ -490,8 +597,9 @@ static int alloc_part(CsrPart &P, int n_rows, long nnz, bool cplx)
 {
     P.n_rows = n_rows; P.nnz = nnz; P.owned = true;
     HIPCHK(hipMalloc(&P.rowptr, sizeof(int) * ((size_t)n_rows + 1)));
-    HIPCHK(hipMalloc(&P.col, sizeof(int) * (size_t)std::max<long>(nnz, 1) + 16));
-    HIPCHK(hipMalloc(&P.val, sizeof(double) * (cplx ? 2 : 1) * (size_t)std::max<long>(nnz, 1) + 16));
+    HIPCHK(hipMalloc(&P.col, sizeof(int) * (size_t)std::max<long>(nnz, 1) + 64));
+    HIPCHK(hipMalloc(&P.val, sizeof(double) * (cplx ? 2 : 1) * (size_t)std::max<long>(nnz, 1) + 64));
+    P.padded = true;
     return 0;
 }
 
@@ -519,7 +627,7 @@ int lcg_hip_csr_create(lcg_hip_csr_t *out, int n_rows, int n_cols, int64_t nnz, 
     A->n_rows = n_rows; A->n_cols = n_cols; A->is_complex = is_complex != 0;
     A->mean_row = (double)nnz / n_rows;
     if (mem == LCG_HIP_MEM_DEVICE && adopt) {
-        A->main.n_rows = n_rows; A->main.nnz = nnz; A->main.owned = false;
+        A->main.n_rows = n_rows; A->main.nnz = nnz; A->main.owned = false; A->main.padded = adopt == 2;
         A->main.rowptr = const_cast<int *>(rowptr); A->main.col = const_cast<int *>(col); A->main.val = const_cast<double *>(val);
     } else {
         rc = alloc_part(A->main, n_rows, nnz, A->is_complex);
@@ -705,8 +813,9 @@ static int finish_generated(lcg_hip_csr *A, int nloc, long r0, int *counts, hipS
     hipFree(counts);
     if (rc) { hipFree(rowptr); return rc; }
     A->main.n_rows = nloc; A->main.nnz = total; A->main.owned = true; A->main.rowptr = rowptr;
-    e = hipMalloc(&A->main.col, sizeof(int) * (size_t)total + 16);
-    if (e == hipSuccess) e = hipMalloc(&A->main.val, sizeof(double) * (size_t)total + 16);
+    e = hipMalloc(&A->main.col, sizeof(int) * (size_t)total + 64);
+    if (e == hipSuccess) e = hipMalloc(&A->main.val, sizeof(double) * (size_t)total + 64);
+    A->main.padded = true;
     if (e != hipSuccess) return fail(e, "generated arrays", __FILE__, __LINE__);
     fill(rowptr, A->main.col, A->main.val);
     HIPCHK(hipGetLastError());

@@ -90,6 +90,9 @@ struct CsrPart {
     int *col = nullptr;
     double *val = nullptr;
     bool owned = false;
+    bool padded = false;           // >= 64 readable bytes follow col[nnz] and val[nnz]
+    mutable int slice_R = 0;       // rows per block the next field was computed for (0 = not yet)
+    mutable int max_slice = 0;     // largest block slice, entries (csr.hip: k_max_slice)
 };
 
 } // namespace lcgh
