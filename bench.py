@@ -59,9 +59,12 @@ def main():
         raise SystemExit(f"lcg_hip_init failed: {lib.lcg_hip_last_error().decode()}")
 
     dist = None
-    if world > 1:
+    sharded = world > 1 or bool(os.environ.get("LCG_HIP_FORCE_COMM"))    # the env var rehearses the RCCL path on one GPU
+    if sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         partition.init_comm_from_torch(lib)
 
     n = args.rows
@@ -69,18 +72,42 @@ def main():
     nloc = r1 - r0
     symmetric = args.solver in ("cg", "pcg")
     A = api.CsrMatrix.generate(n, args.npairs, args.band, symmetric, 1, 0.01, r0, r1)
-    if world > 1:
-        A.distribute(n)
     nnz_local = A.nnz
     if args.solver == "pcg":
         A.build_jacobi()
     xt = torch.empty(nloc, dtype=torch.float64, device="cuda")
     api.gen_xtrue(n, 1, r0, r1, xt)
     b = torch.empty_like(xt)
-    A.spmv(xt, b)
+    exchange = "none"
+    if sharded:
+        # all-gather of x is the reference exchange; the neighbour (range) exchange moves only the
+        # column ranges the shard touches and is used when it reproduces the all-gather product
+        A.distribute(n, 0)
+        A.spmv(xt, b); api.synchronize()
+        exchange = "all-gather"
+        want = int(os.environ.get("LCG_HIP_DIST_MODE", "1"))
+        if want == 1:
+            b1 = torch.empty_like(b)
+            bad = torch.zeros(1, dtype=torch.float64, device="cuda")
+            try:                            # phase 1: every rank builds its plan (collective inside)
+                A.distribute(n, 1)
+            except Exception as exc:
+                print(f"[rank {rank}] neighbour plan unavailable: {exc}", file=sys.stderr)
+                bad[0] = 1.0
+            dist.all_reduce(bad)
+            if bad.item() == 0.0:           # phase 2: all ranks exchange, or none does
+                A.spmv(xt, b1); api.synchronize()
+                bad[0] = 0.0 if torch.equal(b1, b) else 1.0
+                dist.all_reduce(bad)
+            if bad.item() == 0.0:
+                exchange = "neighbour ranges"
+            else:
+                A.distribute(n, 0)
+    else:
+        A.spmv(xt, b)
     api.synchronize()
     nnz = nnz_local
-    if world > 1:
+    if sharded:
         t = torch.tensor([nnz_local], dtype=torch.int64, device="cuda")
         dist.all_reduce(t)
         nnz = int(t.item())
@@ -142,7 +169,8 @@ def main():
         "config": {"workload": f"synthetic SPD CSR, {'banded-random W=%d' % args.band if args.band else 'scrambled affine maps'}, "
                                f"plain {args.solver.upper()} via lcg_hip_lcg (BASELINE configs[2]/[3])",
                    "rows": n, "nnz": nnz, "nnz_per_row": nnz / n, "solver": args.solver, "index": "int32",
-                   "partition": "single" if world == 1 else f"row-block x{world}, RCCL all-gather(x) + all-reduce(dots)"},
+                   "partition": "single" if not sharded else f"row-block x{world}, RCCL x exchange = {exchange} "
+                                f"({lib.lcg_hip_csr_exchange_volume(A.h)} doubles received per rank per A.x) + all-reduce(dots)"},
         "whole_iteration_algorithmic_GBs": iter_bytes / (elapsed / args.steps) / 1e9,
         "frac_of_hbm_peak_whole_iteration": iter_bytes / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
         "rel_err_vs_x_true": rel_err,

@@ -219,6 +219,8 @@ int lcg_hip_comm_size(void);
  * [r*rows_per_rank, min(n_global,(r+1)*rows_per_rank)).  mode: 0 all-gather, 1 neighbour
  * (halo) exchange of only the referenced entries. */
 int lcg_hip_csr_distribute(lcg_hip_csr_t A, int64_t n_global, int mode);
+/* x entries this rank receives per A.x under the chosen mode (plan volume, for reporting). */
+int64_t lcg_hip_csr_exchange_volume(lcg_hip_csr_t A);
 int lcg_hip_allreduce_sum(double *dev_values, int count);
 int lcg_hip_barrier(void);
 /* Test hooks for the sharded product on ONE GPU: split a shard as rank `rank` of `nranks`
@@ -227,6 +229,7 @@ int lcg_hip_barrier(void);
 int lcg_hip_csr_split_for_test(lcg_hip_csr_t A, int64_t n_global, int nranks, int rank);
 double *lcg_hip_csr_xfull(lcg_hip_csr_t A);
 int64_t lcg_hip_csr_local_nnz(lcg_hip_csr_t A);
+int lcg_hip_csr_need_ranges_for_test(lcg_hip_csr_t A, int nranks, int64_t *lohi /* [2*nranks] */);
 
 #ifdef __cplusplus
 }

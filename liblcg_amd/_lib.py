@@ -92,6 +92,8 @@ SIGNATURES = {
     "lcg_hip_csr_split_for_test": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int]),
     "lcg_hip_csr_xfull": (vp, [vp]),
     "lcg_hip_csr_local_nnz": (C.c_int64, [vp]),
+    "lcg_hip_csr_exchange_volume": (C.c_int64, [vp]),
+    "lcg_hip_csr_need_ranges_for_test": (C.c_int, [vp, C.c_int, vp]),
 }
 
 _lib = None

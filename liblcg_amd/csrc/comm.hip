@@ -15,7 +15,9 @@
 
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "devcommon.hpp"
 
@@ -33,6 +35,11 @@ struct Comm {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    bool force = false;     // LCG_HIP_FORCE_COMM: run the collectives even with one rank (tests)
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -65,12 +72,16 @@ static int load_rccl()
     SYM(CommDestroy, "ncclCommDestroy")
     SYM(AllReduce, "ncclAllReduce")
     SYM(AllGather, "ncclAllGather")
+    SYM(Send, "ncclSend")
+    SYM(Recv, "ncclRecv")
+    SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd")
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
     return 0;
 }
 
-bool comm_active() { return g_comm.comm != nullptr && g_comm.nranks > 1; }
+bool comm_active() { return g_comm.comm != nullptr && (g_comm.nranks > 1 || g_comm.force); }
 
 int comm_allreduce(double *dev, int count, hipStream_t s)
 {
@@ -124,8 +135,104 @@ static int alloc_cols(CsrPart &P, int n, long nnz, bool cplx)
     return 0;
 }
 
+// ---- neighbour (range) exchange plan ---------------------------------------------------------------
+// Instead of gathering all of x, rank r receives from each peer q only the CONTIGUOUS range of q's
+// slice that r's remote columns touch, straight into xfull at its global offset (so the remote
+// part of the shard needs no column remapping).  For a banded matrix that is 2*W entries per rank
+// instead of N*(P-1)/P; for scattered columns it degenerates to the all-gather volume.
+struct HaloPlan {
+    std::vector<long long> need;    // [2*P]: lo, hi (global columns) I need from peer q; lo >= hi = nothing
+    std::vector<long long> give;    // [2*P]: lo, hi (global rows of MINE) peer q needs
+    long long recv_total = 0, send_total = 0;
+};
+
+__global__ void k_need_ranges(long nnz, const int *col, long rpr, int nranks, long long *lohi)
+{
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long)gridDim.x * blockDim.x) {
+        const long c = col[k];
+        const int q = (int)(c / rpr);
+        if (q < nranks) { atomicMin(&lohi[2 * q], (long long)c); atomicMax(&lohi[2 * q + 1], (long long)c + 1); }
+    }
+}
+
+// lo/hi per owner rank of the remote part's columns (device scan, host result)
+static int need_ranges(lcg_hip_csr *A, int nranks, std::vector<long long> &out)
+{
+    Ctx &c = ctx();
+    out.assign(2 * (size_t)nranks, 0);
+    for (int q = 0; q < nranks; q++) { out[2 * q] = (1LL << 62); out[2 * q + 1] = 0; }
+    if (A->rem.nnz == 0) return 0;
+    long long *d = nullptr;
+    HIPCHK(hipMalloc(&d, sizeof(long long) * 2 * nranks));
+    hipError_t e = hipMemcpyAsync(d, out.data(), sizeof(long long) * 2 * nranks, hipMemcpyHostToDevice, c.stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_need_ranges, dim3(1024), dim3(VB), 0, c.stream, (long)A->rem.nnz, A->rem.col, (long)A->rows_per_rank, nranks, d);
+        e = hipMemcpyAsync(out.data(), d, sizeof(long long) * 2 * nranks, hipMemcpyDeviceToHost, c.stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(e, "halo ranges", __FILE__, __LINE__);
+    return 0;
+}
+
+static int halo_setup(lcg_hip_csr *A)
+{
+    Ctx &c = ctx();
+    const int P = g_comm.nranks, me = g_comm.rank;
+    HaloPlan *h = new HaloPlan();
+    int rc = need_ranges(A, P, h->need);
+    if (rc) { delete h; return rc; }
+    // everybody learns everybody's needs: table[q][p] = what q needs from p
+    long long *dmine = nullptr, *dall = nullptr;
+    std::vector<long long> table(2 * (size_t)P * P);
+    hipError_t e = hipMalloc(&dall, sizeof(long long) * 2 * P * P);
+    if (e != hipSuccess) { delete h; return fail(e, "halo table", __FILE__, __LINE__); }
+    dmine = dall + 2 * (size_t)P * me;
+    e = hipMemcpyAsync(dmine, h->need.data(), sizeof(long long) * 2 * P, hipMemcpyHostToDevice, c.stream);
+    if (e == hipSuccess) {
+        ncclResult_t r = g_comm.AllGather(dmine, dall, 2 * (size_t)P, ncclInt64, g_comm.comm, c.stream);
+        if (r != ncclSuccess) { hipFree(dall); delete h; return comm_fail("halo ncclAllGather", r); }
+        e = hipMemcpyAsync(table.data(), dall, sizeof(long long) * 2 * P * P, hipMemcpyDeviceToHost, c.stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    hipFree(dall);
+    if (e != hipSuccess) { delete h; return fail(e, "halo table exchange", __FILE__, __LINE__); }
+    h->give.assign(2 * (size_t)P, 0);
+    for (int q = 0; q < P; q++) {
+        h->give[2 * q] = table[2 * ((size_t)q * P + me)];
+        h->give[2 * q + 1] = table[2 * ((size_t)q * P + me) + 1];
+        if (q == me) { h->need[2 * q] = h->need[2 * q + 1] = 0; h->give[2 * q] = h->give[2 * q + 1] = 0; }
+        if (h->need[2 * q + 1] > h->need[2 * q]) h->recv_total += h->need[2 * q + 1] - h->need[2 * q];
+        if (h->give[2 * q + 1] > h->give[2 * q]) h->send_total += h->give[2 * q + 1] - h->give[2 * q];
+    }
+    A->halo = h;
+    return 0;
+}
+
+static int halo_exchange(lcg_hip_csr *A, const double *x, hipStream_t s)
+{
+    const HaloPlan *h = static_cast<const HaloPlan *>(A->halo);
+    const int P = g_comm.nranks;
+    const size_t w = A->is_complex ? 2 : 1;
+    ncclResult_t r = g_comm.GroupStart();
+    if (r != ncclSuccess) return comm_fail("ncclGroupStart", r);
+    for (int q = 0; q < P && r == ncclSuccess; q++) {
+        const long long lo = h->give[2 * q], hi = h->give[2 * q + 1];
+        if (hi > lo) r = g_comm.Send(x + w * (size_t)(lo - A->row0), w * (size_t)(hi - lo), ncclDouble, q, g_comm.comm, s);
+    }
+    for (int q = 0; q < P && r == ncclSuccess; q++) {
+        const long long lo = h->need[2 * q], hi = h->need[2 * q + 1];
+        if (hi > lo) r = g_comm.Recv(A->xfull + w * (size_t)lo, w * (size_t)(hi - lo), ncclDouble, q, g_comm.comm, s);
+    }
+    ncclResult_t r2 = g_comm.GroupEnd();
+    if (r != ncclSuccess) return comm_fail("ncclSend/Recv", r);
+    if (r2 != ncclSuccess) return comm_fail("ncclGroupEnd", r2);
+    return 0;
+}
+
 void dist_free(lcg_hip_csr *A)
 {
+    if (A->halo) { delete static_cast<HaloPlan *>(A->halo); A->halo = nullptr; }
     if (!A->distributed) return;
     free_part(A->loc); free_part(A->rem);
     if (A->xfull) hipFree(A->xfull);
@@ -183,10 +290,16 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
     // gather on the second stream ...
     HIPCHK(hipEventRecord(c.ev_a, c.stream));
     HIPCHK(hipStreamWaitEvent(c.comm_stream, c.ev_a, 0));
-    HIPCHK(hipMemcpyAsync(mine, x, sizeof(double) * w * (size_t)A->n_rows, hipMemcpyDeviceToDevice, c.comm_stream));
-    if (g_comm.comm) {
-        ncclResult_t r = g_comm.AllGather(mine, A->xfull, w * (size_t)A->rows_per_rank, ncclDouble, g_comm.comm, c.comm_stream);
-        if (r != ncclSuccess) return comm_fail("ncclAllGather", r);
+    if (g_comm.comm && A->dist_mode == 1 && A->halo) {
+        // neighbour exchange: only the ranges the remote columns touch (the local product reads x itself)
+        int rc = halo_exchange(A, x, c.comm_stream);
+        if (rc) return rc;
+    } else {
+        HIPCHK(hipMemcpyAsync(mine, x, sizeof(double) * w * (size_t)A->n_rows, hipMemcpyDeviceToDevice, c.comm_stream));
+        if (g_comm.comm) {
+            ncclResult_t r = g_comm.AllGather(mine, A->xfull, w * (size_t)A->rows_per_rank, ncclDouble, g_comm.comm, c.comm_stream);
+            if (r != ncclSuccess) return comm_fail("ncclAllGather", r);
+        }
     }
     HIPCHK(hipEventRecord(c.ev_b, c.comm_stream));
     // ... while the locally-owned columns are multiplied
@@ -228,6 +341,7 @@ int lcg_hip_comm_init(int nranks, int rank, const void *id128)
     ncclResult_t r = g_comm.CommInitRank(&g_comm.comm, nranks, id, rank);
     if (r != ncclSuccess) { g_comm.comm = nullptr; return comm_fail("ncclCommInitRank", r); }
     g_comm.nranks = nranks; g_comm.rank = rank;
+    g_comm.force = std::getenv("LCG_HIP_FORCE_COMM") != nullptr;
     return 0;
 }
 
@@ -245,7 +359,29 @@ int lcg_hip_csr_distribute(lcg_hip_csr_t A, int64_t n_global, int mode)
 {
     if (!A || n_global <= 0) return LCG_HIP_E_ARG;
     A->dist_mode = mode;
-    return dist_split(A, n_global, g_comm.nranks, g_comm.rank);
+    int rc = dist_split(A, n_global, g_comm.nranks, g_comm.rank);
+    if (rc) return rc;
+    if (mode == 1 && g_comm.comm) rc = halo_setup(A);
+    return rc;
+}
+
+// entries of x this rank receives per A.x (doubles; complex counts twice): plan volume
+int64_t lcg_hip_csr_exchange_volume(lcg_hip_csr_t A)
+{
+    if (!A || !A->distributed) return 0;
+    if (A->dist_mode == 1 && A->halo) return static_cast<const HaloPlan *>(A->halo)->recv_total;
+    return (int64_t)A->rows_per_rank * (g_comm.nranks - 1);
+}
+
+// test hook: the [lo,hi) column range needed from each of `nranks` owners (after split_for_test)
+int lcg_hip_csr_need_ranges_for_test(lcg_hip_csr_t A, int nranks, int64_t *lohi)
+{
+    if (!A || !A->distributed || !lohi) return LCG_HIP_E_ARG;
+    std::vector<long long> v;
+    int rc = need_ranges(A, nranks, v);
+    if (rc) return rc;
+    for (int i = 0; i < 2 * nranks; i++) lohi[i] = v[i];
+    return 0;
 }
 
 // test hook: split a shard as rank `rank` of `nranks` without any communicator; the caller

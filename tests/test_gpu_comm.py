@@ -1,0 +1,72 @@
+"""-m gpu: what can be verified of the sharded path on ONE GPU.
+
+ * the neighbour-exchange plan: the per-owner column ranges computed on the device equal the
+   ranges computed from the oracle's rows;
+ * the RCCL plumbing end to end with a one-rank communicator (LCG_HIP_FORCE_COMM): unique id
+   courier over torch.distributed, ncclCommInitRank, all-gather / grouped send-recv on the second
+   stream, all-reduce inside the scalar steps -- bench.py must produce the same iterates as the
+   unsharded run.
+The multi-rank data path itself is rehearsed on the CPU in tests/test_dist_cpu.py.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_need_ranges_match_oracle_rows(port):
+    from liblcg_amd import _lib, api, partition
+    lib = _lib.load()
+    n, nranks = 20011, 4
+    for band in (300, 0):
+        g = port.gen_init(n, 16, band, True, 2, 0.01)
+        rpr = partition.rows_per_rank(n, nranks)
+        for r in range(nranks):
+            r0, r1 = partition.shard_range(n, nranks, r)
+            rp, ci, v = port.gen_rows(g, r0, r1)
+            A = api.CsrMatrix.generate(n, 16, band, True, 2, 0.01, r0, r1)
+            assert lib.lcg_hip_csr_split_for_test(A.h, n, nranks, r) == 0
+            out = (C.c_int64 * (2 * nranks))()
+            assert lib.lcg_hip_csr_need_ranges_for_test(A.h, nranks, out) == 0
+            for q in range(nranks):
+                cols = ci[(ci // rpr) == q]
+                lo, hi = out[2 * q], out[2 * q + 1]
+                if q == r or len(cols) == 0:
+                    assert hi <= lo or q == r
+                else:
+                    assert (lo, hi) == (cols.min(), cols.max() + 1)
+            if band:    # a banded shard only talks to its neighbours, and only about 2*band entries
+                far = [q for q in range(nranks) if abs(q - r) > 1]
+                assert all(out[2 * q + 1] <= out[2 * q] for q in far)
+                vol = sum(max(0, out[2 * q + 1] - out[2 * q]) for q in range(nranks) if q != r)
+                assert vol <= 2 * band
+
+
+def _run_bench(extra_env, *args):
+    env = dict(os.environ, **extra_env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--rows", "400000",
+                        "--band", "5000", "--steps", "30", "--warmup", "3", *args],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_one_rank_communicator_reproduces_unsharded_run(mode):
+    plain = _run_bench({})
+    forced = _run_bench({"LCG_HIP_FORCE_COMM": "1", "LCG_HIP_DIST_MODE": mode, "MASTER_PORT": "29541"})
+    assert forced["config"]["partition"].startswith("row-block x1")
+    assert ("neighbour" in forced["config"]["partition"]) == (mode == "1")
+    assert forced["config"]["nnz"] == plain["config"]["nnz"]
+    assert forced["steps"] == plain["steps"] == 30
+    # same matrix, same arithmetic: the error after 30 iterations agrees to rounding
+    assert abs(forced["rel_err_vs_x_true"] - plain["rel_err_vs_x_true"]) <= 1e-6 * plain["rel_err_vs_x_true"] + 1e-15
