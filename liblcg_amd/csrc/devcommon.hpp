@@ -162,12 +162,24 @@ __global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, in
     constexpr int NRA = Fin::NR > 0 ? Fin::NR : 1;
     __shared__ double sums[NRA];
     if (mode != SC_FIN && Fin::NR > 0) {
-        double acc[NRA];
+        // all NRA * MAXG/VB loads of a lane are issued before the first add (a dependent
+        // load-add chain made this one-block kernel take 16 us); fixed order => reproducible
+        constexpr int PER = MAXG / VB;
+        double acc[NRA], v[NRA][PER];
+#pragma unroll
+        for (int r = 0; r < NRA; r++)
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const int j = threadIdx.x + q * VB;
+                const double x = partials[r * MAXG + (j < G ? j : 0)];     // branch-free: select after the load
+                v[r][q] = j < G ? x : 0.0;
+            }
 #pragma unroll
         for (int r = 0; r < NRA; r++) {
-            double v = 0.0;
-            for (int j = threadIdx.x; j < G; j += VB) v += partials[r * MAXG + j];
-            acc[r] = v;
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < PER; q++) t += v[r][q];
+            acc[r] = t;
         }
         __shared__ double sh[NRA][VB / 64];
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
