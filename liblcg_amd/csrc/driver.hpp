@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <typeinfo>
 
 #include "devcommon.hpp"
 
@@ -32,7 +33,9 @@ struct Driver {
     Driver(const Driver &) = delete;
 
     // ---- launches ------------------------------------------------------------------------
-    template <class Op> int vec(Op op, uintptr_t align_or = 0)
+    template <class Op> int vec(Op op, uintptr_t align_or = 0) { return vec_n(op, n, align_or); }
+    // same pass over a vector of another length (e.g. the per-block partials of a fused A.x)
+    template <class Op> int vec_n(Op op, long n, uintptr_t align_or)
     {
         // complex vectors are naturally 16-byte elements; reals use the 2-wide path when
         // every pointer is 16-byte aligned
@@ -48,9 +51,19 @@ struct Driver {
         }
         last_g = g;
         HIPCHK(hipGetLastError());
-        return 0;
+        return dbg(typeid(Op).name());
     }
     int last_g = 1;
+    // LCG_HIP_DEBUG_SYNC=1: synchronise after every launch and name it on stderr (fault isolation)
+    bool debug_sync = std::getenv("LCG_HIP_DEBUG_SYNC") != nullptr;
+    int dbg(const char *what)
+    {
+        if (!debug_sync) return 0;
+        std::fprintf(stderr, "[lcg_hip] %s ...", what); std::fflush(stderr);
+        HIPCHK(hipStreamSynchronize(c.stream));
+        std::fprintf(stderr, " ok\n");
+        return 0;
+    }
 
     // scalar step after the most recent reducing vec()
     template <class Fin> int scal(Fin fin) { return scal_g(fin, last_g); }
@@ -65,7 +78,7 @@ struct Driver {
             hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FUSED);
         }
         HIPCHK(hipGetLastError());
-        return 0;
+        return dbg(typeid(Fin).name());
     }
 
     // ---- state -------------------------------------------------------------------------------
