@@ -132,9 +132,9 @@ int lcg_hip_lcg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const doubl
 int lcg_hip_lcgs(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B, int n_size,
                  const lcg_para *param, void *instance, double *RK, double *R0T, double *PK,
                  double *AX, double *UK, double *QK, double *WK, int mem);
-/* clcg.h:74-76 clcg_solver() -> clcg.cpp:46-74.  solver_id: CLCG_BICG_SYM, CLCG_CGS,
- * CLCG_BICGSTAB, CLCG_TFQMR; CLCG_BICG (needs A^H.x) and unknown ids run CGS like the
- * reference's default branch.  The shadow residual of CGS/BiCGStab/TFQMR is drawn from
+/* clcg.h:74-76 clcg_solver() -> clcg.cpp:46-74.  solver_id: CLCG_BICG (the callback is asked
+ * for A^H.x, clcg.cpp:187), CLCG_BICG_SYM, CLCG_CGS, CLCG_BICGSTAB, CLCG_TFQMR; other ids run
+ * CGS like the reference's default branch.  The shadow residual of CGS/BiCGStab/TFQMR is drawn from
  * lcg_hip_set_shadow_seed() (default 1) instead of srand(time(0)) (lcg_complex.cpp:118-127). */
 int clcg_hip_solver(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, double *m, const double *B,
                     int n_size, const clcg_para *param, void *instance, int solver_id, int mem);
@@ -181,6 +181,10 @@ void clcg_hip_csr_ax(void *instance, const double *x, double *prod_Ax, const int
 /* Stand-alone launches of the hot-path kernels on the current stream (device pointers).
  * Scalar results are written to host memory after a stream synchronise. */
 int lcg_hip_spmv(lcg_hip_csr_t A, const double *x, double *y);                  /* y = A.x */
+/* y = op(A).x, layout 1 = transpose, conjugate 1 = conjugated entries (A^H = both): the
+ * MatTranspose / Conjugate products the reference's callbacks are asked for (clcg.h:40-41,
+ * clcg.cpp:187; cusparseSpMV with CUSPARSE_OPERATION_*TRANSPOSE in sample9.cu:97). */
+int lcg_hip_spmv_op(lcg_hip_csr_t A, const double *x, double *y, int layout, int conjugate);
 int lcg_hip_dot(int n, const double *a, const double *b, double *result);      /* lcg_dot, algebra.cpp:154-163; cublasDdot lcg_cuda.cu:187 */
 int lcg_hip_nrm2(int n, const double *a, double *result);                      /* cublasDznrm2-style 2-norm */
 int lcg_hip_axpy(int n, double alpha, const double *x, double *y);             /* y += alpha*x, cublasDaxpy lcg_cuda.cu:190 */

@@ -609,6 +609,98 @@ void free_part(CsrPart &P)
     P = CsrPart();
 }
 
+// ------------------------------------------------------------- op(A): A^T, A^H, conj(A)
+// The reference's complex callback carries (layout, conjugate) (clcg.h:40-41); BiCG asks for
+// A^H.x (clcg.cpp:187).  op(A) is materialised once as its own CSR (counting pass, scan,
+// scatter, then a per-row sort so the summation order -- and with it the result -- does not
+// depend on the order in which the scatter's atomics happened to land) and then multiplied by
+// the same A.x kernels.
+__global__ void k_tr_count(long nnz, const int *col, int *cnt)
+{
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long)gridDim.x * blockDim.x)
+        atomicAdd(&cnt[col[k]], 1);
+}
+template <class V>
+__global__ void k_tr_fill(int n, const int *rowptr, const int *col, const V *val, const int *rpT, int *next, int *colT,
+                          V *valT, int conj)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) {
+        const int c = col[k];
+        const int pos = rpT[c] + atomicAdd(&next[c], 1);
+        colT[pos] = i;
+        V v = val[k];
+        if constexpr (sizeof(V) == 16) { if (conj) v.y = -v.y; }
+        valT[pos] = v;
+    }
+}
+template <class V>
+__global__ void k_row_sort(int n, const int *rowptr, int *col, V *val)
+{   // insertion sort by column inside each row (rows are short)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = rowptr[i], e = rowptr[i + 1];
+    for (int a = s + 1; a < e; a++) {
+        const int c = col[a]; const V v = val[a];
+        int b = a - 1;
+        while (b >= s && col[b] > c) { col[b + 1] = col[b]; val[b + 1] = val[b]; b--; }
+        col[b + 1] = c; val[b + 1] = v;
+    }
+}
+__global__ void k_conj_copy(long nnz, const double2 *in, double2 *out)
+{
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long)gridDim.x * blockDim.x)
+        out[k] = make_double2(in[k].x, -in[k].y);
+}
+
+// part of `A` that realises op(A); built on first use.  layout/conjugate as in algebra.h:31-50.
+int op_part(lcg_hip_csr *A, int layout, int conjugate, const CsrPart **out)
+{
+    if (!A->is_complex) conjugate = 0;
+    const int idx = (layout ? 2 : 0) + (conjugate ? 1 : 0);
+    if (idx == 0) { *out = &A->main; return 0; }
+    CsrPart &T = A->op[idx];
+    if (T.rowptr) { *out = &T; return 0; }
+    if (A->distributed || A->n_cols != A->n_rows) return fail(hipErrorInvalidValue, "op(A) needs a square, unsharded matrix", __FILE__, __LINE__);
+    Ctx &c = ctx();
+    const int n = A->n_rows;
+    const long nnz = A->main.nnz;
+    int rc = alloc_part(T, n, nnz, A->is_complex);
+    if (rc) return rc;
+    if (!layout) {      // conj(A): same structure
+        HIPCHK(hipMemcpyAsync(T.rowptr, A->main.rowptr, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToDevice, c.stream));
+        HIPCHK(hipMemcpyAsync(T.col, A->main.col, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToDevice, c.stream));
+        hipLaunchKernelGGL(k_conj_copy, dim3(1024), dim3(VB), 0, c.stream, nnz, reinterpret_cast<const double2 *>(A->main.val),
+                           reinterpret_cast<double2 *>(T.val));
+    } else {
+        int *cnt = nullptr;
+        HIPCHK(hipMalloc(&cnt, sizeof(int) * (size_t)n));
+        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)n, c.stream));
+        hipLaunchKernelGGL(k_tr_count, dim3(1024), dim3(VB), 0, c.stream, nnz, A->main.col, cnt);
+        long total = 0;
+        rc = device_exclusive_scan(n, cnt, T.rowptr, c.stream, &total);
+        if (rc || total != nnz) { hipFree(cnt); return rc ? rc : fail(hipErrorUnknown, "transpose count", __FILE__, __LINE__); }
+        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)n, c.stream));
+        const unsigned g = (unsigned)((n + VB - 1) / VB);
+        if (A->is_complex) {
+            hipLaunchKernelGGL((k_tr_fill<double2>), dim3(g), dim3(VB), 0, c.stream, n, A->main.rowptr, A->main.col,
+                               reinterpret_cast<const double2 *>(A->main.val), T.rowptr, cnt, T.col, reinterpret_cast<double2 *>(T.val), conjugate);
+            hipLaunchKernelGGL((k_row_sort<double2>), dim3(g), dim3(VB), 0, c.stream, n, T.rowptr, T.col, reinterpret_cast<double2 *>(T.val));
+        } else {
+            hipLaunchKernelGGL((k_tr_fill<double>), dim3(g), dim3(VB), 0, c.stream, n, A->main.rowptr, A->main.col, A->main.val,
+                               T.rowptr, cnt, T.col, T.val, 0);
+            hipLaunchKernelGGL((k_row_sort<double>), dim3(g), dim3(VB), 0, c.stream, n, T.rowptr, T.col, T.val);
+        }
+        hipError_t e = hipStreamSynchronize(c.stream);
+        hipFree(cnt);
+        if (e != hipSuccess) return fail(e, "transpose build", __FILE__, __LINE__);
+    }
+    HIPCHK(hipGetLastError());
+    *out = &T;
+    return 0;
+}
+
 } // namespace lcgh
 
 using namespace lcgh;
@@ -712,6 +804,7 @@ int lcg_hip_csr_destroy(lcg_hip_csr_t A)
     if (!A) return 0;
     dist_free(A);
     free_part(A->main);
+    for (int i = 1; i < 4; i++) free_part(A->op[i]);
     if (A->invdiag) hipFree(A->invdiag);
     delete A;
     return 0;
@@ -762,8 +855,20 @@ void lcg_hip_csr_ax(void *instance, const double *x, double *y, const int n)
 
 void clcg_hip_csr_ax(void *instance, const double *x, double *y, const int n, int layout, int conjugate)
 {
-    (void)layout; (void)conjugate; (void)n;
-    lcg_hip_spmv(static_cast<lcg_hip_csr *>(instance), x, y);
+    (void)n;
+    lcg_hip_spmv_op(static_cast<lcg_hip_csr *>(instance), x, y, layout, conjugate);
+}
+
+int lcg_hip_spmv_op(lcg_hip_csr_t A, const double *x, double *y, int layout, int conjugate)
+{
+    if (!A || !x || !y) return LCG_HIP_E_ARG;
+    if (!layout && (!conjugate || !A->is_complex)) return lcg_hip_spmv(A, x, y);
+    Ctx &c = ctx();
+    const CsrPart *P = nullptr;
+    int rc = op_part(A, layout, conjugate, &P);
+    if (rc) return rc;
+    return spmv_launch(*P, A->is_complex, A->variant, A->mean_row, x, y, false, c.stream,
+                       c.in_solve ? &c.state->done : nullptr);
 }
 
 void lcg_hip_jacobi_mx(void *instance, const double *x, double *z, const int n)

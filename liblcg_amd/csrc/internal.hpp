@@ -102,6 +102,7 @@ struct lcg_hip_csr {
     int n_cols = 0;         // columns addressed by `main` (global when sharded)
     bool is_complex = false;
     lcgh::CsrPart main;     // the whole shard (global columns)
+    lcgh::CsrPart op[4];    // [1] conj(A), [2] A^T, [3] A^H as their own CSR, built on first use (csr.hip: op_part)
     double *invdiag = nullptr;  // reciprocal diagonal (1 or 2 doubles per row)
     int variant = 0;        // SpMV kernel choice (0 auto)
     double mean_row = 0.0;
@@ -123,6 +124,7 @@ namespace lcgh {
 int spmv_launch(const CsrPart &P, bool is_complex, int variant, double mean_row, const double *x,
                 double *y, bool accumulate, hipStream_t s, const int *done_flag);
 int jacobi_launch(const lcg_hip_csr *A, const double *x, double *z, int n, hipStream_t s);
+int op_part(lcg_hip_csr *A, int layout, int conjugate, const CsrPart **out);
 
 // comm.cpp
 int comm_allreduce(double *dev, int count, hipStream_t s);

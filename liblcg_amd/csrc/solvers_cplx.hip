@@ -145,6 +145,55 @@ struct OpZXpay {        // d = r + b d       (clcg.cpp:349-353)
     template <class T> __device__ void apply(long i, double *) { S(d, i, cfma(bk, L(d, i), L(r, i))); }
 };
 
+// ---- BiCG (clcg.cpp:77-226): needs A^H.x --------------------------------------------------------
+__device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+struct OpBicgInit {     // d1 = r1 = B - Ax; d2 = r2 = conj(r1); |m|^2, |r1|^2, <r2,r1>   (clcg.cpp:101-120)
+    static constexpr int NR = 4, SKIP = SKIP_NEVER;
+    DevState *st; const double *Ax, *B, *m; double *r1, *r2, *d1, *d2;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const double2 rv = csub(L(B, i), L(Ax, i)), mv = L(m, i), rc = cconj(rv);
+        S(r1, i, rv); S(d1, i, rv); S(r2, i, rc); S(d2, i, rc);
+        acc[0] += cnorm(mv); acc[1] += cnorm(rv);
+        acc_inner(acc + 2, rc, rv);
+    }
+};
+struct OpBicgUpd1 {     // m += a d1; r1 -= a Ax                               (clcg.cpp:173-178)
+    static constexpr int NR = 0, SKIP = SKIP_DONE;
+    DevState *st; double *m, *r1; const double *d1, *Ax; double2 ak;
+    __device__ void prep() { ak = lds2(st, C_AK); }
+    template <class T> __device__ void apply(long i, double *)
+    {
+        S(m, i, cfma(ak, L(d1, i), L(m, i)));
+        S(r1, i, cfma(cneg(ak), L(Ax, i), L(r1, i)));
+    }
+};
+struct OpBicgUpd2 {     // r2 -= conj(a) A^H d2; |m|^2, |r1|^2, <r2,r1>, NaN  (clcg.cpp:180-203)
+    static constexpr int NR = 5, SKIP = SKIP_DONE;
+    DevState *st; double *r2; const double *AHd, *m, *r1; double2 akc;
+    __device__ void prep() { akc = cconj(lds2(st, C_AK)); }
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const double2 r2v = cfma(cneg(akc), L(AHd, i), L(r2, i));
+        const double2 mv = L(m, i), r1v = L(r1, i);
+        S(r2, i, r2v);
+        acc[0] += cnorm(mv); acc[1] += cnorm(r1v);
+        acc_inner(acc + 2, r2v, r1v);
+        acc[4] += cnan(mv);
+    }
+};
+struct OpBicgDir2 {     // d1 = r1 + b d1; d2 = r2 + conj(b) d2                (clcg.cpp:207-212)
+    static constexpr int NR = 0, SKIP = SKIP_DIR;
+    DevState *st; double *d1, *d2; const double *r1, *r2; double2 bk;
+    __device__ void prep() { bk = lds2(st, C_BK); }
+    template <class T> __device__ void apply(long i, double *)
+    {
+        S(d1, i, cfma(bk, L(d1, i), L(r1, i)));
+        S(d2, i, cfma(cconj(bk), L(d2, i), L(r2, i)));
+    }
+};
+
 // ---- CGS / BiCGStab / TFQMR shared ----------------------------------------------------------------
 template <int MODE>   // 0 CGS: p = u = r; 1 BiCGStab: p = r; 2 TFQMR: p = u = r, d = 0
 struct OpZShadowInit {  // r = B - Ax ...; |m|^2, |r|^2, <rbar0, r>
@@ -359,6 +408,7 @@ struct CplxCommon {
     CplxCommon(Ctx &c_, int n_, const clcg_para &p, void *inst_, clcg_hip_axfunc_ptr A, clcg_hip_progress_ptr P, double *m_)
         : c(c_), drv(c_, n_, true, p.max_iterations, p.epsilon, p.abs_diff), para(p), inst(inst_), Afp(A), Pfp(P), m(m_), n(n_) {}
     int ax(const double *x, double *y) { return drv.timed_ax([&] { Afp(inst, x, y, n, 0, 0); }); }
+    int axop(const double *x, double *y, int layout, int conj) { return drv.timed_ax([&] { Afp(inst, x, y, n, layout, conj); }); }
     int run_loop(const std::function<int()> &body)
     {
         auto pfp = [&](double resid, int t) -> int { return Pfp(inst, m, resid, &para, n, t); };
@@ -382,6 +432,40 @@ static int make_shadow(Ctx &c, int n, double *dev)
     HIPCHK(hipMemcpyAsync(dev, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
     return 0;
+}
+
+static int solve_cbicg(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, double *m, const double *B, int n,
+                       const clcg_para *param, void *inst, int mem)
+{
+    const clcg_para p = param ? *param : clcg_hip_default_parameters();
+    TRY(ccheck_args(p, n, m, B));
+    TRY(ensure_init());
+    Ctx &c = ctx();
+    const size_t nb = sizeof(double) * 2 * (size_t)n;
+    HostBridge hb; TRY(hb.open(mem, m, B, nb, c.stream));
+    Workspace ws; double *r1, *r2, *d1, *d2, *Ax;
+    TRY(ws.get(r1, nullptr, nb)); TRY(ws.get(r2, nullptr, nb)); TRY(ws.get(d1, nullptr, nb));
+    TRY(ws.get(d2, nullptr, nb)); TRY(ws.get(Ax, nullptr, nb));
+    CplxCommon k(c, n, p, inst, Afp, Pfp, m);
+    TRY(k.drv.init_state(global_rows(c, n)));
+    DevState *st = c.state;
+
+    TRY(k.ax(m, Ax));                                                   // clcg.cpp:99
+    TRY(k.drv.vec(OpBicgInit{st, Ax, B, m, r1, r2, d1, d2}));           // :101-120
+    TRY(k.drv.scal(FinZInit<false>{}));
+    int rc = k.run_loop([&]() -> int {
+        TRY(k.ax(d1, Ax));                                              // :169
+        TRY(k.drv.vec(OpZDot<true>{st, d2, Ax}));                       // :170
+        TRY(k.drv.scal(FinZAlpha{C_RHO}));                              // :171
+        TRY(k.drv.vec(OpBicgUpd1{st, m, r1, d1, Ax, {}}));              // :173-178
+        TRY(k.axop(d2, Ax, 1, 1));                                      // :187  A^H.d2
+        TRY(k.drv.vec(OpBicgUpd2{st, r2, Ax, m, r1, {}}));              // :180-203
+        TRY(k.drv.scal(FinZClose<0>{}));                                // :204-205
+        TRY(k.drv.vec(OpBicgDir2{st, d1, d2, r1, r2, {}}));             // :207-212
+        return 0;
+    });
+    int rc2 = hb.close(c.stream);
+    return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
 }
 
 static int solve_bicg_sym(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, double *m, const double *B, int n,
@@ -543,6 +627,7 @@ extern "C" int clcg_hip_solver(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pf
                                const clcg_para *param, void *instance, int solver_id, int mem)
 {
     switch (solver_id) {                                                // clcg.cpp:46-74
+    case CLCG_BICG: return solve_cbicg(Afp, Pfp, m, B, n, param, instance, mem);
     case CLCG_BICG_SYM: return solve_bicg_sym(Afp, Pfp, m, B, n, param, instance, mem);
     case CLCG_BICGSTAB: return solve_cbicgstab(Afp, Pfp, m, B, n, param, instance, mem);
     case CLCG_TFQMR: return solve_tfqmr(Afp, Pfp, m, B, n, param, instance, mem);

@@ -110,6 +110,54 @@ static double m4_of(const zc *m, int n)
     return v < 1.0 ? 1.0 : v;
 }
 
+/* ----------------------------------------------------------------- BiCG */
+int orc_clbicg(orc_caxfunc Afp, orc_cprogress Pfp, zc *m, const zc *B, int n,
+               const orc_cpara *param, void *inst)
+{
+    orc_cpara p = param ? *param : orc_cdefaults;
+    int ret = ccheck_args(&p, n, m, B);
+    if (ret) return ret;
+    zc *r1 = malloc(sizeof(zc) * n), *r2 = malloc(sizeof(zc) * n), *d1 = malloc(sizeof(zc) * n),
+       *d2 = malloc(sizeof(zc) * n), *Ax = malloc(sizeof(zc) * n);
+    int t = 0;
+
+    Afp(inst, m, Ax, n, 0, 0);                                  /* clcg.cpp:99 */
+    for (int i = 0; i < n; i++) {                               /* :101-106 */
+        d1[i] = r1[i] = B[i] - Ax[i];
+        d2[i] = r2[i] = conj(r1[i]);
+    }
+    zc rho = orc_cinner(r2, r1, n);                             /* :108-109 */
+    double m4 = m4_of(m, n);                                    /* :111-115 */
+    double r4 = zsquare(orc_cinner(r1, r1, n));                 /* :117-120 */
+
+    if (calready_done(&p, Pfp, inst, m, r4, m4, n)) { ret = ORC_ALREADY_OPTIMIZIED; goto out; }
+
+    while (!cloop_head(&p, Pfp, inst, m, r4, m4, n, &t, &ret)) {
+        Afp(inst, d1, Ax, n, 0, 0);                             /* :169 */
+        zc Add = orc_cinner(d2, Ax, n);                         /* :170 */
+        zc ak = rho / Add;                                      /* :171 */
+        for (int i = 0; i < n; i++) {                           /* :173-178 */
+            m[i] = m[i] + ak * d1[i];
+            r1[i] = r1[i] - ak * Ax[i];
+        }
+        m4 = m4_of(m, n);                                       /* :180-182 */
+        r4 = zsquare(orc_cinner(r1, r1, n));                    /* :184-185 */
+        Afp(inst, d2, Ax, n, 1, 1);                             /* :187: A^H */
+        for (int i = 0; i < n; i++) r2[i] = r2[i] - conj(ak) * Ax[i];   /* :189-193 */
+        if (chas_nan(m, n)) { ret = ORC_C_NAN_VALUE; goto out; } /* :195-201 */
+        zc rho2 = orc_cinner(r2, r1, n);                        /* :203 */
+        zc bk = rho2 / rho;                                     /* :204 */
+        rho = rho2;
+        for (int i = 0; i < n; i++) {                           /* :207-212 */
+            d1[i] = r1[i] + bk * d1[i];
+            d2[i] = r2[i] + conj(bk) * d2[i];
+        }
+    }
+out:
+    free(r1); free(r2); free(d1); free(d2); free(Ax);
+    return ret;
+}
+
 /* ------------------------------------------------- BiCG, complex-symmetric A */
 int orc_clbicg_symmetric(orc_caxfunc Afp, orc_cprogress Pfp, zc *m, const zc *B, int n,
                          const orc_cpara *param, void *inst)

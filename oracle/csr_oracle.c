@@ -60,6 +60,23 @@ void orc_csr_cmatvec(const int *rowptr, const int *col, const zc *val, const zc 
     }
 }
 
+void orc_csr_cmatvec_op(const int *rowptr, const int *col, const zc *val, const zc *x, zc *y,
+                        int n, int transpose, int conjugate)
+{
+    if (!transpose) {
+        for (int i = 0; i < n; i++) {
+            zc s = CMPLX(0.0, 0.0);
+            for (int k = rowptr[i]; k < rowptr[i + 1]; k++) s += (conjugate ? conj(val[k]) : val[k]) * x[col[k]];
+            y[i] = s;
+        }
+        return;
+    }
+    for (int i = 0; i < n; i++) y[i] = CMPLX(0.0, 0.0);
+    for (int i = 0; i < n; i++)
+        for (int k = rowptr[i]; k < rowptr[i + 1]; k++)
+            y[col[k]] += (conjugate ? conj(val[k]) : val[k]) * x[i];
+}
+
 /* Stable counting sort of COO entries by row (what cusparseXcoo2csr assumes is
  * already true, sample8.cu:169).  perm[k] = source index of CSR slot k. */
 int orc_coo_to_csr(const int *row, const int *col, int n, int nnz, int *rowptr, int *perm)
@@ -124,10 +141,10 @@ int orc_record_progress(void *instance, const double *m, double converge,
 
 void orc_csr_cax(void *instance, const zc *x, zc *Ax, int n, int layout, int conjugate)
 {
-    (void)layout; (void)conjugate;
     orc_csr *A = instance;
     A->n_ax++;
-    orc_csr_cmatvec(A->rowptr, A->col, (const zc *)A->val, x, Ax, n, A->threads);
+    if (layout || conjugate) orc_csr_cmatvec_op(A->rowptr, A->col, (const zc *)A->val, x, Ax, n, layout, conjugate);
+    else orc_csr_cmatvec(A->rowptr, A->col, (const zc *)A->val, x, Ax, n, A->threads);
 }
 
 int orc_record_cprogress(void *instance, const zc *m, double converge,
@@ -151,8 +168,8 @@ int orc_solve_csr(int solver_id, int jacobi, orc_csr *A, double *m, const double
     return orc_lcg_solver(orc_csr_ax, orc_record_progress, m, B, A->n, param, A, solver_id);
 }
 
-/* solver_id: clcg_solver_enum (util.h:187-221): 1 BICG_SYM, 2 CGS, 3 BICGSTAB,
- * 4 TFQMR; other ids run CGS as clcg.cpp:68-70 does (BICG needs A^H, out of scope). */
+/* solver_id: clcg_solver_enum (util.h:187-221): 0 BICG, 1 BICG_SYM, 2 CGS, 3 BICGSTAB,
+ * 4 TFQMR; other ids run CGS as clcg.cpp:68-70 does. */
 int orc_csolve_csr(int solver_id, orc_csr *A, double *m, const double *B,
                    const orc_cpara *param, const double *rbar0)
 {
@@ -160,6 +177,7 @@ int orc_csolve_csr(int solver_id, orc_csr *A, double *m, const double *B,
     zc *zm = (zc *)m;
     const zc *zB = (const zc *)B, *zr = (const zc *)rbar0;
     switch (solver_id) {
+    case 0: return orc_clbicg(orc_csr_cax, orc_record_cprogress, zm, zB, A->n, param, A);
     case 1: return orc_clbicg_symmetric(orc_csr_cax, orc_record_cprogress, zm, zB, A->n, param, A);
     case 3: return orc_clbicgstab(orc_csr_cax, orc_record_cprogress, zm, zB, A->n, param, A, zr);
     case 4: return orc_cltfqmr(orc_csr_cax, orc_record_cprogress, zm, zB, A->n, param, A, zr);

@@ -97,6 +97,8 @@ int orc_lcg_solver(orc_axfunc Afp, orc_progress Pfp, double *m, const double *B,
 /* ---- complex solvers: clcg.cpp.  rbar0 = the shadow residual the reference
  * draws from srand(time(0)) (clcg.cpp:399-403,556-560,721-725); here it is an
  * input so runs are reproducible.  orc_clcg_vecrnd restates the draw. ---- */
+int orc_clbicg(orc_caxfunc Afp, orc_cprogress Pfp, double _Complex *m, const double _Complex *B, int n,
+               const orc_cpara *param, void *instance);             /* clcg.cpp:77-226 */
 int orc_clbicg_symmetric(orc_caxfunc Afp, orc_cprogress Pfp, double _Complex *m,
                          const double _Complex *B, int n, const orc_cpara *param,
                          void *instance);                           /* clcg.cpp:228-364 */
@@ -124,6 +126,11 @@ void orc_csr_matvec(const int *rowptr, const int *col, const double *val, const 
                     double *y, int n, int threads);                 /* sample8.cu:96-103 semantics */
 void orc_csr_cmatvec(const int *rowptr, const int *col, const double _Complex *val,
                      const double _Complex *x, double _Complex *y, int n, int threads);
+/* y = op(A).x, op = transpose and/or conjugate (lcg_matrix_e / clcg_complex_e, algebra.h:31-50);
+ * the transposed product scatters in storage order, like clcg_matvec's MatTranspose branch
+ * (lcg_complex.cpp:169-234) does over its dense rows */
+void orc_csr_cmatvec_op(const int *rowptr, const int *col, const double _Complex *val,
+                        const double _Complex *x, double _Complex *y, int n, int transpose, int conjugate);
 int orc_coo_to_csr(const int *row, const int *col, int n, int nnz, int *rowptr, int *perm);
 void orc_csr_diag(const int *rowptr, const int *col, const double *val, int n, double *diag); /* algebra_cuda.cu:40-57 */
 void orc_csr_cdiag(const int *rowptr, const int *col, const double _Complex *val, int n,

@@ -137,7 +137,7 @@ class Oracle:
                                C.byref(s0), C.byref(s1))
             out.update(seed_before=s0.value, seed_after=s1.value)
         else:
-            if rbar0 is None and solver_id != CLCG_BICG_SYM:
+            if rbar0 is None and solver_id not in (CLCG_BICG, CLCG_BICG_SYM):
                 raise ValueError("port needs rbar0 (use vecrnd(seed))")
             rb = None if rbar0 is None else np.ascontiguousarray(rbar0, np.complex128)
             ret = self._csolve(C.c_int(solver_id), C.byref(inst), _ptr(m), _ptr(b), C.byref(para),

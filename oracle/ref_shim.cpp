@@ -48,8 +48,14 @@ int ref_progress(void *instance, const lcg_float *m, const lcg_float converge,
 void ref_cax(void *instance, const lcg_complex *x, lcg_complex *Ax, const int n,
              lcg_matrix_e layout, clcg_complex_e conjugate)
 {
-    (void)layout; (void)conjugate;
     orc_csr *A = static_cast<orc_csr *>(instance);
+    if (layout != MatNormal || conjugate != NonConjugate) {     // A^T / A^H / conj(A): the oracle's scatter product
+        A->n_ax++;
+        orc_csr_cmatvec_op(A->rowptr, A->col, reinterpret_cast<const double _Complex *>(A->val),
+                           reinterpret_cast<const double _Complex *>(x), reinterpret_cast<double _Complex *>(Ax), n,
+                           layout == MatTranspose, conjugate == Conjugate);
+        return;
+    }
     A->n_ax++;
     if (A->n_ax == 1) g_sec_first = (long long)time(0);
     if (A->n_ax == 2) g_sec_second = (long long)time(0);

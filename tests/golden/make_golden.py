@@ -38,6 +38,7 @@ REAL_CASES = [  # (tag, solver_id, jacobi, epsilon, abs_diff)
     ("cg_max25", po.LCG_CG, 0, 1e-12, 1),  # max_iterations = 25 -> LCG_REACHED_MAX_ITERATIONS
 ]
 CPLX_CASES = [  # (tag, fixture, solver_id, epsilon, abs_diff)
+    ("bicg_1K", "1K", po.CLCG_BICG, 1e-10, 1), ("bicg_10K", "10K", po.CLCG_BICG, 1e-10, 1),
     ("bicgsym_1K", "1K", po.CLCG_BICG_SYM, 1e-10, 1), ("cgs_1K", "1K", po.CLCG_CGS, 1e-10, 1),
     ("tfqmr_1K", "1K", po.CLCG_TFQMR, 1e-10, 1), ("bicgstab_1K", "1K", po.CLCG_BICGSTAB, 1e-10, 1),
     ("bicgsym_10K", "10K", po.CLCG_BICG_SYM, 1e-10, 1), ("cgs_10K", "10K", po.CLCG_CGS, 1e-10, 1),

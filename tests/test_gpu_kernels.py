@@ -45,6 +45,45 @@ def test_spmv_all_variants_ragged(api, port, cplx):
         assert np.abs(yd.cpu().numpy() - ref).max() <= 1e-12 * scale, var
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+def test_spmv_transpose_and_conjugate(api, port, cplx):
+    """op(A).x for the (layout, conjugate) pairs of clcg_axfunc_ptr (clcg.h:40-41): A^T, A^H, conj(A)."""
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(21)
+    n = 2500
+    rp, col = _ragged(rng, n, n, 30, long_rows=[(7, 2400)])
+    val = rng.standard_normal(rp[-1]) + (1j * rng.standard_normal(rp[-1]) if cplx else 0)
+    x = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)
+    A = api.CsrMatrix.from_csr(rp, col, val)
+    xd = torch.from_numpy(x).cuda(); yd = torch.empty_like(xd)
+    import scipy.sparse as sp
+    M = sp.csr_matrix((val, col, rp), shape=(n, n))
+    for layout in (0, 1):
+        for conj in (0, 1):
+            ref = (M.T if layout else M)
+            ref = (ref.conj() if conj else ref) @ x
+            if cplx:
+                o = port.lib  # oracle's scatter product agrees with scipy
+                yo = np.empty(n, np.complex128)
+                o.orc_csr_cmatvec_op(rp.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p),
+                                     np.ascontiguousarray(val).ctypes.data_as(C.c_void_p),
+                                     np.ascontiguousarray(x).ctypes.data_as(C.c_void_p), yo.ctypes.data_as(C.c_void_p),
+                                     C.c_int(n), C.c_int(layout), C.c_int(conj))
+                assert np.abs(yo - ref).max() <= 1e-11 * np.abs(ref).max()
+            for rep in range(2):        # second call reuses the cached op(A)
+                yd.zero_()
+                assert lib.lcg_hip_spmv_op(A.h, xd.data_ptr(), yd.data_ptr(), layout, conj) == 0
+                api.synchronize()
+                assert np.abs(yd.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max(), (layout, conj)
+    # the built transpose is deterministic: two independent builds give identical bits
+    B = api.CsrMatrix.from_csr(rp, col, val)
+    y2 = torch.empty_like(xd)
+    lib.lcg_hip_spmv_op(A.h, xd.data_ptr(), yd.data_ptr(), 1, 1); lib.lcg_hip_spmv_op(B.h, xd.data_ptr(), y2.data_ptr(), 1, 1)
+    api.synchronize()
+    assert torch.equal(yd, y2)
+
+
 def test_spmv_edge_shapes(api, port):
     rng = np.random.default_rng(3)
     for n in (1, 2, 63, 64, 65, 255, 256, 257):

@@ -215,6 +215,26 @@ def test_complex_bicg_symmetric(api, port, goldens, case1kc, case10kc, case):
     assert np.linalg.norm(x - gold) / np.linalg.norm(gold) <= 5e-5
 
 
+@pytest.mark.parametrize("case", ["1K", "10K"])
+def test_complex_bicg_with_adjoint_product(api, port, goldens, case1kc, case10kc, case):
+    """clbicg (clcg.cpp:77-226): the second product of every iteration is A^H.d2 (:187)."""
+    from oracle import pyoracle as po
+    n, rp, ci, v, b, xs = case1kc if case == "1K" else case10kc
+    A = api.CsrMatrix.from_csr(rp, ci, v)
+    info, x = _solve_cplx(api, A, api.CLCG_BICG, b, n, api.clcg_default_parameters(epsilon=1e-10, abs_diff=1))
+    ret, iters = goldens[f"cplx/bicg_{case}/meta"][:2]
+    gold = goldens[f"cplx/bicg_{case}/x"]
+    assert info.ret == ret == 0
+    assert abs(info.iterations - iters) <= 0.12 * iters
+    assert np.linalg.norm(x - gold) / np.linalg.norm(gold) <= 5e-5
+    assert np.linalg.norm(x - xs) <= 2e-3
+    # first iterates track the oracle tightly
+    i12, x12 = _solve_cplx(api, A, api.CLCG_BICG, b, n, api.clcg_default_parameters(epsilon=1e-10, abs_diff=1, max_iterations=12))
+    ref = port.csolve(po.CLCG_BICG, rp, ci, v, b, para=po.default_cpara(epsilon=1e-10, abs_diff=1, max_iterations=12))
+    assert i12.ret == ref["ret"] == -1019 and i12.iterations == 12
+    assert np.linalg.norm(x12 - ref["x"]) <= 1e-9 * np.linalg.norm(ref["x"])
+
+
 @pytest.mark.parametrize("sid,name", [(2, "cgs"), (4, "tfqmr")])
 @pytest.mark.parametrize("case", ["1K", "10K"])
 def test_complex_shadow_solvers(api, port, goldens, case1kc, case10kc, sid, name, case):

@@ -12,7 +12,7 @@ from oracle import pyoracle as po
 
 REAL_TAGS = ["cg_e6", "pcg_e6", "cgs_e6", "bicgstab_e6", "cg_e10", "pcg_e10", "cgs_e10",
              "bicgstab_e10", "cg_e20", "pcg_e12", "cgs_e12", "bicgstab_e12", "cg_e12", "cg_max25"]
-CPLX_TAGS = ["bicgsym_1K", "cgs_1K", "tfqmr_1K", "bicgstab_1K", "bicgsym_10K", "cgs_10K", "tfqmr_10K"]
+CPLX_TAGS = ["bicg_1K", "bicg_10K", "bicgsym_1K", "cgs_1K", "tfqmr_1K", "bicgstab_1K", "bicgsym_10K", "cgs_10K", "tfqmr_10K"]
 
 
 @pytest.mark.parametrize("tag", REAL_TAGS)
