@@ -88,6 +88,14 @@ inline int lcg_solver_preconditioned_device(lcg_axfunc_ptr Afp, lcg_axfunc_ptr M
                                          LCG_HIP_MEM_DEVICE);
 }
 
+// lcg.h:111-113
+inline int lcg_solver_constrained(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, lcg_float *m, const lcg_float *B,
+                                  const lcg_float *low, const lcg_float *hig, const int n_size,
+                                  const lcg_para *param, void *instance, lcg_solver_enum solver_id = LCG_PG)
+{
+    return lcg_hip_solver_constrained(Afp, Pfp, m, B, low, hig, n_size, param, instance, solver_id, LCG_HIP_MEM_HOST);
+}
+
 // The workspaces of lcg()/lcgs() exist to avoid per-call allocation (lcg.h:118-119): here they are
 // DEVICE vectors of n_size doubles (or nullptr).
 inline int lcg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, lcg_float *m, const lcg_float *B, const int n_size,

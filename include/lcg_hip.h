@@ -117,14 +117,19 @@ double lcg_hip_last_ax_mean_us(void);
 int    lcg_hip_last_ax_calls(void);
 
 /* ----------------------------------------------------------- solver entry */
-/* lcg.h:71-72 lcg_solver() -> lcg.cpp:59-82.  solver_id: LCG_CG, LCG_CGS, LCG_BICGSTAB;
- * anything else runs CGS exactly as the reference's default branch does. */
+/* lcg.h:71-72 lcg_solver() -> lcg.cpp:59-82.  solver_id: LCG_CG, LCG_CGS, LCG_BICGSTAB,
+ * LCG_BICGSTAB2; anything else runs CGS exactly as the reference's default branch does. */
 int lcg_hip_solver(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B,
                    int n_size, const lcg_para *param, void *instance, int solver_id, int mem);
 /* lcg.h:90-91 lcg_solver_preconditioned() -> lpcg, lcg.cpp:293-434 (solver_id ignored, :90). */
 int lcg_hip_solver_preconditioned(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pfp,
                                   double *m, const double *B, int n_size, const lcg_para *param,
                                   void *instance, int solver_id, int mem);
+/* lcg.h:111-113 lcg_solver_constrained() -> lcg.cpp:121-140: LCG_SPG runs lspg (lcg.cpp:1224-1446),
+ * every other id lpg (lcg.cpp:1054-1204).  low/hig live where m and B live (`mem`). */
+int lcg_hip_solver_constrained(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B,
+                               const double *low, const double *hig, int n_size, const lcg_para *param,
+                               void *instance, int solver_id, int mem);
 /* lcg.h:135-137 lcg() with caller workspaces (DEVICE pointers or NULL), lcg.cpp:143-274. */
 int lcg_hip_lcg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B, int n_size,
                 const lcg_para *param, void *instance, double *Gk, double *Dk, double *ADk, int mem);
@@ -189,6 +194,7 @@ int lcg_hip_dot(int n, const double *a, const double *b, double *result);      /
 int lcg_hip_nrm2(int n, const double *a, double *result);                      /* cublasDznrm2-style 2-norm */
 int lcg_hip_axpy(int n, double alpha, const double *x, double *y);             /* y += alpha*x, cublasDaxpy lcg_cuda.cu:190 */
 int lcg_hip_scal(int n, double alpha, double *x);                              /* cublasDscal lcg_cuda.cu:203 */
+int lcg_hip_set2box(int n, const double *low, const double *hig, double *a);    /* a = clamp(a): lcg_set2box_cuda, algebra_cuda.cu:26-38,79-85 */
 int lcg_hip_vecmul(int n, const double *a, const double *b, double *c);        /* lcg_vecMvecD_element_wise, algebra_cuda.cu:59-67 */
 int lcg_hip_vecdiv(int n, const double *a, const double *b, double *c);        /* lcg_vecDvecD_element_wise, algebra_cuda.cu:69-77 */
 int clcg_hip_dot(int n, const double *a, const double *b, double *result2);    /* clcg_dot (unconjugated), lcg_complex.cpp:143-154 */

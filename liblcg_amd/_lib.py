@@ -51,6 +51,8 @@ SIGNATURES = {
     "lcg_hip_last_ax_calls": (C.c_int, []),
     "lcg_hip_solver": (C.c_int, [vp, vp, vp, vp, C.c_int, C.POINTER(LcgPara), vp, C.c_int, C.c_int]),
     "lcg_hip_solver_preconditioned": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.POINTER(LcgPara), vp, C.c_int, C.c_int]),
+    "lcg_hip_solver_constrained": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(LcgPara), vp, C.c_int, C.c_int]),
+    "lcg_hip_set2box": (C.c_int, [C.c_int, vp, vp, vp]),
     "lcg_hip_lcg": (C.c_int, [vp, vp, vp, vp, C.c_int, C.POINTER(LcgPara), vp, vp, vp, vp, C.c_int]),
     "lcg_hip_lcgs": (C.c_int, [vp, vp, vp, vp, C.c_int, C.POINTER(LcgPara), vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]),
     "clcg_hip_solver": (C.c_int, [vp, vp, vp, vp, C.c_int, C.POINTER(ClcgPara), vp, C.c_int, C.c_int]),

@@ -206,6 +206,17 @@ def lcg_solver_preconditioned(Afp, Mfp, Pfp, m, B, n_size, param, instance, solv
     return SolveInfo(rc, lib.lcg_hip_last_iterations(), lib.lcg_hip_last_residual())
 
 
+def lcg_solver_constrained(Afp, Pfp, m, B, low, hig, n_size, param, instance, solver_id=LCG_PG) -> SolveInfo:
+    """lcg_solver_constrained(), lcg.h:111-113 (LCG_PG / LCG_SPG)."""
+    lib = L.load()
+    a, k1 = _cb(Afp, AXFUNC); p, k2 = _cb(Pfp, PROGRESS)
+    (pm, mem), (pb, _), (pl, _), (ph, _) = _ptr(m), _ptr(B), _ptr(low), _ptr(hig)
+    rc = lib.lcg_hip_solver_constrained(a, p, pm, pb, pl, ph, n_size, C.byref(param) if param is not None else None,
+                                        _instance(instance), solver_id, mem)
+    _chk(rc, "lcg_solver_constrained")
+    return SolveInfo(rc, lib.lcg_hip_last_iterations(), lib.lcg_hip_last_residual())
+
+
 def lcg(Afp, Pfp, m, B, n_size, param, instance, Gk=None, Dk=None, ADk=None) -> SolveInfo:
     """lcg() with optional caller workspaces (device tensors), lcg.h:135-137."""
     lib = L.load()

@@ -467,6 +467,168 @@ static int solve_bicgstab(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, c
     return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
 }
 
+// ---- BiCGStab with restart (lcg.cpp:812-1034) ---------------------------------------------------
+// Two things on top of lbicgstab.  (1) When abs_diff is set there is a second stop test in the
+// middle of the iteration, on |s|/N, and t advances a second time (:910-939): the iteration is
+// enqueued as two counted halves.  If that test fires, m takes the half step m += a p first.
+// (2) When |r.r0| < restart_epsilon the shadow residual and the direction restart from r (:982-997).
+enum { S_RESTART = 8, S_MID = 9 };
+
+struct OpBicgS2 {       // s = r - a Ap; s.s                                  lcg.cpp:904-912
+    static constexpr int NR = 1, SKIP = SKIP_DONE;
+    DevState *st; const double *r, *Ap; double *s; double ak;
+    __device__ void prep() { ak = st->s[S_AK]; }
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const T sv = vsub(ld<T>(r, i), ak * ld<T>(Ap, i));
+        st_(s, i, sv);
+        acc[0] += dotp(sv, sv);
+    }
+};
+struct FinMid {         // the mid-iteration stop test (abs_diff only)
+    static constexpr int NR = 1;
+    int abs_diff;
+    __device__ void operator()(DevState *st, const double *sum) const
+    {
+        if (!abs_diff) return;
+        if (!st->done) {
+            st->t++;                                        // the head's t++ of this half
+            const double res = sqrt(sum[0]) / st->n_global; // :912-913
+            st->residual = res;
+            if (res <= st->eps) { st->done = 1; st->status = ST_CONVERGED; st->s[S_MID] = 1.0; }
+        }
+        publish(st);
+    }
+};
+struct OpMidFinish {    // m += a p when the mid test fired; NaN                lcg.cpp:922-930
+    static constexpr int NR = 1, SKIP = SKIP_NEVER;
+    DevState *st; double *m; const double *p; double ak; bool active;
+    __device__ void prep() { active = st->s[S_MID] == 1.0; ak = st->s[S_AK]; }
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        if (!active) return;
+        const T mv = vadd(ld<T>(m, i), ak * ld<T>(p, i));
+        st_(m, i, mv);
+        acc[0] += nanflag(mv);
+    }
+};
+struct FinMidNan {
+    static constexpr int NR = 1;
+    __device__ void operator()(DevState *st, const double *sum) const
+    {
+        if (st->s[S_MID] != 1.0) return;
+        st->s[S_MID] = 2.0;                                 // applied
+        if (sum[0] > 0.0) st->status = ST_NAN;
+        publish(st);
+    }
+};
+struct FinOmega2 {      // omega; first scalar step of the second half when halves are counted
+    static constexpr int NR = 2;
+    int counts_body;
+    __device__ void operator()(DevState *st, const double *sum) const
+    {
+        if (counts_body) st->it++;
+        if (st->done) return;
+        st->s[S_WK] = sum[0] / sum[1];                      // :949
+    }
+};
+struct FinClose2 {      // sums: m.m, r.r, r.r0, NaN                            lcg.cpp:956-1003
+    static constexpr int NR = 4;
+    double restart_eps;
+    __device__ void operator()(DevState *st, const double *sum) const
+    {
+        if (!st->done) {
+            st->s[S_M2] = clamp1(sum[0]);
+            if (sum[3] > 0.0 || sum[0] != sum[0]) { st->t++; st->done = 1; st->status = ST_NAN; }
+            else {
+                const double rho_new = sum[2];
+                if (fabs(rho_new) < restart_eps) {          // restart: r0 = p = r, so r.r0 = r.r
+                    st->s[S_RESTART] = 1.0;
+                    st->s[S_RHO] = sum[1];
+                } else {
+                    st->s[S_RESTART] = 0.0;
+                    st->s[S_BK] = (st->s[S_AK] / st->s[S_WK]) * rho_new / st->s[S_RHO];
+                    st->s[S_RHO] = rho_new;
+                }
+                st->s[S_G2] = sum[1];
+                st->t++;
+                stop_rule(st, sum[1], st->s[S_M2]);
+            }
+        }
+        publish(st);
+    }
+};
+struct OpBicgDir2 {     // p = r + b (p - w Ap), or the restart r0 = p = r       lcg.cpp:984-1009
+    static constexpr int NR = 0, SKIP = SKIP_DIR;
+    DevState *st; double *p, *r0; const double *r, *Ap; double bk, wk; bool restart;
+    __device__ void prep() { bk = st->s[S_BK]; wk = st->s[S_WK]; restart = st->s[S_RESTART] != 0.0; }
+    template <class T> __device__ void apply(long i, double *)
+    {
+        const T rv = ld<T>(r, i);
+        if (restart) { st_(r0, i, rv); st_(p, i, rv); }
+        else st_(p, i, vadd(rv, bk * vsub(ld<T>(p, i), wk * ld<T>(Ap, i))));
+    }
+};
+
+static int solve_bicgstab2(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B, int n,
+                           const lcg_para *param, void *inst, int mem)
+{
+    const lcg_para p = param ? *param : lcg_hip_default_parameters();
+    if (n <= 0) return LCG_INVILAD_VARIABLE_SIZE;                               // lcg.cpp:818-823
+    if (p.max_iterations < 0) return LCG_INVILAD_MAX_ITERATIONS;
+    if (p.epsilon <= 0.0) return LCG_INVILAD_EPSILON;
+    if (p.restart_epsilon <= 0.0 || p.epsilon >= 1.0) return LCG_INVILAD_RESTART_EPSILON;
+    if (m == nullptr || B == nullptr) return LCG_INVALID_POINTER;
+    TRY(ensure_init());
+    Ctx &c = ctx();
+    HostBridge hb; TRY(hb.open(mem, m, B, sizeof(double) * n, c.stream));
+    Workspace ws; double *r, *r0, *pk, *Ax, *s, *Ap;
+    const size_t nb = sizeof(double) * n;
+    TRY(ws.get(r, nullptr, nb)); TRY(ws.get(r0, nullptr, nb)); TRY(ws.get(pk, nullptr, nb));
+    TRY(ws.get(Ax, nullptr, nb)); TRY(ws.get(s, nullptr, nb)); TRY(ws.get(Ap, nullptr, nb));
+    RealCommon k(c, n, p, inst, Afp, Pfp, m);
+    TRY(k.drv.init_state(global_rows(c, n)));
+    DevState *st = c.state;
+    const uintptr_t a_all = al(m) | al(B) | al(r) | al(r0) | al(pk) | al(Ax) | al(s) | al(Ap);
+    const int halves = p.abs_diff ? 1 : 0;
+
+    TRY(k.ax(m, Ax));                                                            // :832
+    TRY(k.drv.vec(OpShadowInit<false>{st, Ax, B, m, r, r0, pk, nullptr}, a_all));
+    TRY(k.drv.scal(FinInit{}));
+    auto first_half = [&]() -> int {
+        TRY(k.ax(pk, Ap));                                                       // :895
+        TRY(k.drv.vec(OpDot1{st, Ap, r0}, a_all));
+        TRY(k.drv.scal(FinAlpha{}));
+        TRY(k.drv.vec(OpBicgS2{st, r, Ap, s, 0.0}, a_all));                      // :904-912
+        TRY(k.drv.scal(FinMid{halves}));
+        if (halves) {
+            TRY(k.drv.vec(OpMidFinish{st, m, pk, 0.0, false}, a_all));           // :922-930
+            TRY(k.drv.scal(FinMidNan{}));
+        }
+        return 0;
+    };
+    auto second_half = [&]() -> int {
+        TRY(k.ax(s, Ax));                                                        // :941
+        TRY(k.drv.vec(OpDot2{st, Ax, s}, a_all));
+        TRY(k.drv.scal(FinOmega2{halves}));
+        TRY(k.drv.vec(OpBicgUpdate{st, m, r, pk, s, Ax, r0, 0.0, 0.0}, a_all));  // :951-980
+        TRY(k.drv.scal(FinClose2{p.restart_epsilon}));
+        TRY(k.drv.vec(OpBicgDir2{st, pk, r0, r, Ap, 0.0, 0.0, false}, a_all));   // :984-1009
+        return 0;
+    };
+    int step = 0;
+    int rc = k.run_loop([&]() -> int {
+        if (!halves) { TRY(first_half()); return second_half(); }
+        return (step++ & 1) ? second_half() : first_half();
+    });
+    if (rc == LCG_CONVERGENCE || rc == LCG_NAN_VALUE) {      // a NaN found by the mid-iteration half step
+        DevState h; TRY(k.drv.read_state(h));
+        if (h.status == ST_NAN) rc = LCG_NAN_VALUE;
+    }
+    int rc2 = hb.close(c.stream);
+    return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
+}
+
 } // namespace lcgh
 
 using namespace lcgh;
@@ -479,6 +641,7 @@ int lcg_hip_solver(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const do
     switch (solver_id) {                                                        // lcg.cpp:59-82
     case LCG_CG: return solve_cg(Afp, Pfp, m, B, n, param, instance, nullptr, nullptr, nullptr, mem);
     case LCG_BICGSTAB: return solve_bicgstab(Afp, Pfp, m, B, n, param, instance, mem);
+    case LCG_BICGSTAB2: return solve_bicgstab2(Afp, Pfp, m, B, n, param, instance, mem);
     case LCG_CGS:
     default: return solve_cgs(Afp, Pfp, m, B, n, param, instance, nullptr, nullptr, nullptr, nullptr,
                               nullptr, nullptr, nullptr, mem);

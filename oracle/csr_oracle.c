@@ -168,6 +168,14 @@ int orc_solve_csr(int solver_id, int jacobi, orc_csr *A, double *m, const double
     return orc_lcg_solver(orc_csr_ax, orc_record_progress, m, B, A->n, param, A, solver_id);
 }
 
+/* lcg_solver_constrained (lcg.h:111-113): LCG_PG = 5, LCG_SPG = 6 */
+int orc_solve_csr_box(int solver_id, orc_csr *A, double *m, const double *B, const double *low,
+                      const double *hig, const orc_para *param)
+{
+    A->iters = 0; A->last_residual = 0.0; A->n_ax = 0;
+    return orc_lcg_solver_constrained(orc_csr_ax, orc_record_progress, m, B, low, hig, A->n, param, A, solver_id);
+}
+
 /* solver_id: clcg_solver_enum (util.h:187-221): 0 BICG, 1 BICG_SYM, 2 CGS, 3 BICGSTAB,
  * 4 TFQMR; other ids run CGS as clcg.cpp:68-70 does. */
 int orc_csolve_csr(int solver_id, orc_csr *A, double *m, const double *B,

@@ -251,14 +251,205 @@ out:
     return ret;
 }
 
-/* lcg.cpp:59-82: LCG_CG=0, LCG_PCG=1, LCG_CGS=2, LCG_BICGSTAB=3; everything
- * else (PCG/PG/SPG and BICGSTAB2, which is out of scope here) runs CGS. */
+/* --------------------------------------------- BiCGStab with restart (lcg.cpp:812-1034)
+ * Differences from lbicgstab: its own argument checks (:818-821), a second stop test in the
+ * middle of the iteration when abs_diff is set -- which advances t a second time (:897-925,
+ * SURVEY quirk 8) -- and a restart r0 = p = r when |r.r0| < restart_epsilon (:975-990). */
+int orc_lbicgstab2(orc_axfunc Afp, orc_progress Pfp, double *m, const double *B, int n,
+                   const orc_para *param, void *inst)
+{
+    orc_para p = param ? *param : orc_defaults;
+    if (n <= 0) return ORC_INVILAD_VARIABLE_SIZE;                       /* :818 */
+    if (p.max_iterations < 0) return ORC_INVILAD_MAX_ITERATIONS;
+    if (p.epsilon <= 0.0) return ORC_INVILAD_EPSILON;                   /* :820 */
+    if (p.restart_epsilon <= 0.0 || p.epsilon >= 1.0) return ORC_INVILAD_RESTART_EPSILON;   /* :821 */
+    if (m == NULL || B == NULL) return ORC_INVALID_POINTER;
+    int ret = 0, t = 0;
+    double *r = malloc(sizeof(double) * n), *r0 = malloc(sizeof(double) * n),
+           *pk = malloc(sizeof(double) * n), *Ax = malloc(sizeof(double) * n),
+           *s = malloc(sizeof(double) * n), *Ap = malloc(sizeof(double) * n);
+
+    Afp(inst, m, Ax, n);                                                /* :832 */
+    for (int i = 0; i < n; i++) pk[i] = r0[i] = r[i] = B[i] - Ax[i];    /* :834-838 */
+    double rho = 0.0;
+    for (int i = 0; i < n; i++) rho += r[i] * r0[i];                    /* :840-844 */
+    double m2 = clamp1(orc_dot(m, m, n));
+    double r2 = orc_dot(r, r, n);
+    if (already_done(&p, Pfp, inst, m, r2, m2, n)) { ret = ORC_ALREADY_OPTIMIZIED; goto out; }
+
+    while (!loop_head(&p, Pfp, inst, m, r2, m2, n, &t, &ret)) {
+        Afp(inst, pk, Ap, n);                                           /* :895 */
+        double Apr = 0.0;
+        for (int i = 0; i < n; i++) Apr += Ap[i] * r0[i];
+        double ak = rho / Apr;
+        for (int i = 0; i < n; i++) s[i] = r[i] - ak * Ap[i];           /* :904-908 */
+        if (p.abs_diff) {                                               /* :910-939 */
+            double res = sqrt(orc_dot(s, s, n)) / n;
+            if (Pfp && Pfp(inst, m, res, &p, n, t)) { ret = ORC_STOP; goto out; }
+            if (res <= p.epsilon) {
+                for (int i = 0; i < n; i++) {
+                    m[i] += ak * pk[i];
+                    if (m[i] != m[i]) { ret = ORC_NAN_VALUE; goto out; }
+                }
+                ret = ORC_CONVERGENCE; goto out;
+            }
+            if (p.max_iterations > 0 && t + 1 > p.max_iterations) { ret = ORC_REACHED_MAX_ITERATIONS; break; }
+            t++;
+        }
+        Afp(inst, s, Ax, n);                                            /* :941 */
+        double Ass = 0.0, AsAs = 0.0;
+        for (int i = 0; i < n; i++) { Ass += Ax[i] * s[i]; AsAs += Ax[i] * Ax[i]; }
+        double wk = Ass / AsAs;
+        for (int i = 0; i < n; i++) m[i] += ak * pk[i] + wk * s[i];     /* :951-955 */
+        m2 = clamp1(orc_dot(m, m, n));
+        if (has_nan(m, n)) { ret = ORC_NAN_VALUE; goto out; }
+        for (int i = 0; i < n; i++) r[i] = s[i] - wk * Ax[i];           /* :968-972 */
+        r2 = orc_dot(r, r, n);
+        double rhon = 0.0;
+        for (int i = 0; i < n; i++) rhon += r[i] * r0[i];
+        if (fabs(rhon) < p.restart_epsilon) {                           /* :982-997 */
+            for (int i = 0; i < n; i++) { r0[i] = r[i]; pk[i] = r[i]; }
+            rhon = 0.0;
+            for (int i = 0; i < n; i++) rhon += r[i] * r0[i];
+            rho = rhon;
+        } else {
+            double bk = (ak / wk) * rhon / rho;                         /* :1001 */
+            rho = rhon;
+            for (int i = 0; i < n; i++) pk[i] = r[i] + bk * (pk[i] - wk * Ap[i]);
+        }
+    }
+out:
+    free(r); free(r0); free(pk); free(Ax); free(s); free(Ap);
+    return ret;
+}
+
+/* algebra.cpp:50-58 with both bounds inclusive (the defaults the solvers use) */
+static double set2box(double low, double hig, double a)
+{
+    if (a >= hig) return hig;
+    if (a <= low) return low;
+    return a;
+}
+
+/* --------------------------------- projected gradient, Barzilai-Borwein step (lcg.cpp:1054-1204) */
+int orc_lpg(orc_axfunc Afp, orc_progress Pfp, double *m, const double *B, const double *low,
+            const double *hig, int n, const orc_para *param, void *inst)
+{
+    orc_para p = param ? *param : orc_defaults;
+    if (n <= 0) return ORC_INVILAD_VARIABLE_SIZE;                       /* :1060-1067 */
+    if (p.max_iterations < 0) return ORC_INVILAD_MAX_ITERATIONS;
+    if (p.epsilon <= 0.0) return ORC_INVILAD_EPSILON;
+    if (p.step <= 0.0 || p.epsilon >= 1.0) return -1015;                /* LCG_INVALID_LAMBDA */
+    if (m == NULL || B == NULL || low == NULL || hig == NULL) return ORC_INVALID_POINTER;
+    int ret = 0, t = 0;
+    double *g = malloc(sizeof(double) * n), *Ad = malloc(sizeof(double) * n), *mn = malloc(sizeof(double) * n),
+           *gn = malloc(sizeof(double) * n), *s = malloc(sizeof(double) * n), *y = malloc(sizeof(double) * n);
+    double alpha = p.step;
+
+    for (int i = 0; i < n; i++) m[i] = set2box(low[i], hig[i], m[i]);   /* :1084-1088 */
+    Afp(inst, m, Ad, n);
+    for (int i = 0; i < n; i++) g[i] = Ad[i] - B[i];
+    double m2 = clamp1(orc_dot(m, m, n));
+    double g2 = orc_dot(g, g, n);
+    if (already_done(&p, Pfp, inst, m, g2, m2, n)) { ret = ORC_ALREADY_OPTIMIZIED; goto out; }
+
+    while (!loop_head(&p, Pfp, inst, m, g2, m2, n, &t, &ret)) {
+        for (int i = 0; i < n; i++) mn[i] = set2box(low[i], hig[i], m[i] - alpha * g[i]);   /* :1151-1155 */
+        Afp(inst, mn, Ad, n);
+        for (int i = 0; i < n; i++) { gn[i] = Ad[i] - B[i]; s[i] = mn[i] - m[i]; y[i] = gn[i] - g[i]; }
+        double ss = 0.0, sy = 0.0;
+        for (int i = 0; i < n; i++) { ss += s[i] * s[i]; sy += s[i] * y[i]; }                 /* :1168-1175 */
+        alpha = ss / sy;
+        for (int i = 0; i < n; i++) { m[i] = mn[i]; g[i] = gn[i]; }
+        m2 = clamp1(orc_dot(m, m, n));
+        g2 = orc_dot(g, g, n);
+    }
+out:
+    free(g); free(Ad); free(mn); free(gn); free(s); free(y);
+    return ret;
+}
+
+/* --------------------- spectral projected gradient, non-monotone line search (lcg.cpp:1224-1446) */
+int orc_lspg(orc_axfunc Afp, orc_progress Pfp, double *m, const double *B, const double *low,
+             const double *hig, int n, const orc_para *param, void *inst)
+{
+    orc_para p = param ? *param : orc_defaults;
+    if (n <= 0) return ORC_INVILAD_VARIABLE_SIZE;                       /* :1230-1241 */
+    if (p.max_iterations < 0) return ORC_INVILAD_MAX_ITERATIONS;
+    if (p.epsilon <= 0.0 || p.epsilon >= 1.0) return ORC_INVILAD_EPSILON;
+    if (p.step <= 0.0) return -1015;                                    /* LCG_INVALID_LAMBDA */
+    if (p.sigma <= 0.0 || p.sigma >= 1.0) return -1014;                 /* LCG_INVALID_SIGMA */
+    if (p.beta <= 0.0 || p.beta >= 1.0) return -1013;                   /* LCG_INVALID_BETA */
+    if (p.maxi_m <= 0) return -1012;                                    /* LCG_INVALID_MAXIM */
+    if (m == NULL || B == NULL || low == NULL || hig == NULL) return ORC_INVALID_POINTER;
+    int ret = 0, t = 0;
+    double *g = malloc(sizeof(double) * n), *Ad = malloc(sizeof(double) * n), *mn = malloc(sizeof(double) * n),
+           *gn = malloc(sizeof(double) * n), *s = malloc(sizeof(double) * n), *y = malloc(sizeof(double) * n),
+           *d = malloc(sizeof(double) * n), *qm = malloc(sizeof(double) * p.maxi_m);
+    double lambda = p.step, qk = 0.0;
+
+    for (int i = 0; i < n; i++) m[i] = set2box(low[i], hig[i], m[i]);
+    Afp(inst, m, Ad, n);
+    for (int i = 0; i < n; i++) g[i] = Ad[i] - B[i];
+    double m2 = clamp1(orc_dot(m, m, n));
+    double g2 = orc_dot(g, g, n);
+    if (already_done(&p, Pfp, inst, m, g2, m2, n)) { ret = ORC_ALREADY_OPTIMIZIED; goto out; }
+    for (int i = 0; i < n; i++) qk += (0.5 * m[i] * Ad[i] - B[i] * m[i]);   /* :1297-1300 */
+    qm[0] = qk;
+    for (int i = 1; i < p.maxi_m; i++) qm[i] = -1e+30;
+
+    while (!loop_head(&p, Pfp, inst, m, g2, m2, n, &t, &ret)) {
+        for (int i = 0; i < n; i++) d[i] = set2box(low[i], hig[i], m[i] - lambda * g[i]) - m[i];   /* :1339-1343 */
+        double ak = 1.0;
+        for (int i = 0; i < n; i++) mn[i] = m[i] + ak * d[i];
+        Afp(inst, mn, Ad, n);
+        qk = 0.0;
+        for (int i = 0; i < n; i++) qk += (0.5 * mn[i] * Ad[i] - B[i] * mn[i]);
+        double amod = 0.0;
+        for (int i = 0; i < n; i++) amod += p.sigma * ak * g[i] * d[i];
+        double qmax = qm[0];
+        for (int i = 1; i < p.maxi_m; i++) qmax = qmax > qm[i] ? qmax : qm[i];
+        while (qk > qmax + amod) {                                      /* :1372-1392 */
+            ak = ak * p.beta;
+            for (int i = 0; i < n; i++) mn[i] = m[i] + ak * d[i];
+            Afp(inst, mn, Ad, n);
+            qk = 0.0;
+            for (int i = 0; i < n; i++) qk += (0.5 * mn[i] * Ad[i] - B[i] * mn[i]);
+            amod = 0.0;
+            for (int i = 0; i < n; i++) amod += p.sigma * ak * g[i] * d[i];
+        }
+        qm[(t + 1) % p.maxi_m] = qk;                                    /* :1394 */
+        for (int i = 0; i < n; i++) { gn[i] = Ad[i] - B[i]; s[i] = mn[i] - m[i]; y[i] = gn[i] - g[i]; }
+        double ss = 0.0, sy = 0.0;
+        for (int i = 0; i < n; i++) { ss += s[i] * s[i]; sy += s[i] * y[i]; }
+        lambda = ss / sy;
+        for (int i = 0; i < n; i++) { m[i] = mn[i]; g[i] = gn[i]; }
+        m2 = clamp1(orc_dot(m, m, n));
+        g2 = orc_dot(g, g, n);
+    }
+out:
+    free(g); free(Ad); free(mn); free(gn); free(s); free(y); free(d); free(qm);
+    return ret;
+}
+
+/* lcg.cpp:59-82: LCG_CG=0, LCG_CGS=2, LCG_BICGSTAB=3, LCG_BICGSTAB2=4; everything else
+ * (PCG/PG/SPG handed to lcg_solver) runs CGS. */
 int orc_lcg_solver(orc_axfunc Afp, orc_progress Pfp, double *m, const double *B, int n,
                    const orc_para *param, void *inst, int solver_id)
 {
     switch (solver_id) {
     case 0: return orc_lcg(Afp, Pfp, m, B, n, param, inst);
     case 3: return orc_lbicgstab(Afp, Pfp, m, B, n, param, inst);
+    case 4: return orc_lbicgstab2(Afp, Pfp, m, B, n, param, inst);
     default: return orc_lcgs(Afp, Pfp, m, B, n, param, inst);
     }
+}
+
+/* lcg.cpp:121-140: LCG_SPG=6 -> lspg, everything else -> lpg */
+int orc_lcg_solver_constrained(orc_axfunc Afp, orc_progress Pfp, double *m, const double *B,
+                               const double *low, const double *hig, int n, const orc_para *param,
+                               void *inst, int solver_id)
+{
+    if (solver_id == 6) return orc_lspg(Afp, Pfp, m, B, low, hig, n, param, inst);
+    return orc_lpg(Afp, Pfp, m, B, low, hig, n, param, inst);
 }

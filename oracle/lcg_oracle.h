@@ -89,6 +89,15 @@ int orc_lcgs(orc_axfunc Afp, orc_progress Pfp, double *m, const double *B, int n
              const orc_para *param, void *instance);                /* lcg.cpp:437-612 */
 int orc_lbicgstab(orc_axfunc Afp, orc_progress Pfp, double *m, const double *B, int n,
                   const orc_para *param, void *instance);           /* lcg.cpp:629-794 */
+int orc_lbicgstab2(orc_axfunc Afp, orc_progress Pfp, double *m, const double *B, int n,
+                   const orc_para *param, void *instance);          /* lcg.cpp:812-1034 */
+int orc_lpg(orc_axfunc Afp, orc_progress Pfp, double *m, const double *B, const double *low,
+            const double *hig, int n, const orc_para *param, void *instance);    /* lcg.cpp:1054-1204 */
+int orc_lspg(orc_axfunc Afp, orc_progress Pfp, double *m, const double *B, const double *low,
+             const double *hig, int n, const orc_para *param, void *instance);   /* lcg.cpp:1224-1446 */
+int orc_lcg_solver_constrained(orc_axfunc Afp, orc_progress Pfp, double *m, const double *B,
+                               const double *low, const double *hig, int n, const orc_para *param,
+                               void *instance, int solver_id);      /* lcg.cpp:121-140 */
 /* lcg.cpp:59-91 dispatch: solver_id follows lcg_solver_enum (util.h:32-64);
  * ids other than CG/CGS/BICGSTAB fall through to CGS as the reference does. */
 int orc_lcg_solver(orc_axfunc Afp, orc_progress Pfp, double *m, const double *B, int n,
@@ -160,6 +169,8 @@ int  orc_record_cprogress(void *instance, const double _Complex *m, double conve
 /* one-call drivers used from Python (ctypes cannot conveniently pass C callbacks) */
 int orc_solve_csr(int solver_id, int jacobi, orc_csr *A, double *m, const double *B,
                   const orc_para *param);
+int orc_solve_csr_box(int solver_id, orc_csr *A, double *m, const double *B, const double *low,
+                      const double *hig, const orc_para *param);
 int orc_csolve_csr(int solver_id, orc_csr *A, double *m_interleaved, const double *B_interleaved,
                    const orc_cpara *param, const double *rbar0_interleaved);
 

@@ -122,6 +122,19 @@ class Oracle:
                           C.byref(para))
         return dict(x=m, ret=ret, iters=inst.iters, residual=inst.last_residual, n_ax=inst.n_ax)
 
+    def solve_box(self, solver_id, rowptr, col, val, b, low, hig, m0=None, para=None, threads=1):
+        """lcg_solver_constrained (LCG_PG = 5 / LCG_SPG = 6): box-constrained solve."""
+        n = len(rowptr) - 1
+        inst, keep = self._inst(rowptr, col, np.asarray(val, np.float64), None, threads)
+        m = np.zeros(n) if m0 is None else np.array(m0, np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        low = np.ascontiguousarray(low, np.float64); hig = np.ascontiguousarray(hig, np.float64)
+        para = para or default_para()
+        f = self.lib.ref_solve_csr_box if self.kind == "reference" else self.lib.orc_solve_csr_box
+        f.restype = C.c_int
+        ret = f(C.c_int(solver_id), C.byref(inst), _ptr(m), _ptr(b), _ptr(low), _ptr(hig), C.byref(para))
+        return dict(x=m, ret=ret, iters=inst.iters, residual=inst.last_residual, n_ax=inst.n_ax)
+
     def csolve(self, solver_id, rowptr, col, val, b, m0=None, para=None, rbar0=None, threads=1):
         """Complex solve.  `rbar0` is required by the port for CGS/BiCGStab/TFQMR; the
         reference draws its own from time(0) and reports the bracket as seed_before/after."""

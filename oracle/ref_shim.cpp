@@ -101,6 +101,14 @@ int ref_solve_csr(int solver_id, int jacobi, orc_csr *A, double *m, const double
     return lcg_solver(ref_ax, ref_progress, m, B, A->n, p, A, (lcg_solver_enum)solver_id);
 }
 
+int ref_solve_csr_box(int solver_id, orc_csr *A, double *m, const double *B, const double *low,
+                      const double *hig, const orc_para *param)
+{
+    A->iters = 0; A->last_residual = 0.0; A->n_ax = 0;
+    return lcg_solver_constrained(ref_ax, ref_progress, m, B, low, hig, A->n,
+                                  reinterpret_cast<const lcg_para *>(param), A, (lcg_solver_enum)solver_id);
+}
+
 /* The reference seeds rbar0 from time(0) inside the call.  seed_before/after
  * bracket the draw so the caller can replay the very same vector through
  * orc_clcg_vecrnd when both agree (i.e. the second did not tick in between). */

@@ -36,6 +36,10 @@ REAL_CASES = [  # (tag, solver_id, jacobi, epsilon, abs_diff)
     ("cgs_e12", po.LCG_CGS, 0, 1e-12, 1), ("bicgstab_e12", po.LCG_BICGSTAB, 0, 1e-12, 1),
     ("cg_e12", po.LCG_CG, 0, 1e-12, 1),
     ("cg_max25", po.LCG_CG, 0, 1e-12, 1),  # max_iterations = 25 -> LCG_REACHED_MAX_ITERATIONS
+    ("bicgstab2_e10", 4, 0, 1e-10, 1), ("bicgstab2_e6", 4, 0, 1e-6, 0), ("bicgstab2_max31", 4, 0, 1e-10, 1),
+]
+BOX_CASES = [  # (tag, solver_id, epsilon, abs_diff, max_iterations); box = [-5, 8] on case_10K_A
+    ("pg_40", 5, 1e-10, 1, 40), ("spg_40", 6, 1e-10, 1, 40), ("pg_150", 5, 1e-6, 0, 150), ("spg_60", 6, 1e-6, 0, 60),
 ]
 CPLX_CASES = [  # (tag, fixture, solver_id, epsilon, abs_diff)
     ("bicg_1K", "1K", po.CLCG_BICG, 1e-10, 1), ("bicg_10K", "10K", po.CLCG_BICG, 1e-10, 1),
@@ -55,11 +59,21 @@ def main():
         para = po.default_para(epsilon=eps, abs_diff=ad)
         if tag == "cg_max25":
             para.max_iterations = 25
+        if tag == "bicgstab2_max31":
+            para.max_iterations = 31
         r = ref.solve(sid, rp, ci, v, b, para=para, jacobi=bool(jac))
         out[f"real/{tag}/x"] = r["x"]
         out[f"real/{tag}/meta"] = np.array([r["ret"], r["iters"], sid, jac, ad, para.max_iterations], np.int64)
         out[f"real/{tag}/fl"] = np.array([eps, r["residual"]])
         print(tag, r["ret"], r["iters"], r["residual"])
+    low, hig = np.full(n, -5.0), np.full(n, 8.0)
+    for tag, sid, eps, ad, maxit in BOX_CASES:
+        para = po.default_para(epsilon=eps, abs_diff=ad, max_iterations=maxit)
+        r = ref.solve_box(sid, rp, ci, v, b, low, hig, para=para)
+        out[f"box/{tag}/x"] = r["x"]
+        out[f"box/{tag}/meta"] = np.array([r["ret"], r["iters"], sid, ad, maxit, r["n_ax"]], np.int64)
+        out[f"box/{tag}/fl"] = np.array([eps, r["residual"]])
+        print(tag, r["ret"], r["iters"], r["residual"], r["n_ax"])
     for tag, fx, sid, eps, ad in CPLX_CASES:
         n, row, col, val, b = read_coo_system(os.path.join(HERE, f"case_{fx}_cA"), True)
         rp, ci, v = coo_to_csr_host(n, row, col, val)

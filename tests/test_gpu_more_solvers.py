@@ -1,0 +1,131 @@
+"""-m gpu: the remaining real solvers of lcg.cpp through the C ABI:
+BiCGStab with restart (lcg.cpp:812-1034) and the box-constrained PG / SPG
+(lcg_solver_constrained, lcg.cpp:1054-1446), against the oracle and the real liblcg's goldens."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def api():
+    from liblcg_amd import api as a
+    assert torch.cuda.is_available()
+    return a
+
+
+@pytest.fixture(scope="module")
+def A10k(api, case10k):
+    n, rp, ci, v, b, xs = case10k
+    return api.CsrMatrix.from_csr(rp, ci, v)
+
+
+def _run(api, A, sid, b, n, para, pfp=None):
+    m = torch.zeros(n, dtype=torch.float64, device="cuda")
+    info = api.lcg_solver("lcg_hip_csr_ax", pfp, m, torch.from_numpy(b).cuda(), n, para, A, sid)
+    return info, m.cpu().numpy()
+
+
+def test_bicgstab2_counts_two_iterations_per_pass_with_abs_diff(api, port, goldens, case10k, A10k):
+    """abs_diff: the mid-iteration test advances t a second time (lcg.cpp:910-939)."""
+    from oracle import pyoracle as po
+    n, rp, ci, v, b, xs = case10k
+    # capped run: deterministic count, tight agreement with the real liblcg
+    info, x = _run(api, A10k, api.LCG_BICGSTAB2, b, n, api.lcg_default_parameters(epsilon=1e-10, abs_diff=1, max_iterations=31))
+    gold = goldens["real/bicgstab2_max31/x"]
+    assert info.ret == -1019 and info.iterations == 31
+    assert np.linalg.norm(x - gold) / np.linalg.norm(gold) <= 1e-7
+    # to convergence: BiCGStab-type sensitivity band (tests/test_oracle_sensitivity.py)
+    info, x = _run(api, A10k, api.LCG_BICGSTAB2, b, n, api.lcg_default_parameters(epsilon=1e-10, abs_diff=1))
+    ret, iters = goldens["real/bicgstab2_e10/meta"][:2]
+    assert info.ret == ret == 0 and info.residual <= 1e-10
+    # the restart test |r.r0| < 1e-6 makes the count chaotic: the oracle itself lands anywhere in
+    # 280..364 under 1-ulp changes of b (tests/test_oracle_sensitivity.py)
+    assert 0.5 * iters <= info.iterations <= 1.6 * iters
+    assert np.linalg.norm(x - xs) <= 1e-3
+    # without abs_diff one count per pass
+    info, x = _run(api, A10k, api.LCG_BICGSTAB2, b, n, api.lcg_default_parameters(epsilon=1e-6, abs_diff=0))
+    ret, iters = goldens["real/bicgstab2_e6/meta"][:2]
+    assert info.ret == ret == 0 and abs(info.iterations - iters) <= max(2, 0.15 * iters)
+    assert np.linalg.norm(x - goldens["real/bicgstab2_e6/x"]) / np.linalg.norm(x) <= 5e-3
+    # progress callback sees both halves (k = 0, 1, 2, ...) and the oracle's first residuals
+    seen = []
+    _run(api, A10k, api.LCG_BICGSTAB2, b, n, api.lcg_default_parameters(epsilon=1e-10, abs_diff=1, max_iterations=6),
+         pfp=lambda i, m, c, p, nn, k: seen.append((k, c)) or 0)
+    trace = []
+    import ctypes as C
+    PROG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int)
+    cb = PROG(lambda i, m, c, p, nn, k: trace.append((k, c)) or 0)
+    inst, keep = port._inst(rp, ci, v, None, 1)
+    mm = np.zeros(n); para = po.default_para(epsilon=1e-10, abs_diff=1, max_iterations=6)
+    port.lib.orc_lbicgstab2(port.lib.orc_csr_ax, cb, mm.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.c_int(n),
+                            C.byref(para), C.byref(inst))
+    assert [k for k, _ in seen] == [k for k, _ in trace] == list(range(7))
+    assert np.allclose([c for _, c in seen], [c for _, c in trace], rtol=1e-9)
+
+
+def test_bicgstab2_restart_and_argument_checks(api, port, case10k, A10k):
+    from oracle import pyoracle as po
+    n, rp, ci, v, b, xs = case10k
+    # a huge restart_epsilon restarts every pass (lcg.cpp:982-997)
+    info, x = _run(api, A10k, api.LCG_BICGSTAB2, b, n,
+                   api.lcg_default_parameters(epsilon=1e-10, abs_diff=1, restart_epsilon=1e3, max_iterations=40))
+    ref = port.solve(4, rp, ci, v, b, para=po.default_para(epsilon=1e-10, abs_diff=1, restart_epsilon=1e3, max_iterations=40))
+    assert info.ret == ref["ret"] == -1019 and info.iterations == ref["iters"] == 40
+    assert np.linalg.norm(x - ref["x"]) / np.linalg.norm(ref["x"]) <= 1e-9
+    # lcg.cpp:820-821: epsilon >= 1 is reported as a restart-epsilon error by this solver
+    assert _run(api, A10k, api.LCG_BICGSTAB2, b, n, api.lcg_default_parameters(epsilon=1.5))[0].ret == -1020
+    assert _run(api, A10k, api.LCG_BICGSTAB2, b, n, api.lcg_default_parameters(restart_epsilon=0.0))[0].ret == -1020
+    assert _run(api, A10k, api.LCG_BICGSTAB2, b, n, api.lcg_default_parameters(epsilon=0.0))[0].ret == -1021
+
+
+@pytest.mark.parametrize("tag", ["pg_40", "spg_40", "pg_150", "spg_60"])
+def test_box_constrained_vs_golden(api, goldens, case10k, A10k, tag):
+    n, rp, ci, v, b, xs = case10k
+    ret, iters, sid, ad, maxit, n_ax = goldens[f"box/{tag}/meta"]
+    eps, resid = goldens[f"box/{tag}/fl"]
+    gold = goldens[f"box/{tag}/x"]
+    low = torch.full((n,), -5.0, dtype=torch.float64, device="cuda"); hig = torch.full((n,), 8.0, dtype=torch.float64, device="cuda")
+    m = torch.zeros(n, dtype=torch.float64, device="cuda")
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    lib.lcg_hip_set_profiling(1)
+    info = api.lcg_solver_constrained("lcg_hip_csr_ax", None, m, torch.from_numpy(b).cuda(), low, hig, n,
+                                      api.lcg_default_parameters(epsilon=float(eps), abs_diff=int(ad), max_iterations=int(maxit)),
+                                      A10k, int(sid))
+    calls = lib.lcg_hip_last_ax_calls(); lib.lcg_hip_set_profiling(0)
+    x = m.cpu().numpy()
+    assert info.ret == ret and info.iterations == iters
+    assert calls == n_ax                                            # same number of A.x calls: same line-search path
+    assert x.min() >= -5.0 and x.max() <= 8.0
+    assert np.array_equal(x <= -5.0, gold <= -5.0) and np.array_equal(x >= 8.0, gold >= 8.0)    # same active set
+    assert np.linalg.norm(x - gold) / np.linalg.norm(gold) <= 1e-9
+    assert abs(info.residual - resid) <= 1e-8 * resid
+
+
+def test_box_host_memory_progress_and_errors(api, port, case10k, A10k):
+    from oracle import pyoracle as po
+    n, rp, ci, v, b, xs = case10k
+    low, hig = np.full(n, -5.0), np.full(n, 8.0)
+    for sid in (api.LCG_PG, api.LCG_SPG):
+        m = np.full(n, 20.0)                                        # start outside the box: projected first
+        seen = []
+        info = api.lcg_solver_constrained("lcg_hip_csr_ax", lambda i, mp, c, p, nn, k: seen.append(k) or 0, m, b, low, hig, n,
+                                          api.lcg_default_parameters(epsilon=1e-10, abs_diff=1, max_iterations=15), A10k, sid)
+        ref = port.solve_box(sid, rp, ci, v, b, low, hig, m0=np.full(n, 20.0),
+                             para=po.default_para(epsilon=1e-10, abs_diff=1, max_iterations=15))
+        assert info.ret == ref["ret"] == -1019 and seen == list(range(16))
+        assert np.linalg.norm(m - ref["x"]) / np.linalg.norm(ref["x"]) <= 1e-9
+    p = api.lcg_default_parameters
+    run = lambda sid, **kw: api.lcg_solver_constrained("lcg_hip_csr_ax", None, np.zeros(n), b, low, hig, n, p(**kw), A10k, sid).ret
+    assert run(api.LCG_PG, step=0.0) == -1015 and run(api.LCG_PG, epsilon=1.0) == -1015     # lcg.cpp:1063
+    assert run(api.LCG_SPG, epsilon=1.0) == -1021 and run(api.LCG_SPG, step=-1.0) == -1015
+    assert run(api.LCG_SPG, sigma=1.0) == -1014 and run(api.LCG_SPG, beta=0.0) == -1013 and run(api.LCG_SPG, maxi_m=0) == -1012
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    a = torch.linspace(-10, 10, 1001, dtype=torch.float64, device="cuda")
+    lo = torch.full_like(a, -2.0); hi = torch.full_like(a, 3.0)
+    assert lib.lcg_hip_set2box(1001, lo.data_ptr(), hi.data_ptr(), a.data_ptr()) == 0
+    api.synchronize()
+    assert torch.equal(a, torch.linspace(-10, 10, 1001, dtype=torch.float64, device="cuda").clamp(-2.0, 3.0))

@@ -11,7 +11,9 @@ import pytest
 from oracle import pyoracle as po
 
 REAL_TAGS = ["cg_e6", "pcg_e6", "cgs_e6", "bicgstab_e6", "cg_e10", "pcg_e10", "cgs_e10",
-             "bicgstab_e10", "cg_e20", "pcg_e12", "cgs_e12", "bicgstab_e12", "cg_e12", "cg_max25"]
+             "bicgstab_e10", "cg_e20", "pcg_e12", "cgs_e12", "bicgstab_e12", "cg_e12", "cg_max25",
+             "bicgstab2_e10", "bicgstab2_e6", "bicgstab2_max31"]
+BOX_TAGS = ["pg_40", "spg_40", "pg_150", "spg_60"]
 CPLX_TAGS = ["bicg_1K", "bicg_10K", "bicgsym_1K", "cgs_1K", "tfqmr_1K", "bicgstab_1K", "bicgsym_10K", "cgs_10K", "tfqmr_10K"]
 
 
@@ -26,6 +28,18 @@ def test_real_solver_bit_exact(tag, port, goldens, case10k):
     assert r["iters"] == iters
     assert r["residual"] == resid
     assert np.array_equal(r["x"], goldens[f"real/{tag}/x"])
+
+
+@pytest.mark.parametrize("tag", BOX_TAGS)
+def test_box_constrained_solver_bit_exact(tag, port, goldens, case10k):
+    """lpg / lspg (lcg.cpp:1054-1446) on case_10K_A with the box [-5, 8] (1200 active bounds)."""
+    n, rp, ci, v, b, _ = case10k
+    ret, iters, sid, ad, maxit, n_ax = goldens[f"box/{tag}/meta"]
+    eps, resid = goldens[f"box/{tag}/fl"]
+    para = po.default_para(epsilon=float(eps), abs_diff=int(ad), max_iterations=int(maxit))
+    r = port.solve_box(int(sid), rp, ci, v, b, np.full(n, -5.0), np.full(n, 8.0), para=para)
+    assert (r["ret"], r["iters"], r["n_ax"], r["residual"]) == (ret, iters, n_ax, resid)
+    assert np.array_equal(r["x"], goldens[f"box/{tag}/x"])
 
 
 @pytest.mark.parametrize("tag", CPLX_TAGS)

@@ -32,6 +32,18 @@ def test_real_solvers(port, case10k, sid, tight_band, loose_band):
         assert _rel(a["x"], c["x"]) >= 1e-6
 
 
+def test_bicgstab2_iteration_count_is_chaotic(port, case10k):
+    """lbicgstab2's restart test (|r.r0| < restart_epsilon, lcg.cpp:982) flips on rounding: the count to
+    convergence moves by tens of percent under 1-ulp changes of b, the answer does not."""
+    n, rp, ci, v, b, xs = case10k
+    para = po.default_para(epsilon=1e-10, abs_diff=1, max_iterations=2000)
+    runs = [port.solve(4, rp, ci, v, b if s == 0 else _perturbed(b, s), para=para) for s in range(5)]
+    its = [r["iters"] for r in runs]
+    assert all(r["ret"] == 0 for r in runs)
+    assert max(its) - min(its) >= 0.1 * min(its) and 0.5 * its[0] <= min(its) and max(its) <= 1.6 * its[0]
+    assert all(np.linalg.norm(r["x"] - xs) <= 1e-3 for r in runs)
+
+
 @pytest.mark.parametrize("sid", [po.CLCG_BICG_SYM, po.CLCG_CGS, po.CLCG_TFQMR])
 def test_complex_converged_runs(port, case1kc, sid):
     n, rp, ci, v, b, _ = case1kc
