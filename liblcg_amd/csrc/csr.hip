@@ -635,16 +635,19 @@ __global__ void k_tr_fill(int n, const int *rowptr, const int *col, const V *val
         valT[pos] = v;
     }
 }
+__device__ __forceinline__ bool val_after(double a, double b) { return a > b; }
+__device__ __forceinline__ bool val_after(double2 a, double2 b) { return a.x > b.x || (a.x == b.x && a.y > b.y); }
 template <class V>
 __global__ void k_row_sort(int n, const int *rowptr, int *col, V *val)
-{   // insertion sort by column inside each row (rows are short)
+{   // insertion sort by (column, value) inside each row (rows are short).  The value tie-break
+    // gives duplicate (row, col) entries a fixed order too, whatever order the scatter left.
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int s = rowptr[i], e = rowptr[i + 1];
     for (int a = s + 1; a < e; a++) {
         const int c = col[a]; const V v = val[a];
         int b = a - 1;
-        while (b >= s && col[b] > c) { col[b + 1] = col[b]; val[b + 1] = val[b]; b--; }
+        while (b >= s && (col[b] > c || (col[b] == c && val_after(val[b], v)))) { col[b + 1] = col[b]; val[b + 1] = val[b]; b--; }
         col[b + 1] = c; val[b + 1] = v;
     }
 }

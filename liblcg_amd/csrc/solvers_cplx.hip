@@ -147,7 +147,7 @@ struct OpZXpay {        // d = r + b d       (clcg.cpp:349-353)
 
 // ---- BiCG (clcg.cpp:77-226): needs A^H.x --------------------------------------------------------
 __device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
-struct OpBicgInit {     // d1 = r1 = B - Ax; d2 = r2 = conj(r1); |m|^2, |r1|^2, <r2,r1>   (clcg.cpp:101-120)
+struct OpZBicgInit {     // d1 = r1 = B - Ax; d2 = r2 = conj(r1); |m|^2, |r1|^2, <r2,r1>   (clcg.cpp:101-120)
     static constexpr int NR = 4, SKIP = SKIP_NEVER;
     DevState *st; const double *Ax, *B, *m; double *r1, *r2, *d1, *d2;
     __device__ void prep() {}
@@ -159,7 +159,7 @@ struct OpBicgInit {     // d1 = r1 = B - Ax; d2 = r2 = conj(r1); |m|^2, |r1|^2, 
         acc_inner(acc + 2, rc, rv);
     }
 };
-struct OpBicgUpd1 {     // m += a d1; r1 -= a Ax                               (clcg.cpp:173-178)
+struct OpZBicgUpd1 {     // m += a d1; r1 -= a Ax                               (clcg.cpp:173-178)
     static constexpr int NR = 0, SKIP = SKIP_DONE;
     DevState *st; double *m, *r1; const double *d1, *Ax; double2 ak;
     __device__ void prep() { ak = lds2(st, C_AK); }
@@ -169,7 +169,7 @@ struct OpBicgUpd1 {     // m += a d1; r1 -= a Ax                               (
         S(r1, i, cfma(cneg(ak), L(Ax, i), L(r1, i)));
     }
 };
-struct OpBicgUpd2 {     // r2 -= conj(a) A^H d2; |m|^2, |r1|^2, <r2,r1>, NaN  (clcg.cpp:180-203)
+struct OpZBicgUpd2 {     // r2 -= conj(a) A^H d2; |m|^2, |r1|^2, <r2,r1>, NaN  (clcg.cpp:180-203)
     static constexpr int NR = 5, SKIP = SKIP_DONE;
     DevState *st; double *r2; const double *AHd, *m, *r1; double2 akc;
     __device__ void prep() { akc = cconj(lds2(st, C_AK)); }
@@ -183,7 +183,7 @@ struct OpBicgUpd2 {     // r2 -= conj(a) A^H d2; |m|^2, |r1|^2, <r2,r1>, NaN  (c
         acc[4] += cnan(mv);
     }
 };
-struct OpBicgDir2 {     // d1 = r1 + b d1; d2 = r2 + conj(b) d2                (clcg.cpp:207-212)
+struct OpZBicgDirPair {     // d1 = r1 + b d1; d2 = r2 + conj(b) d2                (clcg.cpp:207-212)
     static constexpr int NR = 0, SKIP = SKIP_DIR;
     DevState *st; double *d1, *d2; const double *r1, *r2; double2 bk;
     __device__ void prep() { bk = lds2(st, C_BK); }
@@ -451,17 +451,17 @@ static int solve_cbicg(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, doubl
     DevState *st = c.state;
 
     TRY(k.ax(m, Ax));                                                   // clcg.cpp:99
-    TRY(k.drv.vec(OpBicgInit{st, Ax, B, m, r1, r2, d1, d2}));           // :101-120
+    TRY(k.drv.vec(OpZBicgInit{st, Ax, B, m, r1, r2, d1, d2}));           // :101-120
     TRY(k.drv.scal(FinZInit<false>{}));
     int rc = k.run_loop([&]() -> int {
         TRY(k.ax(d1, Ax));                                              // :169
         TRY(k.drv.vec(OpZDot<true>{st, d2, Ax}));                       // :170
         TRY(k.drv.scal(FinZAlpha{C_RHO}));                              // :171
-        TRY(k.drv.vec(OpBicgUpd1{st, m, r1, d1, Ax, {}}));              // :173-178
+        TRY(k.drv.vec(OpZBicgUpd1{st, m, r1, d1, Ax, {}}));              // :173-178
         TRY(k.axop(d2, Ax, 1, 1));                                      // :187  A^H.d2
-        TRY(k.drv.vec(OpBicgUpd2{st, r2, Ax, m, r1, {}}));              // :180-203
+        TRY(k.drv.vec(OpZBicgUpd2{st, r2, Ax, m, r1, {}}));              // :180-203
         TRY(k.drv.scal(FinZClose<0>{}));                                // :204-205
-        TRY(k.drv.vec(OpBicgDir2{st, d1, d2, r1, r2, {}}));             // :207-212
+        TRY(k.drv.vec(OpZBicgDirPair{st, d1, d2, r1, r2, {}}));             // :207-212
         return 0;
     });
     int rc2 = hb.close(c.stream);

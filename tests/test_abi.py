@@ -72,6 +72,21 @@ def test_loads_and_fails_loudly_without_gpu(so_path):
     assert lib.lcg_hip_solver(_lib.fnptr(lib, "lcg_hip_csr_ax"), None, buf, buf, 8, C.byref(pp), None, 0, 0) == -1021
 
 
+def test_no_kernel_functor_is_defined_in_two_translation_units(so_path):
+    """k_vec<Op>/k_scal<Fin> are templates instantiated per source file; two files defining
+    different structs of one name would silently share ONE kernel at link time (an ODR clash that
+    once made complex BiCG run the real BiCGStab2 direction update)."""
+    import glob
+    seen = {}
+    for obj in glob.glob(os.path.join(os.path.dirname(so_path), "*.o")):
+        out = subprocess.check_output(["nm", "-C", obj], text=True)
+        for name in set(re.findall(r" [WwVv] (.*__device_stub__k_(?:vec|scal)<.*)", out)):
+            seen.setdefault(name, []).append(os.path.basename(obj))
+    shared_ok = ("OpMul", "OpDiv")          # none expected; keep the list explicit
+    dup = {k: v for k, v in seen.items() if len(v) > 1 and not any(s in k for s in shared_ok)}
+    assert len(seen) > 50 and not dup, dup
+
+
 def test_product_never_touches_the_oracle():
     """Only tests/, smoke() and bench.py's cpu_baseline may reach into oracle/."""
     pkg = os.path.join(ROOT, "liblcg_amd")
