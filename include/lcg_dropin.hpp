@@ -132,6 +132,16 @@ inline int clcg_solver_device(clcg_axfunc_ptr Afp, clcg_progress_ptr Pfp, lcg_co
                            reinterpret_cast<double *>(d_m), reinterpret_cast<const double *>(d_B), n_size, param,
                            instance, solver_id, LCG_HIP_MEM_DEVICE);
 }
+// clcg_solver_preconditioned_cuda (clcg_cuda.h:105-108) without the vendor handles
+inline int clcg_solver_preconditioned(clcg_axfunc_ptr Afp, clcg_axfunc_ptr Mfp, clcg_progress_ptr Pfp, lcg_complex *m,
+                                      const lcg_complex *B, const int n_size, const clcg_para *param, void *instance,
+                                      clcg_solver_enum solver_id = CLCG_PCG)
+{
+    return clcg_hip_solver_preconditioned(reinterpret_cast<clcg_hip_axfunc_ptr>(Afp), reinterpret_cast<clcg_hip_axfunc_ptr>(Mfp),
+                                          reinterpret_cast<clcg_hip_progress_ptr>(Pfp), reinterpret_cast<double *>(m),
+                                          reinterpret_cast<const double *>(B), n_size, param, instance, solver_id,
+                                          LCG_HIP_MEM_HOST);
+}
 // the ready-made complex CSR callback with the reference's C++ signature
 inline void clcg_csr_ax(void *instance, const lcg_complex *x, lcg_complex *prod_Ax, const int n,
                         lcg_matrix_e layout, clcg_complex_e conjugate)

@@ -143,6 +143,12 @@ int lcg_hip_lcgs(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const doub
  * lcg_hip_set_shadow_seed() (default 1) instead of srand(time(0)) (lcg_complex.cpp:118-127). */
 int clcg_hip_solver(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, double *m, const double *B,
                     int n_size, const clcg_para *param, void *instance, int solver_id, int mem);
+/* clcg_solver_preconditioned_cuda() (clcg_cuda.h:105-108) -> clpcg (clcg_cuda.cu:403-558): PCG for
+ * complex-symmetric A with unconjugated products; monitors |r|^2/max(|m|^2,1) (or |r|/N), as that
+ * CUDA loop does.  Mfp has the complex callback type; clcg_hip_jacobi_mx is the ready-made one. */
+int clcg_hip_solver_preconditioned(clcg_hip_axfunc_ptr Afp, clcg_hip_axfunc_ptr Mfp, clcg_hip_progress_ptr Pfp,
+                                   double *m, const double *B, int n_size, const clcg_para *param,
+                                   void *instance, int solver_id, int mem);
 int lcg_hip_set_shadow_seed(unsigned seed);
 /* Replace the drawn shadow residual by an explicit vector (n complex, host memory) for the
  * next complex solve only; lets a test replay the reference's own rbar0. */
@@ -181,6 +187,8 @@ void lcg_hip_csr_ax(void *instance, const double *x, double *prod_Ax, const int 
 void lcg_hip_jacobi_mx(void *instance, const double *x, double *prod_Mx, const int n_size);   /* sample1.cpp:55-62 (z = x/diag, reciprocal form) */
 void clcg_hip_csr_ax(void *instance, const double *x, double *prod_Ax, const int n_size,
                      int layout, int conjugate);                                                /* sample10.cu:90-97 */
+void clcg_hip_jacobi_mx(void *instance, const double *x, double *prod_Mx, const int n_size,
+                        int layout, int conjugate);                                             /* sample10.cu:99-120 (Jacobi branch) */
 
 /* ---------------------------------------------------------------- kernels */
 /* Stand-alone launches of the hot-path kernels on the current stream (device pointers).

@@ -56,6 +56,8 @@ SIGNATURES = {
     "lcg_hip_lcg": (C.c_int, [vp, vp, vp, vp, C.c_int, C.POINTER(LcgPara), vp, vp, vp, vp, C.c_int]),
     "lcg_hip_lcgs": (C.c_int, [vp, vp, vp, vp, C.c_int, C.POINTER(LcgPara), vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]),
     "clcg_hip_solver": (C.c_int, [vp, vp, vp, vp, C.c_int, C.POINTER(ClcgPara), vp, C.c_int, C.c_int]),
+    "clcg_hip_solver_preconditioned": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.POINTER(ClcgPara), vp, C.c_int, C.c_int]),
+    "clcg_hip_jacobi_mx": (None, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "lcg_hip_set_shadow_seed": (C.c_int, [C.c_uint]),
     "lcg_hip_set_shadow_vector": (C.c_int, [vp, C.c_int]),
     "lcg_hip_csr_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int64, vp, vp, vp, C.c_int, C.c_int, C.c_int]),

@@ -258,6 +258,17 @@ def clcg_solver(Afp, Pfp, m, B, n_size, param, instance, solver_id=CLCG_BICG, sh
     return SolveInfo(rc, lib.lcg_hip_last_iterations(), lib.lcg_hip_last_residual())
 
 
+def clcg_solver_preconditioned(Afp, Mfp, Pfp, m, B, n_size, param, instance, solver_id=CLCG_PCG) -> SolveInfo:
+    """clcg_solver_preconditioned_cuda(), clcg_cuda.h:105-108 -> clpcg."""
+    lib = L.load()
+    a, k1 = _cb(Afp, CAXFUNC); mm, k3 = _cb(Mfp, CAXFUNC); p, k2 = _cb(Pfp, CPROGRESS)
+    (pm, mem), (pb, _) = _ptr(m), _ptr(B)
+    rc = lib.clcg_hip_solver_preconditioned(a, mm, p, pm, pb, n_size, C.byref(param) if param is not None else None,
+                                            _instance(instance), solver_id, mem)
+    _chk(rc, "clcg_solver_preconditioned")
+    return SolveInfo(rc, lib.lcg_hip_last_iterations(), lib.lcg_hip_last_residual())
+
+
 # ---- kernel-level helpers ------------------------------------------------------------------------
 def dot(a, b) -> float:
     out = C.c_double()

@@ -35,8 +35,12 @@ int ensure_init()
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     c.device = dev;
-    HIPCHK(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c.comm_stream, hipStreamNonBlocking));
+    // "Blocking" streams: they order themselves against the legacy default stream, which is where a
+    // host program that does not think about streams (a plain hipMemset, PyTorch's default stream)
+    // puts its work -- so `y.zero_(); lcg_hip_spmv(A, x, y)` cannot race.  The two streams still
+    // run concurrently with each other (gather/compute overlap).
+    HIPCHK(hipStreamCreateWithFlags(&c.own_stream, hipStreamDefault));
+    HIPCHK(hipStreamCreateWithFlags(&c.comm_stream, hipStreamDefault));
     if (!c.stream) c.stream = c.own_stream;
     HIPCHK(hipEventCreateWithFlags(&c.ev_a, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c.ev_b, hipEventDisableTiming));

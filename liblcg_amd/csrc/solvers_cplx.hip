@@ -194,6 +194,73 @@ struct OpZBicgDirPair {     // d1 = r1 + b d1; d2 = r2 + conj(b) d2             
     }
 };
 
+// ---- PCG for complex-symmetric A (reference: CUDA back-end only, clcg_cuda.cu:403-558) -------------
+// Unconjugated products (cublasZdotu) and the REAL solvers' stop rule |r|^2 / max(|m|^2,1)
+// (clcg_cuda.cu:459,472), not the 4th power of clcg.cpp.  No NaN scan in the reference loop.
+struct OpZResid {       // r = B - Ax                                          clcg_cuda.cu:442-443
+    static constexpr int NR = 0, SKIP = SKIP_NEVER;
+    DevState *st; const double *Ax, *B; double *r;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *) { S(r, i, csub(L(B, i), L(Ax, i))); }
+};
+struct OpZPcgDots {     // |m|^2, |r|^2, r.s                                   clcg_cuda.cu:448-457, 507-516
+    static constexpr int NR = 4, SKIP = SKIP_DONE;
+    DevState *st; const double *m, *r, *s;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const double2 rv = L(r, i);
+        acc[0] += cnorm(L(m, i)); acc[1] += cnorm(rv);
+        acc_dot(acc + 2, rv, L(s, i));
+    }
+};
+struct OpZPcgUpd {      // m += a d; r -= a Ax                                 clcg_cuda.cu:504-505
+    static constexpr int NR = 0, SKIP = SKIP_DONE;
+    DevState *st; double *m, *r; const double *d, *Ax; double2 ak;
+    __device__ void prep() { ak = lds2(st, C_AK); }
+    template <class T> __device__ void apply(long i, double *)
+    {
+        S(m, i, cfma(ak, L(d, i), L(m, i)));
+        S(r, i, cfma(cneg(ak), L(Ax, i), L(r, i)));
+    }
+};
+struct OpZPcgUpdJacobi {    // built-in Jacobi: update, s = r .* invdiag and the three sums in one pass
+    static constexpr int NR = 4, SKIP = SKIP_DONE;
+    DevState *st; double *m, *r, *s; const double *d, *Ax, *inv; double2 ak;
+    __device__ void prep() { ak = lds2(st, C_AK); }
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const double2 mv = cfma(ak, L(d, i), L(m, i));
+        const double2 rv = cfma(cneg(ak), L(Ax, i), L(r, i));
+        const double2 sv = cmul(L(inv, i), rv);
+        S(m, i, mv); S(r, i, rv); S(s, i, sv);
+        acc[0] += cnorm(mv); acc[1] += cnorm(rv);
+        acc_dot(acc + 2, rv, sv);
+    }
+};
+template <bool INIT>
+struct FinZPcg {        // sums: |m|^2, |r|^2, (r.s).re, (r.s).im
+    static constexpr int NR = 4;
+    __device__ void operator()(DevState *st, const double *sum) const
+    {
+        if (INIT || !st->done) {
+            const double m2 = clamp1c(sum[0]), r2 = sum[1];
+            const double2 nw = make_double2(sum[2], sum[3]);
+            if (INIT) {
+                const double r = st->abs_diff ? sqrt(r2) / st->n_global : r2 / m2;     // clcg_cuda.cu:456-466
+                st->residual = r;
+                if (r <= st->eps) { st->done = 1; st->status = ST_ALREADY; }
+            } else {
+                sts2(st, C_BK, cdiv(nw, lds2(st, C_RHO)));                               // :517
+                st->t++;
+                stop_rule(st, r2, m2);
+            }
+            sts2(st, C_RHO, nw);
+        }
+        publish(st);
+    }
+};
+
 // ---- CGS / BiCGStab / TFQMR shared ----------------------------------------------------------------
 template <int MODE>   // 0 CGS: p = u = r; 1 BiCGStab: p = r; 2 TFQMR: p = u = r, d = 0
 struct OpZShadowInit {  // r = B - Ax ...; |m|^2, |r|^2, <rbar0, r>
@@ -468,6 +535,51 @@ static int solve_cbicg(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, doubl
     return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
 }
 
+static int solve_cpcg(clcg_hip_axfunc_ptr Afp, clcg_hip_axfunc_ptr Mfp, clcg_hip_progress_ptr Pfp, double *m,
+                      const double *B, int n, const clcg_para *param, void *inst, int mem)
+{
+    const clcg_para p = param ? *param : clcg_hip_default_parameters();
+    TRY(ccheck_args(p, n, m, B));
+    if (Mfp == nullptr) return LCG_NULL_PRECONDITION_MATRIX;
+    TRY(ensure_init());
+    Ctx &c = ctx();
+    const size_t nb = sizeof(double) * 2 * (size_t)n;
+    HostBridge hb; TRY(hb.open(mem, m, B, nb, c.stream));
+    Workspace ws; double *r, *d, *s, *Ax;
+    TRY(ws.get(r, nullptr, nb)); TRY(ws.get(d, nullptr, nb)); TRY(ws.get(s, nullptr, nb)); TRY(ws.get(Ax, nullptr, nb));
+    CplxCommon k(c, n, p, inst, Afp, Pfp, m);
+    TRY(k.drv.init_state(global_rows(c, n)));
+    DevState *st = c.state;
+    const double *inv = nullptr;        // built-in Jacobi on a complex handle: fold M^-1 into the update
+    if (Mfp == clcg_hip_jacobi_mx && inst) {
+        const lcg_hip_csr *A = static_cast<const lcg_hip_csr *>(inst);
+        if (A->is_complex && A->n_rows == n) inv = A->invdiag;
+    }
+
+    TRY(k.ax(m, Ax));                                                   // clcg_cuda.cu:441
+    TRY(k.drv.vec(OpZResid{st, Ax, B, r}));                             // :442-443
+    Mfp(inst, r, d, n, 0, 0);                                           // :445
+    TRY(k.drv.vec(OpZPcgDots{st, m, r, d}));                            // :448-457
+    TRY(k.drv.scal(FinZPcg<true>{}));
+    int rc = k.run_loop([&]() -> int {
+        TRY(k.ax(d, Ax));                                               // :500
+        TRY(k.drv.vec(OpZDot<false>{st, d, Ax}));                       // :501
+        TRY(k.drv.scal(FinZAlpha{C_RHO}));                              // :502
+        if (inv) {
+            TRY(k.drv.vec(OpZPcgUpdJacobi{st, m, r, s, d, Ax, inv, {}}));   // :504-516
+        } else {
+            TRY(k.drv.vec(OpZPcgUpd{st, m, r, d, Ax, {}}));             // :504-505
+            Mfp(inst, r, s, n, 0, 0);                                   // :513
+            TRY(k.drv.vec(OpZPcgDots{st, m, r, s}));                    // :507-516
+        }
+        TRY(k.drv.scal(FinZPcg<false>{}));                              // :517
+        TRY(k.drv.vec(OpZXpay{st, d, s, {}}));                          // :519-520  d = s + b d
+        return 0;
+    });
+    int rc2 = hb.close(c.stream);
+    return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
+}
+
 static int solve_bicg_sym(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, double *m, const double *B, int n,
                           const clcg_para *param, void *inst, int mem)
 {
@@ -634,4 +746,22 @@ extern "C" int clcg_hip_solver(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pf
     case CLCG_CGS:
     default: return solve_ccgs(Afp, Pfp, m, B, n, param, instance, mem);
     }
+}
+
+// clcg_solver_preconditioned_cuda (clcg_cuda.h:105-108) -> clpcg (clcg_cuda.cu:403-558); solver_id is
+// accepted for signature parity (CLCG_PCG is the only preconditioned complex loop ported here).
+extern "C" int clcg_hip_solver_preconditioned(clcg_hip_axfunc_ptr Afp, clcg_hip_axfunc_ptr Mfp, clcg_hip_progress_ptr Pfp,
+                                              double *m, const double *B, int n, const clcg_para *param,
+                                              void *instance, int solver_id, int mem)
+{
+    (void)solver_id;
+    return solve_cpcg(Afp, Mfp, Pfp, m, B, n, param, instance, mem);
+}
+
+// complex Jacobi z = x ./ diag (reciprocal multiply) with the complex callback signature:
+// clcg_vecDvecZ_element_wise as used by sample10.cu:117
+extern "C" void clcg_hip_jacobi_mx(void *instance, const double *x, double *z, const int n, int layout, int conjugate)
+{
+    (void)layout; (void)conjugate;
+    jacobi_launch(static_cast<lcg_hip_csr *>(instance), x, z, n, ctx().stream);
 }

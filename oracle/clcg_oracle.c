@@ -158,6 +158,56 @@ out:
     return ret;
 }
 
+/* ------------------------------------------------- preconditioned CG, complex-symmetric A
+ * PARITY UNPINNED for this one function: clpcg exists only in the reference's CUDA back-end
+ * (clcg_cuda.cu:403-558) and its Eigen back-end (clcg_eigen.cpp:577); neither can be built here
+ * (no nvcc, no Eigen3), so there is no reference output to pin against.  Restated from the CUDA
+ * source with the cuBLAS calls spelled out: Zdotu = sum x_i y_i, Dznrm2 = sqrt(sum |x_i|^2).
+ * Its stop rule is the REAL solvers' |r|^2 / max(|m|^2, 1) (clcg_cuda.cu:459,472), not the 4th
+ * power of the CPU complex loops.  In abs_diff mode the CUDA code never computes m_mod yet reads it
+ * in the "already optimised" else-if (:456-466): here only the abs_diff test is
+ * made in that mode.  The CUDA loop has no NaN scan. */
+int orc_clpcg(orc_caxfunc Afp, orc_caxfunc Mfp, orc_cprogress Pfp, zc *m, const zc *B, int n,
+              const orc_cpara *param, void *inst)
+{
+    orc_cpara p = param ? *param : orc_cdefaults;
+    int ret = ccheck_args(&p, n, m, B);
+    if (ret) return ret;
+    zc *r = malloc(sizeof(zc) * n), *d = malloc(sizeof(zc) * n), *s = malloc(sizeof(zc) * n), *Ax = malloc(sizeof(zc) * n);
+    int t = 0;
+    Afp(inst, m, Ax, n, 0, 0);                                  /* clcg_cuda.cu:441 */
+    for (int i = 0; i < n; i++) r[i] = B[i] - Ax[i];            /* :442-443 */
+    Mfp(inst, r, d, n, 0, 0);                                   /* :445 */
+    zc dn = orc_cdot(r, d, n);                                  /* :448 Zdotu */
+    double m2 = 1.0, r2 = creal(orc_cinner(r, r, n));           /* :450-457 */
+    if (!p.abs_diff) { m2 = creal(orc_cinner(m, m, n)); if (m2 < 1.0) m2 = 1.0; }
+    if (p.abs_diff ? sqrt(r2) / n <= p.epsilon : r2 / m2 <= p.epsilon) {
+        if (Pfp) Pfp(inst, m, p.abs_diff ? sqrt(r2) / n : r2 / m2, &p, n, 0);
+        ret = ORC_ALREADY_OPTIMIZIED; goto out;
+    }
+    for (;;) {
+        const double res = p.abs_diff ? sqrt(r2) / n : r2 / m2;  /* :478-479 */
+        if (Pfp && Pfp(inst, m, res, &p, n, t)) { ret = ORC_STOP; goto out; }
+        if (res <= p.epsilon) { ret = ORC_CONVERGENCE; goto out; }
+        if (p.max_iterations > 0 && t + 1 > p.max_iterations) { ret = ORC_REACHED_MAX_ITERATIONS; break; }
+        t++;
+        Afp(inst, d, Ax, n, 0, 0);                              /* :500 */
+        zc dAx = orc_cdot(d, Ax, n);                            /* :501 */
+        zc ak = dn / dAx;                                       /* :502 */
+        for (int i = 0; i < n; i++) { m[i] = m[i] + ak * d[i]; r[i] = r[i] - ak * Ax[i]; }   /* :504-505 */
+        if (!p.abs_diff) { m2 = creal(orc_cinner(m, m, n)); if (m2 < 1.0) m2 = 1.0; }
+        r2 = creal(orc_cinner(r, r, n));                        /* :511 */
+        Mfp(inst, r, s, n, 0, 0);                               /* :513 */
+        zc dold = dn;
+        dn = orc_cdot(r, s, n);                                 /* :516 */
+        zc bk = dn / dold;
+        for (int i = 0; i < n; i++) d[i] = bk * d[i] + s[i];    /* :519-520 */
+    }
+out:
+    free(r); free(d); free(s); free(Ax);
+    return ret;
+}
+
 /* ------------------------------------------------- BiCG, complex-symmetric A */
 int orc_clbicg_symmetric(orc_caxfunc Afp, orc_cprogress Pfp, zc *m, const zc *B, int n,
                          const orc_cpara *param, void *inst)

@@ -168,6 +168,21 @@ int orc_solve_csr(int solver_id, int jacobi, orc_csr *A, double *m, const double
     return orc_lcg_solver(orc_csr_ax, orc_record_progress, m, B, A->n, param, A, solver_id);
 }
 
+/* complex Jacobi, z = x / diag as reciprocal multiply (sample10.cu:117 divides; DESIGN.md deviation 3) */
+static void orc_cjacobi_mx(void *instance, const zc *x, zc *Mx, int n, int layout, int conjugate)
+{
+    (void)layout; (void)conjugate;
+    const orc_csr *A = instance;
+    const zc *inv = (const zc *)A->invdiag;
+    for (int i = 0; i < n; i++) Mx[i] = inv[i] * x[i];
+}
+
+int orc_csolve_csr_pcg(orc_csr *A, double *m, const double *B, const orc_cpara *param)
+{
+    A->iters = 0; A->last_residual = 0.0; A->n_ax = 0;
+    return orc_clpcg(orc_csr_cax, orc_cjacobi_mx, orc_record_cprogress, (zc *)m, (const zc *)B, A->n, param, A);
+}
+
 /* lcg_solver_constrained (lcg.h:111-113): LCG_PG = 5, LCG_SPG = 6 */
 int orc_solve_csr_box(int solver_id, orc_csr *A, double *m, const double *B, const double *low,
                       const double *hig, const orc_para *param)

@@ -65,6 +65,40 @@ def test_bicgstab2_counts_two_iterations_per_pass_with_abs_diff(api, port, golde
     assert np.allclose([c for _, c in seen], [c for _, c in trace], rtol=1e-9)
 
 
+@pytest.mark.parametrize("case", ["1K", "10K"])
+def test_complex_pcg_jacobi_sample10_workload(api, port, case1kc, case10kc, case):
+    """clpcg (clcg_cuda.cu:403-558) with the complex Jacobi of sample10.cu:117,193 -- the reference's own
+    GPU workload for these fixtures.  Oracle = restatement of the CUDA source (parity unpinned: no CPU
+    implementation exists in the reference), plus the known answers case_*_cB."""
+    from oracle import pyoracle as po
+    n, rp, ci, v, b, xs = case1kc if case == "1K" else case10kc
+    A = api.CsrMatrix.from_csr(rp, ci, v)
+    A.build_jacobi()
+    bd = torch.from_numpy(b).cuda()
+    for eps, ad in ((1e-10, 1), (1e-6, 0)):
+        m = torch.zeros(n, dtype=torch.complex128, device="cuda")
+        info = api.clcg_solver_preconditioned("clcg_hip_csr_ax", "clcg_hip_jacobi_mx", None, m, bd, n,
+                                              api.clcg_default_parameters(epsilon=eps, abs_diff=ad), A)
+        ref = port.csolve_pcg(rp, ci, v, b, para=po.default_cpara(epsilon=eps, abs_diff=ad))
+        x = m.cpu().numpy()
+        assert info.ret == ref["ret"] == 0 and info.residual <= eps
+        assert abs(info.iterations - ref["iters"]) <= 0.12 * ref["iters"]
+        assert np.linalg.norm(x - ref["x"]) / np.linalg.norm(ref["x"]) <= (5e-5 if ad else 5e-3)
+        if ad:
+            assert np.linalg.norm(x - xs) <= 1e-5                   # far tighter than the shadow-residual solvers
+    # a user-written preconditioner (Python callable launching the library's kernel) takes the unfused path
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    m1 = torch.zeros(n, dtype=torch.complex128, device="cuda"); m2 = torch.zeros_like(m1)
+    p12 = api.clcg_default_parameters(epsilon=1e-10, abs_diff=1, max_iterations=12)
+    i1 = api.clcg_solver_preconditioned("clcg_hip_csr_ax", lambda inst, xp, zp, nn, lay, cj: lib.clcg_hip_jacobi_mx(A.h, xp, zp, nn, 0, 0),
+                                        None, m1, bd, n, p12, A)
+    i2 = api.clcg_solver_preconditioned("clcg_hip_csr_ax", "clcg_hip_jacobi_mx", None, m2, bd, n, p12, A)
+    assert i1.ret == i2.ret == -1019 and i1.iterations == i2.iterations == 12
+    assert (m1 - m2).abs().max().item() <= 1e-8 * m2.abs().max().item()      # fused vs separate passes: rounding only
+    assert api.clcg_solver_preconditioned("clcg_hip_csr_ax", None, None, m1, bd, n, p12, A).ret == -1018
+
+
 def test_bicgstab2_restart_and_argument_checks(api, port, case10k, A10k):
     from oracle import pyoracle as po
     n, rp, ci, v, b, xs = case10k

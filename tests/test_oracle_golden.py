@@ -56,6 +56,18 @@ def test_complex_solver_bit_exact(tag, port, goldens, case1kc, case10kc):
     assert np.array_equal(r["x"], goldens[f"cplx/{tag}/x"])
 
 
+def test_clpcg_restatement_against_known_answers(port, case1kc, case10kc):
+    """orc_clpcg is the one oracle function WITHOUT a reference pin (clpcg exists only in liblcg's CUDA and
+    Eigen back-ends, neither buildable here).  What can be checked: it solves the bundled complex systems
+    to their known answers, and its monitored value is |r|/N recomputed independently."""
+    for (n, rp, ci, v, b, xs), iters in ((case1kc, 377), (case10kc, 526)):
+        r = port.csolve_pcg(rp, ci, v, b, para=po.default_cpara(epsilon=1e-10, abs_diff=1))
+        assert r["ret"] == 0 and r["iters"] == iters
+        assert np.linalg.norm(r["x"] - xs) <= 2e-7
+        res = np.linalg.norm(port.csr_matvec(rp, ci, v, r["x"]) - b) / n
+        assert res <= 1.05e-10
+
+
 def test_known_answer_case_10K(port, case10k):
     """CG at eps=1e-20/abs_diff reaches the fp64 floor of case_10K_B."""
     n, rp, ci, v, b, xs = case10k
