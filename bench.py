@@ -194,6 +194,23 @@ def main():
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "bytes_per_launch": shard_bytes, "avg_launch_us": ax_us, "launches": ax_calls}
 
+    if rank == 0 and world == 1 and "roofline" in out:
+        # what THIS box's memory system sustains on a plain device copy (1 GiB read + 1 GiB written),
+        # next to the nominal 8 TB/s the fractions above are quoted against
+        src = torch.empty(1 << 27, dtype=torch.float64, device="cuda").normal_()
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * src.numel() * 8 / (time.perf_counter() - t0) / 1e9
+        out["roofline"]["device_copy_GBs_this_box"] = copy_gbs
+        out["roofline"]["frac_of_device_copy"] = out["roofline"]["achieved"] / copy_gbs
+        del src, dst
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(A, b, n, args, np)
 

@@ -119,8 +119,12 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(SO_PATH):
-        raise ImportError(f"{SO_PATH} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                          "(there is no CPU fallback)")
+        # not a fallback: the same HIP library, compiled now if the toolchain is at hand
+        try:
+            build()
+        except Exception as exc:
+            raise ImportError(f"{SO_PATH} is not built and could not be built here ({exc}): run "
+                              "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
     # torch ships its own libamdhip64/librccl; importing it first makes this library bind to
     # the SAME runtime objects instead of mapping a second HIP runtime into the process.
     import torch  # noqa: F401

@@ -593,6 +593,41 @@ __global__ void k_coo_rowptr(long nnz, int n, const int *row, int *rowptr)
     for (int r = prev + 1; r <= cur; r++) rowptr[r] = (int)k;
 }
 
+__global__ void k_coo_count(long nnz, int n, const int *row, int *cnt, int *bad)
+{
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long)gridDim.x * blockDim.x) {
+        const int r = row[k];
+        if (r < 0 || r >= n) *bad = 1; else atomicAdd(&cnt[r], 1);
+    }
+}
+__global__ void k_coo_place(long nnz, const int *row, const int *rowptr, int *next, int *perm)
+{
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long)gridDim.x * blockDim.x) {
+        const int r = row[k];
+        perm[rowptr[r] + atomicAdd(&next[r], 1)] = (int)k;
+    }
+}
+__global__ void k_perm_sort(int n, const int *rowptr, int *perm)
+{   // ascending input position inside each row = the order a stable sort by row would give
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = rowptr[i], e = rowptr[i + 1];
+    for (int a = s + 1; a < e; a++) {
+        const int v = perm[a];
+        int b = a - 1;
+        while (b >= s && perm[b] > v) { perm[b + 1] = perm[b]; b--; }
+        perm[b + 1] = v;
+    }
+}
+template <class V>
+__global__ void k_coo_gather(long nnz, const int *perm, const int *colin, const V *valin, int *col, V *val)
+{
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long)gridDim.x * blockDim.x) {
+        const int src = perm[k];
+        col[k] = colin[src]; val[k] = valin[src];
+    }
+}
+
 static int alloc_part(CsrPart &P, int n_rows, long nnz, bool cplx)
 {
     P.n_rows = n_rows; P.nnz = nnz; P.owned = true;
@@ -771,31 +806,54 @@ int lcg_hip_csr_from_coo(lcg_hip_csr_t *out, int n, int64_t nnz, const int *row,
         if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
         if (e != hipSuccess) return bail(fail(e, "coo copy", __FILE__, __LINE__));
     } else {
-        // unsorted input: stable counting sort by row on the host, then upload
-        std::vector<int> hrow((size_t)nnz), hcol((size_t)nnz);
-        std::vector<double> hval((size_t)nnz * vw);
-        const hipMemcpyKind back = mem == LCG_HIP_MEM_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyHostToHost;
-        e = hipMemcpy(hrow.data(), row, sizeof(int) * (size_t)nnz, back);
-        if (e == hipSuccess) e = hipMemcpy(hcol.data(), col, sizeof(int) * (size_t)nnz, back);
-        if (e == hipSuccess) e = hipMemcpy(hval.data(), val, sizeof(double) * vw * (size_t)nnz, back);
-        if (e != hipSuccess) return bail(fail(e, "coo fetch", __FILE__, __LINE__));
-        std::vector<int> rp((size_t)n + 1, 0), scol((size_t)nnz);
-        std::vector<double> sval((size_t)nnz * vw);
-        for (int64_t k = 0; k < nnz; k++) {
-            if (hrow[k] < 0 || hrow[k] >= n) return bail(LCG_HIP_E_ARG);
-            rp[hrow[k] + 1]++;
+        // unsorted input: stable counting sort by row on the device.  Entries are scattered into
+        // their rows with atomics (arbitrary order), then each row's slots are sorted by the
+        // entry's position in the input, which restores the input order inside every row --
+        // the same result as a stable host sort, whatever order the atomics landed in.
+        int *cnt = nullptr, *perm = nullptr, *d_colin = nullptr;
+        double *d_valin = nullptr;
+        auto bail2 = [&](int code) {
+            if (cnt) hipFree(cnt); if (perm) hipFree(perm);
+            if (mem != LCG_HIP_MEM_DEVICE) { if (d_colin) hipFree(d_colin); if (d_valin) hipFree(d_valin); }
+            return bail(code);
+        };
+        if (hipMalloc(&cnt, sizeof(int) * (size_t)n) != hipSuccess || hipMalloc(&perm, sizeof(int) * (size_t)nnz) != hipSuccess)
+            return bail2(fail(hipErrorOutOfMemory, "coo sort workspace", __FILE__, __LINE__));
+        if (mem == LCG_HIP_MEM_DEVICE) { d_colin = const_cast<int *>(col); d_valin = const_cast<double *>(val); }
+        else {
+            if (hipMalloc(&d_colin, sizeof(int) * (size_t)nnz) != hipSuccess || hipMalloc(&d_valin, sizeof(double) * vw * (size_t)nnz) != hipSuccess)
+                return bail2(fail(hipErrorOutOfMemory, "coo staging", __FILE__, __LINE__));
+            e = hipMemcpyAsync(d_colin, col, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c.stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_valin, val, sizeof(double) * vw * (size_t)nnz, hipMemcpyHostToDevice, c.stream);
+            if (e != hipSuccess) return bail2(fail(e, "coo upload", __FILE__, __LINE__));
         }
-        for (int i = 0; i < n; i++) rp[i + 1] += rp[i];
-        std::vector<int> next(rp.begin(), rp.end() - 1);
-        for (int64_t k = 0; k < nnz; k++) {
-            const int p = next[hrow[k]]++;
-            scol[p] = hcol[k];
-            for (size_t q = 0; q < vw; q++) sval[(size_t)p * vw + q] = hval[(size_t)k * vw + q];
-        }
-        e = hipMemcpy(A->main.rowptr, rp.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(A->main.col, scol.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(A->main.val, sval.data(), sizeof(double) * vw * (size_t)nnz, hipMemcpyHostToDevice);
-        if (e != hipSuccess) return bail(fail(e, "coo sorted upload", __FILE__, __LINE__));
+        e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)n, c.stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, sizeof(int), c.stream);
+        if (e != hipSuccess) return bail2(fail(e, "coo sort init", __FILE__, __LINE__));
+        hipLaunchKernelGGL(k_coo_count, dim3(1024), dim3(VB), 0, c.stream, (long)nnz, n, d_row, cnt, d_flag);
+        int bad = 0;
+        e = hipMemcpyAsync(&bad, d_flag, sizeof(int), hipMemcpyDeviceToHost, c.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+        if (e != hipSuccess) return bail2(fail(e, "coo count", __FILE__, __LINE__));
+        if (bad) return bail2(LCG_HIP_E_ARG);                          // a row index outside [0, n)
+        long total = 0;
+        int rc2 = device_exclusive_scan(n, cnt, A->main.rowptr, c.stream, &total);
+        if (rc2 || total != nnz) return bail2(rc2 ? rc2 : LCG_HIP_E_ARG);
+        e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)n, c.stream);
+        if (e != hipSuccess) return bail2(fail(e, "coo sort", __FILE__, __LINE__));
+        hipLaunchKernelGGL(k_coo_place, dim3(1024), dim3(VB), 0, c.stream, (long)nnz, d_row, A->main.rowptr, cnt, perm);
+        hipLaunchKernelGGL(k_perm_sort, dim3((unsigned)((n + VB - 1) / VB)), dim3(VB), 0, c.stream, n, A->main.rowptr, perm);
+        if (is_complex)
+            hipLaunchKernelGGL((k_coo_gather<double2>), dim3(1024), dim3(VB), 0, c.stream, (long)nnz, perm, d_colin,
+                               reinterpret_cast<const double2 *>(d_valin), A->main.col, reinterpret_cast<double2 *>(A->main.val));
+        else
+            hipLaunchKernelGGL((k_coo_gather<double>), dim3(1024), dim3(VB), 0, c.stream, (long)nnz, perm, d_colin, d_valin,
+                               A->main.col, A->main.val);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+        hipFree(cnt); hipFree(perm);
+        if (mem != LCG_HIP_MEM_DEVICE) { hipFree(d_colin); hipFree(d_valin); }
+        if (e != hipSuccess) return bail(fail(e, "coo device sort", __FILE__, __LINE__));
     }
     hipFree(d_row); hipFree(d_flag);
     *out = A;

@@ -180,6 +180,16 @@ def test_coo_ingest(api, port, case10k):
     xd = torch.from_numpy(x).cuda(); yd = torch.empty_like(xd)
     A.spmv(xd, yd); api.synchronize()
     assert np.allclose(yd.cpu().numpy(), port.coo_matvec(row, col, val, x), rtol=0, atol=1e-12)
+    # duplicates of one (row, col) keep their input order too (stable), complex values included
+    r2 = np.array([3, 0, 3, 3, 1, 0, 3], np.int32); c2 = np.array([1, 2, 1, 0, 1, 2, 1], np.int32)
+    v2 = (np.arange(7) + 1) * (1 + 0.5j)
+    A2 = api.CsrMatrix.from_coo(4, r2, c2, v2)
+    rp5, ci5, v5 = A2.arrays_to_host()
+    rp6, perm6 = port.coo_to_csr(r2, c2, 4)
+    assert np.array_equal(rp5, rp6) and np.array_equal(ci5, c2[perm6]) and np.array_equal(v5, v2[perm6])
+    bad = row.copy(); bad[17] = n
+    with pytest.raises(api.LcgHipError):
+        api.CsrMatrix.from_coo(n, bad[sh], col[sh], val[sh])
 
 
 @pytest.mark.parametrize("band,sym", [(64, True), (0, True), (1000, False), (0, False), (3, True)])
