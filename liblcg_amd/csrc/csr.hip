@@ -4,7 +4,7 @@
 // A.x is the kernel the whole path is judged on: >= 80 % of the bytes of a CG iteration.
 // It is HBM-bound (0.17 flop/byte): no MFMA.  Two kernels:
 //
-//  k_spmv_lds<R,T>  (default)  One 256-thread block owns R consecutive rows (R*T = 256).
+//  k_spmv_lds1<R>   (default)  One 256-thread block owns R consecutive rows (R*T = 256).
 //      Stage 1: the block's contiguous slice of val/col streams from HBM into LDS with
 //      16-byte-per-lane coalesced loads, ALL issued before the first LDS store (the CSR
 //      arrays are read exactly once, at full width, whatever the row lengths).  Stage 2: lane (row = tid % R, j = tid / R) walks

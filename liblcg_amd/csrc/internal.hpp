@@ -44,7 +44,7 @@ struct DevState {
     HostStatus *host;
 };
 
-struct Comm;            // comm.cpp
+struct Comm;            // comm.hip
 
 struct Ctx {
     bool inited = false;
@@ -106,7 +106,7 @@ struct lcg_hip_csr {
     double *invdiag = nullptr;  // reciprocal diagonal (1 or 2 doubles per row)
     int variant = 0;        // SpMV kernel choice (0 auto)
     double mean_row = 0.0;
-    // --- sharded operation (comm.cpp) ---
+    // --- sharded operation (comm.hip) ---
     bool distributed = false;
     int dist_mode = 0;
     int64_t n_global = 0;
@@ -115,18 +115,18 @@ struct lcg_hip_csr {
     lcgh::CsrPart loc;          // entries whose column is owned by this rank (LOCAL column index)
     lcgh::CsrPart rem;          // the others (column index into xfull / halo buffer)
     double *xfull = nullptr;    // gather buffer
-    void *halo = nullptr;       // neighbour-exchange plan (comm.cpp)
+    void *halo = nullptr;       // neighbour-exchange plan (comm.hip)
 };
 
 namespace lcgh {
 
-// kernels_real.hip / kernels_cplx.hip
+// csr.hip
 int spmv_launch(const CsrPart &P, bool is_complex, int variant, double mean_row, const double *x,
                 double *y, bool accumulate, hipStream_t s, const int *done_flag);
 int jacobi_launch(const lcg_hip_csr *A, const double *x, double *z, int n, hipStream_t s);
 int op_part(lcg_hip_csr *A, int layout, int conjugate, const CsrPart **out);
 
-// comm.cpp
+// comm.hip
 int comm_allreduce(double *dev, int count, hipStream_t s);
 bool comm_active();
 int dist_spmv(lcg_hip_csr *A, const double *x, double *y);

@@ -312,7 +312,7 @@ static int check_args(const lcg_para &p, int n, const double *m, const double *B
     return 0;
 }
 
-double global_rows(Ctx &c, int n);   // comm.cpp: n summed over ranks (n itself when single)
+double global_rows(Ctx &c, int n);   // comm.hip: n summed over ranks (n itself when single)
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
