@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--band", type=int, default=131072, help="0 = scrambled (random-column) variant")
     ap.add_argument("--npairs", type=int, default=16)
     ap.add_argument("--solver", default="cg", choices=["cg", "pcg", "cgs", "bicgstab"])
+    ap.add_argument("--cg-schedule", default="auto", choices=["auto", "classic", "one-reduction"],
+                    help="lcg_hip_set_cg_schedule: auto = classic on one GPU, one all-reduce per iteration when sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -114,6 +116,8 @@ def main():
 
     m = torch.zeros_like(xt)
     ws = [torch.empty_like(xt) for _ in range(7)]
+    api.set_cg_schedule({"auto": api.CG_AUTO, "classic": api.CG_CLASSIC, "one-reduction": api.CG_ONE_REDUCTION}[args.cg_schedule])
+    one_red = args.solver == "cg" and (args.cg_schedule == "one-reduction" or (args.cg_schedule == "auto" and sharded))
 
     def solve(iters):
         m.zero_()
@@ -172,6 +176,7 @@ def main():
         "config": {"workload": f"synthetic SPD CSR, {'banded-random W=%d' % args.band if args.band else 'scrambled affine maps'}, "
                                f"plain {args.solver.upper()} via lcg_hip_lcg (BASELINE configs[2]/[3])",
                    "rows": n, "nnz": nnz, "nnz_per_row": nnz / n, "solver": args.solver, "index": "int32",
+                   "cg_schedule": ("one reduction per iteration (Chronopoulos-Gear)" if one_red else "classic, two reductions per iteration"),
                    "partition": "single" if not sharded else f"row-block x{world}, RCCL x exchange = {exchange} "
                                 f"({lib.lcg_hip_csr_exchange_volume(A.h)} doubles received per rank per A.x) + all-reduce(dots)"},
         "whole_iteration_algorithmic_GBs": iter_bytes / (elapsed / args.steps) / 1e9,

@@ -115,6 +115,14 @@ double lcg_hip_last_residual(void);
 int    lcg_hip_set_profiling(int on);
 double lcg_hip_last_ax_mean_us(void);
 int    lcg_hip_last_ax_calls(void);
+/* How plain CG (LCG_CG, lcg.cpp:143-274) is scheduled.  LCG_HIP_CG_CLASSIC: the reference's own
+ * recurrence, two reductions per iteration (d.Ad, then m.m/g.g).  LCG_HIP_CG_ONE_REDUCTION: the
+ * Chronopoulos-Gear rearrangement of the same recurrence -- w = A.g is applied to the gradient,
+ * A.d follows from Ad = beta Ad - w, and g.g, g.w, m.m share ONE reduction (one RCCL all-reduce
+ * per iteration instead of two); same iterates in exact arithmetic, same stop rule and counts.
+ * LCG_HIP_CG_AUTO (default): classic on one GPU, one-reduction when the rows are sharded. */
+enum { LCG_HIP_CG_AUTO = 0, LCG_HIP_CG_CLASSIC = 1, LCG_HIP_CG_ONE_REDUCTION = 2 };
+int    lcg_hip_set_cg_schedule(int schedule);
 
 /* ----------------------------------------------------------- solver entry */
 /* lcg.h:71-72 lcg_solver() -> lcg.cpp:59-82.  solver_id: LCG_CG, LCG_CGS, LCG_BICGSTAB,

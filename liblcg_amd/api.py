@@ -295,3 +295,11 @@ def gen_xtrue(n, seed, r0, r1, out):
 
 def synchronize():
     _chk(L.load().lcg_hip_synchronize(), "synchronize")
+
+
+CG_AUTO, CG_CLASSIC, CG_ONE_REDUCTION = 0, 1, 2
+
+
+def set_cg_schedule(schedule: int):
+    """lcg_hip_set_cg_schedule: classic two-reduction CG or the one-reduction rearrangement."""
+    _chk(L.load().lcg_hip_set_cg_schedule(schedule), "set_cg_schedule")

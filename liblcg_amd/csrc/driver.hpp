@@ -138,6 +138,7 @@ struct Driver {
                 if (h.status == ST_NAN) { finish(h); return code_nan; }
             }
         }
+        if (comm_active()) return run_lockstep(body, code_max_it, code_nan);
         // asynchronous path
         const long work = cplx ? 2 * n : n;
         int inflight = work >= (1 << 20) ? 6 : 24;
@@ -163,6 +164,42 @@ struct Driver {
             if ((enq & 255) == 0) {     // authoritative check now and then
                 rc = read_state(h); if (rc) return rc;
                 if (h.done) break;
+            }
+        }
+        rc = read_state(h); if (rc) return rc;
+        finish(h);
+        if (h.status == ST_NAN) return code_nan;
+        if (h.done && h.status == ST_CONVERGED) return LCG_CONVERGENCE;
+        return code_max_it;
+    }
+
+    // Sharded rows: every body holds collectives, so every rank must enqueue the SAME number of
+    // bodies -- a rank that stopped on its own view of the mapped stop flag would leave its peers
+    // waiting in an all-reduce.  Bodies therefore go out in batches; behind each batch the stream
+    // copies DevState into a pinned slot, and the decision to go on after batch k+1 is taken from
+    // the slot of batch k.  That slot holds the state as of one fixed body, computed from
+    // all-reduced sums only, so it is bit-identical on all ranks and so is the decision; and the
+    // stream always holds one whole batch while the host waits (no drain).
+    template <class Body>
+    int run_lockstep(Body &&body, int code_max_it, int code_nan)
+    {
+        int batch = 8;
+        if (const char *e = std::getenv("LCG_HIP_BATCH")) batch = std::max(1, atoi(e));
+        int nb = 0, rc = 0;
+        DevState h;
+        for (;;) {
+            int todo = batch;
+            if (max_it > 0) todo = std::min(batch, max_it - enq);
+            if (todo <= 0) break;
+            for (int i = 0; i < todo; i++) { rc = body(); if (rc) return rc; enq++; }
+            const int slot = nb & 1;
+            HIPCHK(hipMemcpyAsync(c.snap[slot], c.state, sizeof(DevState), hipMemcpyDeviceToHost, c.stream));
+            HIPCHK(hipEventRecord(c.snap_ev[slot], c.stream));
+            nb++;
+            if (nb >= 2) {
+                const int prev = (nb - 2) & 1;
+                HIPCHK(hipEventSynchronize(c.snap_ev[prev]));
+                if (c.snap[prev]->done) break;
             }
         }
         rc = read_state(h); if (rc) return rc;

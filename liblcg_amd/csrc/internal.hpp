@@ -58,10 +58,13 @@ struct Ctx {
     HostStatus *hstat = nullptr;       // pinned, mapped
     HostStatus *hstat_dev = nullptr;   // device alias of hstat
     double *scratch_host = nullptr;    // pinned, 64 doubles
+    DevState *snap[2] = {nullptr, nullptr};     // pinned: per-batch copies of DevState (sharded loop, driver.hpp)
+    hipEvent_t snap_ev[2] = {nullptr, nullptr};
     Comm *comm = nullptr;
     int last_iters = 0;
     double last_residual = 0.0;
     bool in_solve = false;             // a Driver is alive: A.x may honour DevState::done
+    int cg_schedule = 0;               // LCG_HIP_CG_*
     bool profile = false;
     std::vector<hipEvent_t> prof_ev;   // pairs
     int prof_used = 0;

@@ -50,6 +50,10 @@ int ensure_init()
     HIPCHK(hipHostMalloc((void **)&c.hstat, sizeof(HostStatus), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void **)&c.hstat_dev, c.hstat, 0));
     HIPCHK(hipHostMalloc((void **)&c.scratch_host, sizeof(double) * 64, hipHostMallocDefault));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipHostMalloc((void **)&c.snap[i], sizeof(DevState), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&c.snap_ev[i], hipEventDisableTiming));
+    }
     c.inited = true;
     return 0;
 }
@@ -192,6 +196,13 @@ int lcg_hip_last_iterations(void) { return ctx().last_iters; }
 double lcg_hip_last_residual(void) { return ctx().last_residual; }
 double lcg_hip_last_ax_mean_us(void) { return ctx().last_ax_mean_us; }
 int lcg_hip_last_ax_calls(void) { return ctx().last_ax_calls; }
+
+int lcg_hip_set_cg_schedule(int schedule)
+{
+    if (schedule < LCG_HIP_CG_AUTO || schedule > LCG_HIP_CG_ONE_REDUCTION) return LCG_HIP_E_ARG;
+    ctx().cg_schedule = schedule;      // no device needed: a host-side choice
+    return 0;
+}
 
 int lcg_hip_set_profiling(int on)
 {

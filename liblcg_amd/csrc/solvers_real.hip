@@ -147,6 +147,73 @@ struct OpCgDir {    // d = b d - g                                         lcg.c
     }
 };
 
+// ---- CG, one reduction per iteration (Chronopoulos-Gear schedule of lcg.cpp:206-264) ----------
+// The classic body needs d.Ad before the update and g.g after it: two reductions, two RCCL
+// all-reduces per iteration once the rows are sharded.  Here A is applied to the GRADIENT,
+// w = A.g, and A.d is carried by the same recurrence as d (d = b d - g  =>  Ad = b Ad - w), so
+//     d.Ad = g.w - b g.g / a_prev        (g_new . A d_old = g.g / a_prev,  d_old.Ad_old = rho / a_prev)
+// and g.g, g.w, m.m, NaN ride in ONE reduction.  Per row: 9 words (update) + 2 (A.g) + 3 (dots).
+struct OpCg1Update {    // d = b d - g; Ad = b Ad - w; m += a d; g += a Ad      lcg.cpp:259-263, 237-243
+    static constexpr int NR = 0, SKIP = SKIP_DONE;
+    DevState *st; double *m, *g, *d, *Ad; const double *w; double ak, bk;
+    __device__ void prep() { ak = st->s[S_AK]; bk = st->s[S_BK]; }
+    template <class T> __device__ void apply(long i, double *)
+    {
+        const T gv = ld<T>(g, i);
+        const T dv = vsub(bk * ld<T>(d, i), gv);
+        const T sv = vsub(bk * ld<T>(Ad, i), ld<T>(w, i));
+        st_(d, i, dv); st_(Ad, i, sv);
+        st_(m, i, vadd(ld<T>(m, i), ak * dv));
+        st_(g, i, vadd(gv, ak * sv));
+    }
+};
+struct OpCg1Dots {      // m.m, g.g, g.w, NaN                                   lcg.cpp:244-255, 234
+    static constexpr int NR = 4, SKIP = SKIP_DONE;
+    DevState *st; const double *m, *g, *w;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const T mv = ld<T>(m, i), gv = ld<T>(g, i);
+        acc[0] += dotp(mv, mv);
+        acc[1] += dotp(gv, gv);
+        acc[2] += dotp(gv, ld<T>(w, i));
+        acc[3] += nanflag(mv);
+    }
+};
+struct FinCg1Start {    // a_0 = g.g / g.A.g, b_0 = 0 (d_0 = -g, lcg.cpp:171-176)
+    static constexpr int NR = 1;
+    __device__ void operator()(DevState *st, const double *sum) const
+    {
+        if (st->done) return;
+        st->s[S_AK] = st->s[S_RHO] / sum[0];
+        st->s[S_BK] = 0.0;
+    }
+};
+struct FinCg1Close {    // the only scalar step of a body: counts it, closes it, prepares the next
+    static constexpr int NR = 4;
+    __device__ void operator()(DevState *st, const double *sum) const
+    {
+        st->it++;
+        if (!st->done) {
+            st->s[S_M2] = clamp1(sum[0]);
+            if (sum[3] > 0.0 || sum[0] != sum[0]) {         // lcg.cpp:247-253
+                st->t++;
+                st->done = 1; st->status = ST_NAN;
+            } else {
+                const double rho_new = sum[1];
+                const double bk = rho_new / st->s[S_RHO];                       // lcg.cpp:256
+                st->s[S_AK] = rho_new / (sum[2] - bk * rho_new / st->s[S_AK]);  // lcg.cpp:235 with d.Ad as above
+                st->s[S_BK] = bk;
+                st->s[S_RHO] = rho_new;
+                st->s[S_G2] = rho_new;
+                st->t++;
+                stop_rule(st, rho_new, st->s[S_M2]);
+            }
+        }
+        publish(st);
+    }
+};
+
 // ---- PCG ------------------------------------------------------------------------------------
 struct OpResidual { // r = B - Ax   (also the start of CGS/BiCGStab with extra copies)
     static constexpr int NR = 0, SKIP = SKIP_NEVER;
@@ -334,6 +401,23 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
     TRY(k.drv.vec(OpCgInit{st, Ad, B, m, g, d}, al(Ad) | al(B) | al(m) | al(g) | al(d)));
     TRY(k.drv.scal(FinInit{}));
     const uintptr_t a_upd = al(m) | al(g) | al(d) | al(Ad);
+    const bool one_reduction = c.cg_schedule == LCG_HIP_CG_ONE_REDUCTION ||
+                               (c.cg_schedule == LCG_HIP_CG_AUTO && comm_active());
+    if (one_reduction) {
+        double *w; TRY(ws.get(w, nullptr, sizeof(double) * n));
+        TRY(k.ax(g, w));
+        TRY(k.drv.vec(OpDot1{st, g, w}, al(g) | al(w)));
+        TRY(k.drv.scal(FinCg1Start{}));
+        int rc = k.run_loop([&]() -> int {
+            TRY(k.drv.vec(OpCg1Update{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
+            TRY(k.ax(g, w));
+            TRY(k.drv.vec(OpCg1Dots{st, m, g, w}, al(m) | al(g) | al(w)));
+            TRY(k.drv.scal(FinCg1Close{}));
+            return 0;
+        });
+        int rc2 = hb.close(c.stream);
+        return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
+    }
     int rc = k.run_loop([&]() -> int {
         TRY(k.ax(d, Ad));                                                        // :232
         TRY(k.drv.vec(OpDot1{st, d, Ad}, al(d) | al(Ad)));                       // :234

@@ -70,3 +70,34 @@ def test_one_rank_communicator_reproduces_unsharded_run(mode):
     assert forced["steps"] == plain["steps"] == 30
     # same matrix, same arithmetic: the error after 30 iterations agrees to rounding
     assert abs(forced["rel_err_vs_x_true"] - plain["rel_err_vs_x_true"]) <= 1e-6 * plain["rel_err_vs_x_true"] + 1e-15
+
+
+def _solve_cases(tmp_path, tag, extra_env):
+    out = str(tmp_path / f"{tag}.npz")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_sharded_case.py"), out],
+                       capture_output=True, text=True, env=dict(os.environ, **extra_env), timeout=280)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_sharded_loops_converge_like_the_unsharded_ones(tmp_path, mode):
+    """Every solver family to CONVERGENCE over a one-rank communicator (reduce -> all-reduce -> finish
+    scalar steps, split A.x, lock-step batched enqueue) against the plain single-GPU run of the same
+    process image.  Bands = those of tests/test_gpu_solvers.py: CG / PCG / CGS insensitive (1e-9, +-3
+    iterations; sharded CG runs the one-reduction schedule), BiCGStab(2) 1e-7 and +-15 %, complex
+    solvers 5e-5 and +-12 %.  Capped and progress-callback runs must count exactly."""
+    plain = _solve_cases(tmp_path, "plain", {})
+    forced = _solve_cases(tmp_path, "forced", {"LCG_HIP_FORCE_COMM": "1", "LCG_HIP_DIST_MODE": mode, "MASTER_PORT": "29548"})
+    bands = {"cg": (1e-9, 3, 0.0), "pcg": (1e-9, 3, 0.0), "cgs": (1e-9, 3, 0.0), "bicgstab": (1e-7, 3, 0.15),
+             "bicgstab2": (1e-7, 3, 0.15), "c_bicg_sym": (5e-5, 3, 0.12), "c_cgs": (5e-5, 3, 0.12), "c_tfqmr": (5e-5, 3, 0.12)}
+    for name, (xtol, it_abs, it_rel) in bands.items():
+        rp, ip, _ = plain[f"{name}/meta"]; rf, itf, resf = forced[f"{name}/meta"]
+        assert rp == rf == 0, name
+        assert abs(itf - ip) <= max(it_abs, it_rel * ip), (name, ip, itf)
+        xp, xf = plain[f"{name}/x"], forced[f"{name}/x"]
+        assert np.linalg.norm(xf - xp) / np.linalg.norm(xp) <= xtol, name
+    assert tuple(forced["cg13/meta"][:2]) == tuple(plain["cg13/meta"][:2]) == (-1019, 13)
+    assert np.linalg.norm(forced["cg13/x"] - plain["cg13/x"]) / np.linalg.norm(plain["cg13/x"]) <= 1e-10
+    assert forced["cgpfp/meta"][0] == 0 and abs(forced["cgpfp/meta"][1] - plain["cgpfp/meta"][1]) <= 2
+    assert forced["cgpfp/meta"][3] == forced["cgpfp/meta"][1] + 1          # Pfp called for k = 0..t

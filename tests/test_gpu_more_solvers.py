@@ -163,3 +163,40 @@ def test_box_host_memory_progress_and_errors(api, port, case10k, A10k):
     assert lib.lcg_hip_set2box(1001, lo.data_ptr(), hi.data_ptr(), a.data_ptr()) == 0
     api.synchronize()
     assert torch.equal(a, torch.linspace(-10, 10, 1001, dtype=torch.float64, device="cuda").clamp(-2.0, 3.0))
+
+
+def test_cg_one_reduction_schedule_matches_reference_cg(api, goldens, case10k, A10k):
+    """lcg_hip_set_cg_schedule(ONE_REDUCTION): the Chronopoulos-Gear arrangement of lcg.cpp:206-264 that
+    the sharded path uses (one all-reduce per iteration).  Same iterates in exact arithmetic, so on the
+    bundled system it must meet the bands of the classic schedule: the real liblcg's x to 1e-9 (tight) /
+    1e-6 (loose), its iteration counts to +-3 / +-2, the 25-iteration iterate to 1e-9, and the progress
+    callback contract (k = 0..t, residual of the classic recurrence)."""
+    n, rp, ci, v, b, xs = case10k
+    api.set_cg_schedule(api.CG_ONE_REDUCTION)
+    try:
+        for tag, kw, xtol, itol in (("e12", dict(epsilon=1e-12, abs_diff=1), 1e-9, 3), ("e6", dict(epsilon=1e-6), 1e-6, 2)):
+            info, x = _run(api, A10k, api.LCG_CG, b, n, api.lcg_default_parameters(**kw))
+            ret, iters = goldens[f"real/cg_{tag}/meta"][:2]
+            gold = goldens[f"real/cg_{tag}/x"]
+            assert info.ret == ret == 0 and abs(info.iterations - iters) <= itol
+            assert np.linalg.norm(x - gold) / np.linalg.norm(gold) <= xtol
+            assert np.linalg.norm(x - xs) <= 1.1 * np.linalg.norm(gold - xs) + 1e-9
+        seen = []
+        pfp = lambda i, mp, c, p, nn, k: seen.append((k, c)) or 0
+        info, x = _run(api, A10k, api.LCG_CG, b, n, api.lcg_default_parameters(epsilon=1e-12, abs_diff=1, max_iterations=25), pfp)
+        gold = goldens["real/cg_max25/x"]
+        assert info.ret == -1019 and info.iterations == 25 and [k for k, _ in seen] == list(range(26))
+        assert np.linalg.norm(x - gold) / np.linalg.norm(gold) <= 1e-9
+        assert abs(seen[-1][1] - goldens["real/cg_max25/fl"][1]) <= 1e-8 * seen[-1][1]
+        # x0 already solves the system: same early exit as the classic schedule (lcg.cpp:186-203)
+        m = torch.from_numpy(xs.copy()).cuda()
+        bd = torch.from_numpy(np.asarray(A10k_matvec(rp, ci, v, xs))).cuda()
+        info = api.lcg_solver("lcg_hip_csr_ax", None, m, bd, n, api.lcg_default_parameters(epsilon=1e-10), A10k, api.LCG_CG)
+        assert info.ret == 2 and info.iterations == 0                 # LCG_ALREADY_OPTIMIZIED
+    finally:
+        api.set_cg_schedule(api.CG_AUTO)
+
+
+def A10k_matvec(rp, ci, v, x):
+    import scipy.sparse as sp
+    return sp.csr_matrix((v, ci, rp), shape=(len(rp) - 1, len(rp) - 1)) @ x
