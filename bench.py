@@ -139,7 +139,9 @@ def main():
 
     if args.warmup > 0:
         solve(args.warmup)
-    lib.lcg_hip_set_profiling(1)
+    # HIP events around A.x: every call on one GPU (0.3 % of a 10M-row iteration); every 8th call when
+    # sharded, where the two stream markers of a timed call are ~3 % of a 150 us iteration
+    lib.lcg_hip_set_profiling(0 if os.environ.get("LCG_BENCH_NO_EVENTS") else (8 if sharded else 1))
     barrier()
     t0 = time.perf_counter()
     info = solve(args.steps)

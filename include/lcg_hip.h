@@ -111,7 +111,8 @@ clcg_para clcg_hip_default_parameters(void);   /* util.h:278,287 */
 int    lcg_hip_last_iterations(void);
 double lcg_hip_last_residual(void);
 /* Mean device time of the A.x callback over the last solve, in microseconds, from HIP
- * events recorded on the solver stream around each call; 0 unless profiling was enabled. */
+ * events recorded on the solver stream around each call; 0 unless profiling was enabled.
+ * on = 1 times every call, on = k > 1 every k-th call (two stream markers per timed call). */
 int    lcg_hip_set_profiling(int on);
 double lcg_hip_last_ax_mean_us(void);
 int    lcg_hip_last_ax_calls(void);

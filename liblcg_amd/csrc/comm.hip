@@ -5,8 +5,9 @@
 //   A.x   : the local x slices are all-gathered into xfull (P*rpr doubles; only the tail of
 //           the last slice is padding, so GLOBAL column indices address xfull directly).
 //           The shard is split once into entries with locally-owned columns and the rest:
-//           y = A_loc.x_loc runs on the compute stream WHILE the gather runs on a second
-//           stream; y += A_rem.xfull follows when the gather's event fires.
+//           y = A_loc.x_loc runs on the compute stream WHILE the second stream gathers and then
+//           multiplies the (few) rows that hold remote columns; their sums are added to y when
+//           that stream's event fires.
 //   dots  : k_scal reduces the local partials into DevState::red, one ncclAllReduce (sum,
 //           <= MAXR doubles) makes them global, the scalar recurrence continues on device.
 // RCCL is bound at run time (dlopen) so that the library loads on machines without it and
@@ -126,6 +127,27 @@ __global__ void k_split_fill(int n, long lo, long hi, const int *rowptr, const i
     }
 }
 
+// Rows of the remote part that hold anything (for a banded matrix: the two ends of the shard).
+__global__ void k_row_flags(int n, const int *rowptr, int *flag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = rowptr[i + 1] > rowptr[i];
+}
+__global__ void k_row_compact(int n, const int *rowptr, const int *pos, int *rows, int *crowptr, int n_kept)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && rowptr[i + 1] > rowptr[i]) { rows[pos[i]] = i; crowptr[pos[i]] = rowptr[i]; }
+    if (i == 0) crowptr[n_kept] = rowptr[n];
+}
+template <class V>
+__global__ __launch_bounds__(VB) void k_scatter_add(int nr, const int *__restrict__ rows, const V *__restrict__ part,
+                                                    V *__restrict__ y, const int *done)
+{
+    if (done && *done) return;
+    const int j = blockIdx.x * VB + threadIdx.x;
+    if (j < nr) { const int i = rows[j]; y[i] = vadd(y[i], part[j]); }
+}
+
 static int alloc_cols(CsrPart &P, int n, long nnz, bool cplx)
 {
     P.n_rows = n; P.nnz = nnz; P.owned = true;
@@ -235,6 +257,11 @@ void dist_free(lcg_hip_csr *A)
     if (A->halo) { delete static_cast<HaloPlan *>(A->halo); A->halo = nullptr; }
     if (!A->distributed) return;
     free_part(A->loc); free_part(A->rem);
+    if (A->remc.rowptr) hipFree(A->remc.rowptr);
+    A->remc = CsrPart();
+    if (A->rem_rows) hipFree(A->rem_rows);
+    if (A->rem_y) hipFree(A->rem_y);
+    A->rem_rows = nullptr; A->rem_y = nullptr;
     if (A->xfull) hipFree(A->xfull);
     A->xfull = nullptr; A->distributed = false;
 }
@@ -274,6 +301,32 @@ int dist_split(lcg_hip_csr *A, int64_t n_global, int nranks, int rank)
         hipLaunchKernelGGL((k_split_fill<double>), dim3(g), dim3(VB), 0, c.stream, n, (long)row0, (long)(row0 + n), A->main.rowptr,
                            A->main.col, A->main.val, A->loc.rowptr, A->loc.col, A->loc.val, A->rem.rowptr, A->rem.col, A->rem.val);
     HIPCHK(hipGetLastError());
+    if (nr > 0) {
+        // the remote part touches few rows (the two ends of a banded shard): drop the empty ones, so
+        // that its product costs what its entries cost and can run beside the local product
+        int *flag = nullptr, *pos = nullptr;
+        long kept = 0;
+        HIPCHK(hipMalloc(&flag, sizeof(int) * (size_t)n));
+        HIPCHK(hipMalloc(&pos, sizeof(int) * ((size_t)n + 1)));
+        hipLaunchKernelGGL(k_row_flags, dim3(g), dim3(VB), 0, c.stream, n, A->rem.rowptr, flag);
+        rc = device_exclusive_scan(n, flag, pos, c.stream, &kept);
+        if (!rc) {
+            hipError_t e = hipMalloc(&A->remc.rowptr, sizeof(int) * ((size_t)kept + 1));
+            if (e == hipSuccess) e = hipMalloc(&A->rem_rows, sizeof(int) * (size_t)kept);
+            if (e == hipSuccess) e = hipMalloc(&A->rem_y, sizeof(double) * (A->is_complex ? 2 : 1) * (size_t)kept);
+            if (e != hipSuccess) rc = fail(e, "remote-row compaction", __FILE__, __LINE__);
+        }
+        if (!rc) {
+            hipLaunchKernelGGL(k_row_compact, dim3(g), dim3(VB), 0, c.stream, n, A->rem.rowptr, pos, A->rem_rows,
+                               A->remc.rowptr, (int)kept);
+            A->remc.n_rows = (int)kept; A->remc.nnz = nr; A->remc.col = A->rem.col; A->remc.val = A->rem.val;
+            A->remc.owned = false; A->remc.padded = true;
+        }
+        hipError_t e2 = hipStreamSynchronize(c.stream);
+        hipFree(flag); hipFree(pos);
+        if (rc) return rc;
+        if (e2 != hipSuccess) return fail(e2, "remote-row compaction", __FILE__, __LINE__);
+    }
     HIPCHK(hipMalloc(&A->xfull, sizeof(double) * (A->is_complex ? 2 : 1) * (size_t)(rpr * nranks)));
     HIPCHK(hipMemsetAsync(A->xfull, 0, sizeof(double) * (A->is_complex ? 2 : 1) * (size_t)(rpr * nranks), c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
@@ -301,15 +354,28 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
             if (r != ncclSuccess) return comm_fail("ncclAllGather", r);
         }
     }
+    // ... followed there by the product of the remote columns (few rows: their sums go to rem_y) ...
+    int rc = 0;
+    if (A->remc.n_rows > 0) {
+        const double mean_r = (double)A->remc.nnz / A->remc.n_rows;
+        rc = spmv_launch(A->remc, A->is_complex, 0, mean_r, A->xfull, A->rem_y, false, c.comm_stream, done);
+        if (rc) return rc;
+    }
     HIPCHK(hipEventRecord(c.ev_b, c.comm_stream));
-    // ... while the locally-owned columns are multiplied
+    // ... while the locally-owned columns are multiplied here; then y[row] += rem_y
     const double mean_l = A->n_rows ? (double)A->loc.nnz / A->n_rows : 0.0;
-    int rc = spmv_launch(A->loc, A->is_complex, A->variant, mean_l, x, y, false, c.stream, done);
+    rc = spmv_launch(A->loc, A->is_complex, A->variant, mean_l, x, y, false, c.stream, done);
     if (rc) return rc;
     HIPCHK(hipStreamWaitEvent(c.stream, c.ev_b, 0));
-    if (A->rem.nnz > 0) {
-        const double mean_r = (double)A->rem.nnz / A->n_rows;
-        rc = spmv_launch(A->rem, A->is_complex, A->variant, mean_r, A->xfull, y, true, c.stream, done);
+    if (A->remc.n_rows > 0) {
+        const unsigned g = (unsigned)((A->remc.n_rows + VB - 1) / VB);
+        if (A->is_complex)
+            hipLaunchKernelGGL((k_scatter_add<double2>), dim3(g), dim3(VB), 0, c.stream, A->remc.n_rows, A->rem_rows,
+                               reinterpret_cast<const double2 *>(A->rem_y), reinterpret_cast<double2 *>(y), done);
+        else
+            hipLaunchKernelGGL((k_scatter_add<double>), dim3(g), dim3(VB), 0, c.stream, A->remc.n_rows, A->rem_rows,
+                               A->rem_y, y, done);
+        HIPCHK(hipGetLastError());
     }
     return rc;
 }

@@ -102,7 +102,7 @@ struct Driver {
     // A.x callback with optional event timing
     template <class F> int timed_ax(F &&call)
     {
-        if (c.profile && c.prof_used + 2 <= (int)c.prof_ev.size()) {
+        if (c.profile && (c.ax_seq++ % c.profile_every) == 0 && c.prof_used + 2 <= (int)c.prof_ev.size()) {
             HIPCHK(hipEventRecord(c.prof_ev[c.prof_used], c.stream));
             call();
             HIPCHK(hipEventRecord(c.prof_ev[c.prof_used + 1], c.stream));

@@ -66,6 +66,8 @@ struct Ctx {
     bool in_solve = false;             // a Driver is alive: A.x may honour DevState::done
     int cg_schedule = 0;               // LCG_HIP_CG_*
     bool profile = false;
+    int profile_every = 1;             // time every k-th A.x only (each timed call costs ~2 x 2 us of markers)
+    long ax_seq = 0;
     std::vector<hipEvent_t> prof_ev;   // pairs
     int prof_used = 0;
     double last_ax_mean_us = 0.0;
@@ -117,6 +119,9 @@ struct lcg_hip_csr {
     int64_t rows_per_rank = 0;
     lcgh::CsrPart loc;          // entries whose column is owned by this rank (LOCAL column index)
     lcgh::CsrPart rem;          // the others (column index into xfull / halo buffer)
+    lcgh::CsrPart remc;         // rem without its empty rows: own rowptr, rem's col/val (comm.hip: dist_split)
+    int *rem_rows = nullptr;    // local row of each remc row
+    double *rem_y = nullptr;    // remc . xfull, scattered into y after the local product
     double *xfull = nullptr;    // gather buffer
     void *halo = nullptr;       // neighbour-exchange plan (comm.hip)
 };
