@@ -43,7 +43,7 @@ class _StubLib:
         return b""
 
 
-def _worker(rank, world, port_no, n, band, q):
+def _worker(rank, world, port_no, n, band, q, schedule="classic"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_no))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -85,18 +85,46 @@ def _worker(rank, world, port_no, n, band, q):
         dist.all_reduce(t)
         return float(t.item())
 
+    reductions = [0]
+
+    def gsum(*pairs):           # ONE all-reduce for several inner products
+        t = torch.tensor([float(np.dot(a, b)) for a, b in pairs], dtype=torch.float64)
+        dist.all_reduce(t)
+        reductions[0] += 1
+        return t.tolist()
+
     b = ax(xt)
     eps, m = 1e-10, np.zeros(r1 - r0)
     Ad = ax(m); gk = Ad - b; d = -gk
     g2 = gdot(gk, gk); t = 0
-    while True:
-        if np.sqrt(g2) / n <= eps:
-            break
-        t += 1
-        Ad = ax(d); ak = g2 / gdot(d, Ad)
-        m += ak * d; gk += ak * Ad
-        g2n = gdot(gk, gk); bk = g2n / g2; g2 = g2n
-        d = bk * d - gk
+    if schedule == "classic":
+        while True:
+            if np.sqrt(g2) / n <= eps:
+                break
+            t += 1
+            Ad = ax(d); ak = g2 / gdot(d, Ad)
+            m += ak * d; gk += ak * Ad
+            g2n = gdot(gk, gk); bk = g2n / g2; g2 = g2n
+            d = bk * d - gk
+    else:
+        # the one-reduction schedule of solvers_real.hip (OpCg1Update / OpCg1Dots / FinCg1Close)
+        w = ax(gk)
+        (gw,) = gsum((gk, w))
+        ak, bk = g2 / gw, 0.0
+        d = np.zeros_like(gk); Ad = np.zeros_like(gk)
+        reductions[0] = 0
+        while True:
+            if np.sqrt(g2) / n <= eps:
+                break
+            t += 1
+            d = bk * d - gk; Ad = bk * Ad - w
+            m += ak * d; gk += ak * Ad
+            w = ax(gk)
+            g2n, gw = gsum((gk, gk), (gk, w))
+            bk = g2n / g2
+            ak = g2n / (gw - bk * g2n / ak)
+            g2 = g2n
+        assert reductions[0] == t
     err = gdot(m - xt, m - xt) ** 0.5
     mall = gather(m)[:n]
     if rank == 0:
@@ -105,16 +133,15 @@ def _worker(rank, world, port_no, n, band, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,band", [(2, 40), (2, 0), (3, 40)])
-def test_sharded_cg_matches_single_process(world, band, port):
+@pytest.mark.parametrize("world,band,schedule", [(2, 40, "classic"), (2, 0, "classic"), (3, 40, "classic"),
+                                                 (2, 40, "one-reduction"), (3, 0, "one-reduction")])
+def test_sharded_cg_matches_single_process(world, band, schedule, port):
     from oracle import pyoracle as po
     n = 1501
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, _free_port() if r == 0 else 0, n, band, q)) for r in range(world)]
-    # all ranks must share the port: re-create with the same number
-    port_no = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port_no, n, band, q)) for r in range(world)]
+    port_no = _free_port()          # all ranks share it
+    procs = [ctx.Process(target=_worker, args=(r, world, port_no, n, band, q, schedule)) for r in range(world)]
     for p in procs:
         p.start()
     t, err, mall = q.get(timeout=120)
