@@ -201,6 +201,26 @@ def main():
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "bytes_per_launch": shard_bytes, "avg_launch_us": ax_us, "launches": ax_calls}
 
+    if sharded:
+        # outside the timed region: what the two collectives of an iteration cost on this node's links
+        # (dependent back-to-back calls; all ranks take part).  Diagnostic fields for the next tuning step.
+        probe = torch.ones(8, dtype=torch.float64, device="cuda")
+        xs = torch.rand(nloc, dtype=torch.float64, device="cuda"); ys = torch.empty_like(xs)
+        res = {}
+        for name, call, reps in (("allreduce_4_doubles_us", lambda: lib.lcg_hip_allreduce_sum(probe.data_ptr(), 4), 200),
+                                 ("ax_with_exchange_us", lambda: A.spmv(xs, ys), 50)):
+            for _ in range(5):
+                call()
+            api.synchronize(); barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                call()
+            api.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) / reps * 1e6], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            res[name] = float(t.item())
+        out["comm_probe"] = res
+
     if rank == 0 and world == 1 and "roofline" in out:
         # what THIS box's memory system sustains on a plain device copy (1 GiB read + 1 GiB written),
         # next to the nominal 8 TB/s the fractions above are quoted against
