@@ -138,6 +138,9 @@ enum { SC_FUSED = 0, SC_REDUCE = 1, SC_FIN = 2 };
 __device__ __forceinline__ void publish(DevState *st)
 {
     HostStatus *h = st->host;
+    // the kernel cannot retire before these PCIe writes are acknowledged (a few us): between stops
+    // the mirror is refreshed only every (pub_mask + 1)-th body -- enough for the host's pacing
+    if (!st->done && (st->it & st->pub_mask)) return;
     // posted writes over PCIe; no fence: the host only uses `it` to pace itself and `done`
     // to stop enqueuing early, and re-reads DevState with a real copy before it returns
     // (a system-scope fence here costs ~10 us per iteration)

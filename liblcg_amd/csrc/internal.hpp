@@ -41,6 +41,7 @@ struct DevState {
     int t;              // completed iterations (the reference's t)
     int done;           // set once: every later kernel becomes a no-op
     int status;         // ST_*
+    int pub_mask;       // HostStatus is refreshed when (it & pub_mask) == 0, and at every stop
     HostStatus *host;
 };
 
