@@ -215,7 +215,10 @@ int lcg_hip_set_profiling(int on)
     c.ax_seq = 0;
     if (c.profile && c.prof_ev.empty()) {
         c.prof_ev.resize(2 * 4096);
-        for (auto &ev : c.prof_ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));   // timing only
+        // default flags on purpose: a hipEventDisableSystemFence event is not a marker of its own, it
+        // rides on the previous command, and the elapsed time then starts with THAT kernel (A.x read
+        // 35 us long -- the direction update before it -- against rocprofv3's kernel trace)
+        for (auto &ev : c.prof_ev) HIPCHK(hipEventCreate(&ev));
     }
     c.prof_used = 0;
     return 0;

@@ -68,9 +68,10 @@ def main():
         n, row, col, val, b = read_coo_system(os.path.join(G, "case_10K_A")); xs = read_solution(os.path.join(G, "case_10K_B"))
         A = api.CsrMatrix.from_coo(n, row, col, val); A.build_jacobi()
         bd = torch.from_numpy(b).cuda()
-        for name, sid in (("CG", 0), ("PCG", 1), ("CGS", 2), ("BICGSTAB", 3)):
+        for name, sid in (("CG", 0), ("CG one-reduction schedule", 0), ("PCG", 1), ("CGS", 2), ("BICGSTAB", 3)):
             m = torch.zeros(n, dtype=torch.float64, device="cuda")
             p = api.lcg_default_parameters(epsilon=1e-10, abs_diff=1)
+            api.set_cg_schedule(api.CG_ONE_REDUCTION if "one-reduction" in name else api.CG_AUTO)
 
             def go():
                 m.zero_()
