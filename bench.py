@@ -257,27 +257,43 @@ def cpu_baseline(A, b, n, args, np):
     cores = min(16, len(os.sched_getaffinity(0)))
     kind = "reference" if po.have_ref() else "port"
     orc = po.Oracle(kind)
-    try:    # libgomp is already initialised (torch loaded it): set the team size at run time
-        import ctypes
-        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
-    except OSError:
-        pass
     rp, ci, v = A.arrays_to_host()
     bh = b.cpu().numpy()
     sid = {"cg": po.LCG_CG, "pcg": po.LCG_PCG, "cgs": po.LCG_CGS, "bicgstab": po.LCG_BICGSTAB}[args.solver]
     jac = args.solver == "pcg"
 
-    def run(iters):
+    def set_team(k):    # libgomp is already initialised (torch loaded it): set the team size at run time
+        try:
+            import ctypes
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(k)
+        except OSError:
+            pass
+
+    def run(iters, k):
+        set_team(k)
         t0 = time.perf_counter()
-        r = orc.solve(sid, rp, ci, v, bh, para=po.default_para(epsilon=1e-300, max_iterations=iters), jacobi=jac,
-                      threads=cores if kind == "reference" else 1)
+        r = orc.solve(sid, rp, ci, v, bh, para=po.default_para(epsilon=1e-300, max_iterations=iters), jacobi=jac, threads=k)
         return time.perf_counter() - t0, r
-    t_probe, _ = run(3)
-    iters = int(max(5, min(400, args.cpu_seconds / max(t_probe / 3, 1e-3))))
-    t, r = run(iters)
-    return {"value": iters / t, "unit": "iter/s", "cores": cores if kind == "reference" else 1, "kind": kind,
-            "sample": f"{iters} {args.solver.upper()} iterations of the same {n}-row system "
-                      f"({'liblcg lcg_solver + OpenMP CSR callback' if kind == 'reference' else 'serial C restatement'}), {t:.1f} s"}
+
+    def sample(k, seconds):
+        t_probe, _ = run(3, k)
+        iters = int(max(5, min(400, seconds / max(t_probe / 3, 1e-3))))
+        t, _ = run(iters, k)
+        return iters, t
+    team = cores if kind == "reference" else 1
+    iters, t = sample(team, args.cpu_seconds)
+    out = {"value": iters / t, "unit": "iter/s", "cores": team, "kind": kind,
+           "sample": f"{iters} {args.solver.upper()} iterations of the same {n}-row system "
+                     f"({'liblcg lcg_solver + OpenMP CSR callback' if kind == 'reference' else 'serial C restatement'}), {t:.1f} s"}
+    if team > 1:        # all entitled cores AND one
+        i1, t1 = sample(1, args.cpu_seconds / 3)
+        out["single_thread"] = {"value": i1 / t1, "unit": "iter/s", "cores": 1, "sample": f"{i1} iterations, {t1:.1f} s"}
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
+        out["cpu_model"] = f"{model[0]} ({len(model)} logical CPUs on the node)"
+    except (OSError, IndexError):
+        pass
+    return out
 
 
 if __name__ == "__main__":
