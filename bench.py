@@ -61,6 +61,7 @@ def main():
         raise SystemExit(f"lcg_hip_init failed: {lib.lcg_hip_last_error().decode()}")
 
     dist = None
+    p2p, p2p_why = False, "disabled"
     sharded = world > 1 or bool(os.environ.get("LCG_HIP_FORCE_COMM"))    # the env var rehearses the RCCL path on one GPU
     if sharded:
         import torch.distributed as dist
@@ -68,6 +69,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         partition.init_comm_from_torch(lib)
+        # the <= 8 sums of a sync point go straight into the peers' mailboxes over xGMI when every
+        # rank could map them and the self-test passed everywhere; otherwise RCCL all-reduces them
+        if os.environ.get("LCG_HIP_P2P", "1") != "0":
+            p2p, p2p_why = partition.init_p2p_from_torch(lib)
+            if not p2p and rank == 0:
+                print(f"[bench] direct all-reduce not used: {p2p_why}", file=sys.stderr)
 
     n = args.rows
     r0, r1 = partition.shard_range(n, world, rank)
@@ -180,7 +187,8 @@ def main():
                    "rows": n, "nnz": nnz, "nnz_per_row": nnz / n, "solver": args.solver, "index": "int32",
                    "cg_schedule": ("one reduction per iteration (Chronopoulos-Gear)" if one_red else "classic, two reductions per iteration"),
                    "partition": "single" if not sharded else f"row-block x{world}, RCCL x exchange = {exchange} "
-                                f"({lib.lcg_hip_csr_exchange_volume(A.h)} doubles received per rank per A.x) + all-reduce(dots)"},
+                                f"({lib.lcg_hip_csr_exchange_volume(A.h)} doubles received per rank per A.x) + "
+                                + ("direct all-reduce(dots) over peer-mapped mailboxes, fused into the scalar step" if p2p else "RCCL all-reduce(dots)")},
         "whole_iteration_algorithmic_GBs": iter_bytes / (elapsed / args.steps) / 1e9,
         "frac_of_hbm_peak_whole_iteration": iter_bytes / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
         "rel_err_vs_x_true": rel_err,
@@ -219,6 +227,21 @@ def main():
             t = torch.tensor([(time.perf_counter() - t0) / reps * 1e6], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             res[name] = float(t.item())
+        if p2p:     # the same all-reduce through RCCL, for comparison (all ranks switch together)
+            lib.lcg_hip_p2p_enable(0)
+            call = lambda: lib.lcg_hip_allreduce_sum(probe.data_ptr(), 4)
+            for _ in range(5):
+                call()
+            api.synchronize(); barrier()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                call()
+            api.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) / 200 * 1e6], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            res["allreduce_4_doubles_rccl_us"] = float(t.item())
+            lib.lcg_hip_p2p_enable(1)
+        res["allreduce_path"] = "direct (peer mailboxes)" if p2p else "rccl"
         out["comm_probe"] = res
 
     if rank == 0 and world == 1 and "roofline" in out:
@@ -244,6 +267,9 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
+        if p2p:
+            api.synchronize(); barrier()        # nobody unmaps a mailbox a peer may still write to
+            lib.lcg_hip_p2p_disconnect()
         lib.lcg_hip_comm_destroy()
         dist.destroy_process_group()
 

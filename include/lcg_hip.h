@@ -250,6 +250,27 @@ int lcg_hip_csr_distribute(lcg_hip_csr_t A, int64_t n_global, int mode);
 int64_t lcg_hip_csr_exchange_volume(lcg_hip_csr_t A);
 int lcg_hip_allreduce_sum(double *dev_values, int count);
 int lcg_hip_barrier(void);
+/* Direct all-reduce over xGMI peer mappings (optional; RCCL stays the fallback and the courier
+ * of x).  The <= 8 sums of a sync point are a latency problem, not a bandwidth one: every rank
+ * owns a small uncached mailbox in its HBM, maps every peer's mailbox through HIP IPC, and the
+ * scalar kernel of a sync point writes its sums straight into all peers' mailboxes, waits for
+ * theirs and adds them in rank order -- reduce, exchange and scalar step in ONE kernel instead
+ * of reduce | ncclAllReduce | scalar step, and the same bits on every rank.
+ *   lcg_hip_p2p_export   allocate my mailbox, return its 64-byte IPC handle
+ *   lcg_hip_p2p_connect  handles = nranks x 64 bytes in rank order (shipped like the unique id)
+ *   lcg_hip_p2p_selftest `rounds` all-reduces of known values with a short timeout; 0 = all correct
+ *   lcg_hip_p2p_enable   route the solvers' sync points (and lcg_hip_allreduce_sum) through it;
+ *                        the caller makes sure all ranks pass the same value
+ *   lcg_hip_p2p_status   0 = not connected, 1 = connected, 2 = enabled
+ * A contribution that does not arrive within the timeout (default 20 s, LCG_HIP_P2P_TIMEOUT_MS)
+ * ends the solve on every rank with LCG_HIP_E_COMM instead of hanging. */
+#define LCG_HIP_P2P_HANDLE_BYTES 64
+int lcg_hip_p2p_export(void *handle64);
+int lcg_hip_p2p_connect(int nranks, int rank, const void *handles);
+int lcg_hip_p2p_selftest(int rounds);
+int lcg_hip_p2p_enable(int on);
+int lcg_hip_p2p_status(void);
+int lcg_hip_p2p_disconnect(void);
 /* Test hooks for the sharded product on ONE GPU: split a shard as rank `rank` of `nranks`
  * with no communicator; the caller fills the other ranks' slices of the gather buffer
  * (lcg_hip_csr_xfull) itself and then calls lcg_hip_spmv. */

@@ -95,6 +95,12 @@ SIGNATURES = {
     "lcg_hip_csr_distribute": (C.c_int, [vp, C.c_int64, C.c_int]),
     "lcg_hip_allreduce_sum": (C.c_int, [vp, C.c_int]),
     "lcg_hip_barrier": (C.c_int, []),
+    "lcg_hip_p2p_export": (C.c_int, [vp]),
+    "lcg_hip_p2p_connect": (C.c_int, [C.c_int, C.c_int, vp]),
+    "lcg_hip_p2p_selftest": (C.c_int, [C.c_int]),
+    "lcg_hip_p2p_enable": (C.c_int, [C.c_int]),
+    "lcg_hip_p2p_status": (C.c_int, []),
+    "lcg_hip_p2p_disconnect": (C.c_int, []),
     "lcg_hip_csr_split_for_test": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int]),
     "lcg_hip_csr_xfull": (vp, [vp]),
     "lcg_hip_csr_local_nnz": (C.c_int64, [vp]),

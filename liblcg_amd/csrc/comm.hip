@@ -84,8 +84,49 @@ static int load_rccl()
 
 bool comm_active() { return g_comm.comm != nullptr && (g_comm.nranks > 1 || g_comm.force); }
 
+// ---- direct all-reduce over peer-mapped mailboxes (lcg_hip.h: lcg_hip_p2p_*) -------------------
+struct Xg {
+    bool connected = false, enabled = false;
+    int P = 0, me = 0;
+    double *mine = nullptr;             // [2][XG_MAXP][XG_SLOT], uncached (or fine-grained) device memory
+    const char *mem_kind = "";
+    double **peers_dev = nullptr;       // device array [P]
+    unsigned long long *seq = nullptr;
+    int *fail = nullptr;
+    std::vector<void *> opened;         // peer mappings to close
+    long long timeout_ticks = 2000000000LL;     // 20 s of the 100 MHz wall clock
+};
+static Xg g_xg;
+constexpr size_t XG_BYTES = sizeof(double) * 2 * XG_MAXP * XG_SLOT;
+
+bool xg_box(XgBox *out)
+{
+    if (!g_xg.enabled) return false;
+    out->mine = g_xg.mine; out->peers = g_xg.peers_dev; out->seq = g_xg.seq; out->fail = g_xg.fail;
+    out->timeout_ticks = g_xg.timeout_ticks; out->P = g_xg.P; out->me = g_xg.me;
+    return true;
+}
+
+// stand-alone form: `count` doubles in device memory, in place
+__global__ __launch_bounds__(VB) void k_xg_allreduce(double *v, int count, XgBox xb, int *ok_out)
+{
+    __shared__ double sums[MAXR];
+    if ((int)threadIdx.x < MAXR) sums[threadIdx.x] = (int)threadIdx.x < count ? v[threadIdx.x] : 0.0;
+    __syncthreads();
+    const bool ok = xg_allreduce<MAXR>(xb, sums);
+    if ((int)threadIdx.x < count && ok) v[threadIdx.x] = sums[threadIdx.x];
+    if (threadIdx.x == 0 && ok_out) *ok_out = ok ? 1 : 0;
+}
+
 int comm_allreduce(double *dev, int count, hipStream_t s)
 {
+    XgBox xb;
+    if (xg_box(&xb)) {
+        if (count > MAXR) { ctx().err = "direct all-reduce: more than 8 values"; return LCG_HIP_E_ARG; }
+        hipLaunchKernelGGL(k_xg_allreduce, dim3(1), dim3(VB), 0, s, dev, count, xb, (int *)nullptr);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (!g_comm.comm) return 0;
     ncclResult_t r = g_comm.AllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, g_comm.comm, s);
     if (r != ncclSuccess) return comm_fail("ncclAllReduce", r);
@@ -466,11 +507,139 @@ int lcg_hip_allreduce_sum(double *dev_values, int count)
     return comm_allreduce(dev_values, count, ctx().stream);
 }
 
+int lcg_hip_p2p_export(void *handle64)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if (!handle64) return LCG_HIP_E_ARG;
+    if (g_xg.connected) { ctx().err = "direct all-reduce already connected"; return LCG_HIP_E_ARG; }
+    if (!g_xg.mine) {
+        // the mailbox is written by peers over the fabric while a local kernel polls it: it must not
+        // live in this GPU's L2 as ordinary (coarse-grained) memory does
+        void *p = nullptr;
+        hipError_t e = hipExtMallocWithFlags(&p, XG_BYTES, hipDeviceMallocUncached);
+        g_xg.mem_kind = "uncached";
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipExtMallocWithFlags(&p, XG_BYTES, hipDeviceMallocFinegrained);
+            g_xg.mem_kind = "fine-grained";
+        }
+        if (e != hipSuccess) return fail(e, "mailbox allocation (uncached / fine-grained device memory)", __FILE__, __LINE__);
+        g_xg.mine = static_cast<double *>(p);
+        HIPCHK(hipMemset(g_xg.mine, 0, XG_BYTES));
+        HIPCHK(hipDeviceSynchronize());
+    }
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(hipIpcMemHandle_t) == LCG_HIP_P2P_HANDLE_BYTES, "IPC handle size");
+    HIPCHK(hipIpcGetMemHandle(&h, g_xg.mine));
+    std::memcpy(handle64, &h, sizeof h);
+    return 0;
+}
+
+int lcg_hip_p2p_disconnect(void)
+{
+    if (ctx().inited) hipDeviceSynchronize();
+    for (void *p : g_xg.opened) hipIpcCloseMemHandle(p);
+    g_xg.opened.clear();
+    if (g_xg.peers_dev) hipFree(g_xg.peers_dev);
+    if (g_xg.seq) hipFree(g_xg.seq);
+    if (g_xg.fail) hipFree(g_xg.fail);
+    if (g_xg.mine) hipFree(g_xg.mine);
+    g_xg = Xg();
+    return 0;
+}
+
+int lcg_hip_p2p_connect(int nranks, int rank, const void *handles)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if (nranks < 1 || nranks > XG_MAXP || rank < 0 || rank >= nranks || !handles) return LCG_HIP_E_ARG;
+    if (!g_xg.mine) { ctx().err = "lcg_hip_p2p_connect before lcg_hip_p2p_export"; return LCG_HIP_E_ARG; }
+    if (g_xg.connected) return 0;
+    std::vector<double *> peers((size_t)nranks, nullptr);
+    for (int q = 0; q < nranks; q++) {
+        if (q == rank) { peers[q] = g_xg.mine; continue; }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, static_cast<const char *>(handles) + (size_t)q * sizeof h, sizeof h);
+        void *p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            for (void *o : g_xg.opened) hipIpcCloseMemHandle(o);
+            g_xg.opened.clear();
+            return fail(e, "hipIpcOpenMemHandle (peer mailbox)", __FILE__, __LINE__);
+        }
+        g_xg.opened.push_back(p);
+        peers[q] = static_cast<double *>(p);
+    }
+    HIPCHK(hipMalloc(&g_xg.peers_dev, sizeof(double *) * (size_t)nranks));
+    HIPCHK(hipMalloc(&g_xg.seq, sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&g_xg.fail, sizeof(int)));
+    HIPCHK(hipMemcpy(g_xg.peers_dev, peers.data(), sizeof(double *) * (size_t)nranks, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(g_xg.seq, 0, sizeof(unsigned long long)));
+    HIPCHK(hipMemset(g_xg.fail, 0, sizeof(int)));
+    HIPCHK(hipDeviceSynchronize());
+    if (const char *e = std::getenv("LCG_HIP_P2P_TIMEOUT_MS")) g_xg.timeout_ticks = std::max(1LL, atoll(e)) * 100000LL;
+    g_xg.P = nranks; g_xg.me = rank; g_xg.connected = true;
+    return 0;
+}
+
+// `rounds` all-reduces of values every rank can predict, with a 2 s timeout.  All ranks must call
+// it together (it advances the shared sequence).  A failure leaves the path disabled for good.
+int lcg_hip_p2p_selftest(int rounds)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if (!g_xg.connected) { ctx().err = "direct all-reduce not connected"; return LCG_HIP_E_COMM; }
+    Ctx &c = ctx();
+    const int P = g_xg.P, me = g_xg.me;
+    if (rounds < 1) rounds = 1;
+    double *dv = nullptr; int *dok = nullptr;
+    HIPCHK(hipMalloc(&dv, sizeof(double) * MAXR * (size_t)rounds));
+    HIPCHK(hipMalloc(&dok, sizeof(int) * (size_t)rounds));
+    std::vector<double> hv((size_t)MAXR * rounds);
+    std::vector<int> hok((size_t)rounds, 0);
+    for (int i = 0; i < rounds; i++)
+        for (int r = 0; r < MAXR; r++) hv[(size_t)i * MAXR + r] = (me + 1.0) * (i + 1.0) + 0.125 * r;
+    HIPCHK(hipMemcpyAsync(dv, hv.data(), sizeof(double) * hv.size(), hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemsetAsync(dok, 0, sizeof(int) * (size_t)rounds, c.stream));
+    XgBox xb;
+    xb.mine = g_xg.mine; xb.peers = g_xg.peers_dev; xb.seq = g_xg.seq; xb.fail = g_xg.fail;
+    xb.timeout_ticks = std::min(g_xg.timeout_ticks, 200000000LL); xb.P = P; xb.me = me;
+    for (int i = 0; i < rounds; i++)
+        hipLaunchKernelGGL(k_xg_allreduce, dim3(1), dim3(VB), 0, c.stream, dv + (size_t)i * MAXR, MAXR, xb, dok + i);
+    hipError_t e = hipMemcpyAsync(hv.data(), dv, sizeof(double) * hv.size(), hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hok.data(), dok, sizeof(int) * (size_t)rounds, hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    hipFree(dv); hipFree(dok);
+    if (e != hipSuccess) return fail(e, "direct all-reduce self-test", __FILE__, __LINE__);
+    for (int i = 0; i < rounds; i++) {
+        bool good = hok[i] == 1;
+        for (int r = 0; r < MAXR && good; r++) {
+            const double expect = 0.5 * P * (P + 1.0) * (i + 1.0) + 0.125 * r * P;   // exact in fp64
+            good = hv[(size_t)i * MAXR + r] == expect;
+        }
+        if (!good) {
+            char buf[160];
+            std::snprintf(buf, sizeof buf, "direct all-reduce self-test failed in round %d (%s mailbox, %d ranks)", i, g_xg.mem_kind, P);
+            c.err = buf;
+            g_xg.enabled = false;
+            return LCG_HIP_E_COMM;
+        }
+    }
+    return 0;
+}
+
+int lcg_hip_p2p_enable(int on)
+{
+    if (on && !g_xg.connected) { ctx().err = "direct all-reduce not connected"; return LCG_HIP_E_COMM; }
+    g_xg.enabled = on != 0;
+    return 0;
+}
+
+int lcg_hip_p2p_status(void) { return g_xg.enabled ? 2 : (g_xg.connected ? 1 : 0); }
+
 int lcg_hip_barrier(void)
 {
     int rc = ensure_init(); if (rc) return rc;
     Ctx &c = ctx();
-    if (g_comm.comm) { rc = comm_allreduce(c.state->red + MAXR - 1, 1, c.stream); if (rc) return rc; }
+    if (g_comm.comm || g_xg.enabled) { rc = comm_allreduce(c.state->red + MAXR - 1, 1, c.stream); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(c.stream));
     return 0;
 }

@@ -133,7 +133,57 @@ __device__ __forceinline__ double cnorm(double2 a) { return a.x * a.x + a.y * a.
 // ---- scalar step ----------------------------------------------------------------------------
 // mode 0: reduce partials and run fin (single GPU)   1: reduce only -> st->red
 // mode 2: fin only, sums taken from st->red (after the all-reduce)
-enum { SC_FUSED = 0, SC_REDUCE = 1, SC_FIN = 2 };
+// mode 3: reduce, exchange the sums with every peer through the mailboxes, run fin -- ONE kernel
+//         where the RCCL path needs reduce | ncclAllReduce | fin
+enum { SC_FUSED = 0, SC_REDUCE = 1, SC_FIN = 2, SC_XGMI = 3 };
+
+// Direct all-reduce (sum) of NR doubles held in LDS by one block per rank.  Lane q < P writes this
+// rank's sums and then the call's sequence number into slot [parity][me] of peer q's mailbox
+// (release, system scope), waits for slot [parity][q] of its own mailbox to show the same number
+// (acquire) and fetches peer q's sums.  The totals are then added in RANK order, so every rank
+// obtains the same bits -- which the lock-step loop (driver.hpp) relies on.  Two parities suffice:
+// a rank can finish call k+1 only after every peer has entered k+1, i.e. finished reading call k.
+// A contribution that does not arrive within timeout_ticks raises *fail; the call returns false.
+template <int NR>
+__device__ __forceinline__ bool xg_allreduce(const XgBox &xb, double *sums)
+{
+    __shared__ unsigned long long sq;
+    __shared__ double got[NR][XG_MAXP];
+    __shared__ int bad;
+    if (threadIdx.x == 0) { sq = *xb.seq + 1; *xb.seq = sq; bad = *xb.fail; }
+    __syncthreads();
+    if (bad) return false;      // an earlier exchange failed: the peers are gone, do not wait again
+    const unsigned long long k = sq;
+    const int par = (int)(k & 1);
+    if ((int)threadIdx.x < xb.P) {
+        const int q = threadIdx.x;
+        double *dst = xb.peers[q] + (size_t)(par * xb.P + xb.me) * XG_SLOT;
+#pragma unroll
+        for (int r = 0; r < NR; r++) __hip_atomic_store(dst + r, sums[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + MAXR), k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        double *src = xb.mine + (size_t)(par * xb.P + q) * XG_SLOT;
+        const long long t0 = wall_clock64();
+        bool ok = true;
+        while (__hip_atomic_load(reinterpret_cast<unsigned long long *>(src + MAXR), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != k) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > xb.timeout_ticks) { ok = false; break; }
+        }
+        if (!ok) { bad = 1; *xb.fail = 1; }
+        double tmp[NR];     // all loads in flight before the first use
+#pragma unroll
+        for (int r = 0; r < NR; r++) tmp[r] = __hip_atomic_load(src + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int r = 0; r < NR; r++) got[r][q] = tmp[r];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NR) {
+        double v = 0.0;
+        for (int q = 0; q < xb.P; q++) v += got[threadIdx.x][q];
+        sums[threadIdx.x] = v;
+    }
+    __syncthreads();
+    return bad == 0;
+}
 
 __device__ __forceinline__ void publish(DevState *st)
 {
@@ -160,7 +210,7 @@ __device__ __forceinline__ void stop_rule(DevState *st, double g2, double m2)
 }
 
 template <class Fin>
-__global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, int G, DevState *st, int mode)
+__global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, int G, DevState *st, int mode, XgBox xb)
 {
     constexpr int NRA = Fin::NR > 0 ? Fin::NR : 1;
     __shared__ double sums[NRA];
@@ -203,6 +253,13 @@ __global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, in
     } else if (Fin::NR > 0) {
         if (threadIdx.x < NRA) sums[threadIdx.x] = st->red[threadIdx.x];
         __syncthreads();
+    }
+    if (mode == SC_XGMI && Fin::NR > 0) {
+        if (!xg_allreduce<NRA>(xb, sums)) {
+            // every rank sees the failure of this or a later exchange and stops the same way
+            if (threadIdx.x == 0) { st->done = 1; st->status = ST_COMM; }
+            return;
+        }
     }
     if (mode != SC_REDUCE && threadIdx.x == 0) fin(st, sums);
 }

@@ -69,13 +69,17 @@ struct Driver {
     template <class Fin> int scal(Fin fin) { return scal_g(fin, last_g); }
     template <class Fin> int scal_g(Fin fin, int g)
     {
-        if (comm_active() && Fin::NR > 0) {
-            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_REDUCE);
+        XgBox xb;
+        if (comm_active() && Fin::NR > 0 && xg_box(&xb)) {
+            // reduce + exchange over the peer mailboxes + scalar step in one launch
+            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_XGMI, xb);
+        } else if (comm_active() && Fin::NR > 0) {
+            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_REDUCE, xb);
             int rc = comm_allreduce(c.state->red, Fin::NR, c.stream);
             if (rc) return rc;
-            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FIN);
+            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FIN, xb);
         } else {
-            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FUSED);
+            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FUSED, xb);
         }
         HIPCHK(hipGetLastError());
         return dbg(typeid(Fin).name());
@@ -140,6 +144,7 @@ struct Driver {
                 rc = body(); if (rc) return rc;
                 enq++;
                 rc = read_state(h); if (rc) return rc;
+                if (h.status == ST_COMM) return comm_lost(h);
                 if (h.status == ST_NAN) { finish(h); return code_nan; }
             }
         }
@@ -172,6 +177,7 @@ struct Driver {
             }
         }
         rc = read_state(h); if (rc) return rc;
+        if (h.status == ST_COMM) return comm_lost(h);
         finish(h);
         if (h.status == ST_NAN) return code_nan;
         if (h.done && h.status == ST_CONVERGED) return LCG_CONVERGENCE;
@@ -208,10 +214,19 @@ struct Driver {
             }
         }
         rc = read_state(h); if (rc) return rc;
+        if (h.status == ST_COMM) return comm_lost(h);
         finish(h);
         if (h.status == ST_NAN) return code_nan;
         if (h.done && h.status == ST_CONVERGED) return LCG_CONVERGENCE;
         return code_max_it;
+    }
+
+    // a peer's sums did not arrive in the direct all-reduce (devcommon.hpp: xg_allreduce)
+    int comm_lost(const DevState &h)
+    {
+        finish(h);
+        c.err = "direct all-reduce: a peer's contribution did not arrive in time";
+        return LCG_HIP_E_COMM;
     }
 
     void finish(const DevState &h)

@@ -16,7 +16,20 @@ constexpr int VB = 256;     // threads per block of every vector / scalar kernel
 constexpr int MAXG = 2048;  // most blocks a reducing kernel launches = stride of the partial-sum table
 constexpr int MAXR = 8;     // most simultaneous reductions of one kernel
 
-enum { ST_RUNNING = 0, ST_CONVERGED = 1, ST_NAN = 2, ST_ALREADY = 3 };
+enum { ST_RUNNING = 0, ST_CONVERGED = 1, ST_NAN = 2, ST_ALREADY = 3, ST_COMM = 4 };
+
+// Direct all-reduce over peer-mapped mailboxes (comm.hip, "direct all-reduce").  Handed by value to
+// the scalar kernel; all pointers are device addresses valid on THIS rank.
+constexpr int XG_SLOT = 16;     // doubles per (parity, source) slot: MAXR values + the sequence word, 128 B
+constexpr int XG_MAXP = 64;     // most ranks (one lane of one wavefront per peer)
+struct XgBox {
+    double *mine = nullptr;             // my mailbox [2][P][XG_SLOT], uncached/fine-grained device memory
+    double *const *peers = nullptr;     // [P]: every rank's mailbox as mapped into this process (peers[me] == mine)
+    unsigned long long *seq = nullptr;  // all-reduces issued so far (advanced by the kernel itself)
+    int *fail = nullptr;                // raised when a peer's contribution did not arrive in time
+    long long timeout_ticks = 0;        // wall_clock64 ticks (100 MHz)
+    int P = 0, me = 0;
+};
 
 // Mirror of the stop state in host-mapped pinned memory; written by the scalar kernels,
 // polled by the host without touching the stream.
@@ -138,6 +151,7 @@ int op_part(lcg_hip_csr *A, int layout, int conjugate, const CsrPart **out);
 // comm.hip
 int comm_allreduce(double *dev, int count, hipStream_t s);
 bool comm_active();
+bool xg_box(XgBox *out);        // true when the direct all-reduce is connected and enabled
 int dist_spmv(lcg_hip_csr *A, const double *x, double *y);
 
 } // namespace lcgh

@@ -118,7 +118,7 @@ static int reduce_to_host(Op op, long n, bool cplx, uintptr_t align_or, double *
     double *dst = nullptr;
     HIPCHK(hipMalloc(&dst, sizeof(double) * NRR));
     FinCopy<NRR> fin{dst};
-    hipLaunchKernelGGL((k_scal<FinCopy<NRR>>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FUSED);
+    hipLaunchKernelGGL((k_scal<FinCopy<NRR>>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FUSED, XgBox());
     if (comm_active()) { rc = comm_allreduce(dst, NRR, c.stream); if (rc) { hipFree(dst); return rc; } }
     hipError_t e = hipMemcpyAsync(c.scratch_host, dst, sizeof(double) * NRR, hipMemcpyDeviceToHost, c.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c.stream);

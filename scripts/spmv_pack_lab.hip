@@ -146,6 +146,114 @@ __global__ __launch_bounds__(VB) void k_spmv_p(int n, const int *__restrict__ ro
     }
 }
 
+// ---- software-pipelined tiles: a block walks CHUNKS consecutive tiles of R rows.  For the staged
+// tile it issues ALL its x gathers first and the stream loads of the NEXT tile behind them: vmcnt
+// retires in order, so waiting for the gathers (vmcnt = number of prefetch loads) leaves the
+// stream of the next tile in flight during the multiply, the row sums and the y store.
+template <int R, int UNR>
+__global__ __launch_bounds__(VB) void k_pipe(int n, int CHUNKS, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                             const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y)
+{
+    constexpr int T = VB / R;
+    constexpr int CH = 2240;
+    constexpr int NRND = (CH + VB * 4 - 1) / (VB * 4);
+    __shared__ __attribute__((aligned(16))) double sval[CH];
+    __shared__ __attribute__((aligned(16))) int scol[CH];
+    double(*sred)[R] = reinterpret_cast<double(*)[R]>(sval);
+
+    const int tid = threadIdx.x;
+    const int rl = tid % R, j0 = tid / R;
+    const int ntiles = (n + R - 1) / R;
+    const int t0 = blockIdx.x * CHUNKS;
+    const int t1 = min(ntiles, t0 + CHUNKS);
+    if (t0 >= ntiles) return;
+
+    v4i pc[NRND]; v2d pv[NRND * 2];
+    // prologue: tile t0 into registers
+    int s_cur = rowptr[t0 * R];
+    int s_nxt = rowptr[min(n, (t0 + 1) * R)];
+    {
+        const int base = s_cur & ~3, cnt = s_nxt - base;
+#pragma unroll
+        for (int r = 0; r < NRND; r++) {
+            const int u = tid * 4 + r * VB * 4;
+            const long g = (long)base + (u < cnt ? u : 0);
+            pc[r] = *reinterpret_cast<const v4i *>(col + g);
+            pv[2 * r] = reinterpret_cast<const v2d *>(val + g)[0];
+            pv[2 * r + 1] = reinterpret_cast<const v2d *>(val + g)[1];
+        }
+    }
+    int rs, re;
+    rs = rowptr[min(n, t0 * R + rl)]; re = rowptr[min(n, t0 * R + rl + 1)];
+
+    for (int t = t0; t < t1; t++) {
+        const int row0 = t * R;
+        const int nrows = min(R, n - row0);
+        const int base = s_cur & ~3, cnt = s_nxt - base;
+        // registers -> LDS
+#pragma unroll
+        for (int r = 0; r < NRND; r++) {
+            const int u = tid * 4 + r * VB * 4;
+            if (u < cnt) {
+                *reinterpret_cast<v4i *>(scol + u) = pc[r];
+                reinterpret_cast<v2d *>(sval + u)[0] = pv[2 * r];
+                reinterpret_cast<v2d *>(sval + u)[1] = pv[2 * r + 1];
+            }
+        }
+        // bounds of the next tile (uniform loads) while the stores drain
+        const bool more = t + 1 < t1;
+        const int s_n2 = more ? rowptr[min(n, (t + 2) * R)] : s_nxt;
+        __syncthreads();
+        // 1. gathers of this tile (coefficients are re-read from LDS after the wait: LDS has its own counter)
+        int c[UNR]; double xv[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; q++) {
+            const int k = rs + j0 + q * T;
+            c[q] = scol[k < re ? k - base : 0];
+        }
+        // row bounds of the next tile: older than the gathers, so the wait for the gathers covers them
+        const int rsn = rowptr[min(n, row0 + R + rl)], ren = rowptr[min(n, row0 + R + rl + 1)];
+#pragma unroll
+        for (int q = 0; q < UNR; q++) xv[q] = x[c[q]];
+        // 2. stream loads of the next tile, queued BEHIND the gathers
+        const int nbase = more ? (s_nxt & ~3) : base;
+        const int ncnt = more ? s_n2 - nbase : 0;
+#pragma unroll
+        for (int r = 0; r < NRND; r++) {
+            const int u = tid * 4 + r * VB * 4;
+            const long g = (long)nbase + (u < ncnt ? u : 0);
+            pc[r] = *reinterpret_cast<const v4i *>(col + g);
+            pv[2 * r] = reinterpret_cast<const v2d *>(val + g)[0];
+            pv[2 * r + 1] = reinterpret_cast<const v2d *>(val + g)[1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // 3. multiply (waits for the gathers only)
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < UNR; q++) {
+            const int k = rs + j0 + q * T;
+            const double a = k < re ? sval[k - base] : 0.0;
+            acc = fma(a, xv[q], acc);
+        }
+        for (int k = rs + j0 + UNR * T; k < re; k += T) acc = fma(sval[k - base], x[scol[k - base]], acc);   // rows longer than UNR*T
+        __syncthreads();
+        if (T > 1) {
+            sred[j0][rl] = acc;
+            __syncthreads();
+            if (j0 == 0 && rl < nrows) {
+                double v = sred[0][rl];
+#pragma unroll
+                for (int j = 1; j < T; j++) v += sred[j][rl];
+                y[row0 + rl] = v;
+            }
+            __syncthreads();
+        } else if (rl < nrows) {
+            y[row0 + rl] = acc;
+        }
+        s_cur = s_nxt; s_nxt = s_n2; rs = rsn; re = ren;
+    }
+}
+
 int main(int argc, char **argv)
 {
     const long n = argc > 1 ? atol(argv[1]) : 10000000;
@@ -189,8 +297,20 @@ int main(int argc, char **argv)
 
     const double bytes = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
     struct Var { const char *name; int id; std::vector<double> ms; double dev; };
-    std::vector<Var> vs = {{"shipped (lcg_hip_spmv)", 0, {}, 0}, {"packed unr4", 1, {}, 0}, {"packed unr8", 2, {}, 0}};
+    std::vector<Var> vs = {{"shipped (lcg_hip_spmv)", 0, {}, 0}, {"packed unr4", 1, {}, 0}, {"packed unr8", 2, {}, 0},
+                           {"pipe unr9 1 tile", 9001, {}, 0}, {"pipe unr9 4 tiles", 9004, {}, 0}, {"pipe unr9 16 tiles", 9016, {}, 0},
+                           {"pipe unr9 64 tiles", 9064, {}, 0}, {"pipe unr9 102 tiles", 9102, {}, 0}, {"pipe unr9 128 tiles", 9128, {}, 0},
+                           {"pipe unr8 16 tiles", 8016, {}, 0}, {"pipe unr8 102 tiles", 8102, {}, 0},
+                           {"pipe unr10 16 tiles", 10016, {}, 0}, {"pipe unr10 102 tiles", 10102, {}, 0}};
     auto run = [&](int id) {
+        if (id >= 100) {
+            const int unr = id / 1000, ch = id % 1000;
+            const int g = (nb + ch - 1) / ch;
+            if (unr == 8) hipLaunchKernelGGL((k_pipe<R, 8>), dim3(g), dim3(VB), 0, s, (int)n, ch, rowptr, col, val, x, y);
+            else if (unr == 9) hipLaunchKernelGGL((k_pipe<R, 9>), dim3(g), dim3(VB), 0, s, (int)n, ch, rowptr, col, val, x, y);
+            else hipLaunchKernelGGL((k_pipe<R, 10>), dim3(g), dim3(VB), 0, s, (int)n, ch, rowptr, col, val, x, y);
+            return;
+        }
         if (id == 0) lcg_hip_spmv(A, x, y);
         else if (id == 1) hipLaunchKernelGGL((k_spmv_p<R, 4>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
         else hipLaunchKernelGGL((k_spmv_p<R, 8>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);

@@ -30,6 +30,9 @@ def main(out_path):
         os.environ.setdefault("MASTER_PORT", "29547")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         partition.init_comm_from_torch(lib)
+        if os.environ.get("LCG_HIP_P2P", "0") == "1":
+            ok, why = partition.init_p2p_from_torch(lib)
+            assert ok, why
     mode = int(os.environ.get("LCG_HIP_DIST_MODE", "1"))
     res = {}
 
@@ -73,6 +76,7 @@ def main(out_path):
         res[f"{name}/meta"] = np.array([info.ret, info.iterations, info.residual])
         res[f"{name}/x"] = m.cpu().numpy()
     api.synchronize()
+    res["p2p_status"] = np.array(lib.lcg_hip_p2p_status())
     np.savez(out_path, **res)
     if sharded:
         dist.destroy_process_group()
