@@ -244,7 +244,13 @@ int lcg_hip_comm_size(void);
  * communicator: splits it into local-column and remote-column parts and sizes the gather
  * buffer.  rows_per_rank = ceil(n_global / nranks); rank r owns rows
  * [r*rows_per_rank, min(n_global,(r+1)*rows_per_rank)).  mode: 0 all-gather, 1 neighbour
- * (halo) exchange of only the referenced entries. */
+ * (halo) exchange of only the referenced entries (both RCCL, on a second stream beside the
+ * local product), 2 direct neighbour exchange: needs the mailboxes (lcg_hip_p2p_*), uses no
+ * collective call and no second stream -- the owner's A.x kernel carries a few extra blocks that
+ * write its boundary entries of x into the neighbours' receive buffers over the peer mappings
+ * and raise a flag there; the neighbours' remote-column product waits for that flag.  At most 8
+ * neighbours per rank; returns LCG_HIP_E_COMM on EVERY rank when any rank cannot set it up, so
+ * that all of them can fall back to mode 1 or 0 together. */
 int lcg_hip_csr_distribute(lcg_hip_csr_t A, int64_t n_global, int mode);
 /* x entries this rank receives per A.x under the chosen mode (plan volume, for reporting). */
 int64_t lcg_hip_csr_exchange_volume(lcg_hip_csr_t A);

@@ -82,7 +82,14 @@ static int load_rccl()
     return 0;
 }
 
-bool comm_active() { return g_comm.comm != nullptr && (g_comm.nranks > 1 || g_comm.force); }
+struct Xg;
+static bool xg_world(int *P, int *me);
+bool comm_active()
+{
+    if (g_comm.comm != nullptr && (g_comm.nranks > 1 || g_comm.force)) return true;
+    int P = 1, me = 0;
+    return xg_world(&P, &me) && P > 1;      // mailboxes only (no RCCL): the one-GPU rehearsal of several ranks
+}
 
 // ---- direct all-reduce over peer-mapped mailboxes (lcg_hip.h: lcg_hip_p2p_*) -------------------
 struct Xg {
@@ -98,6 +105,15 @@ struct Xg {
 };
 static Xg g_xg;
 constexpr size_t XG_BYTES = sizeof(double) * 2 * XG_MAXP * XG_SLOT;
+
+static bool xg_world(int *P, int *me)
+{
+    if (!g_xg.enabled) return false;
+    *P = g_xg.P; *me = g_xg.me;
+    return true;
+}
+static int world_size() { return g_comm.comm ? g_comm.nranks : (g_xg.enabled ? g_xg.P : 1); }
+static int world_rank() { return g_comm.comm ? g_comm.rank : (g_xg.enabled ? g_xg.me : 0); }
 
 bool xg_box(XgBox *out)
 {
@@ -116,6 +132,72 @@ __global__ __launch_bounds__(VB) void k_xg_allreduce(double *v, int count, XgBox
     const bool ok = xg_allreduce<MAXR>(xb, sums);
     if ((int)threadIdx.x < count && ok) v[threadIdx.x] = sums[threadIdx.x];
     if (threadIdx.x == 0 && ok_out) *ok_out = ok ? 1 : 0;
+}
+
+// all-gather of MAXR 64-bit words per rank through the same mailboxes: out[q][r] = word r of rank q
+__global__ __launch_bounds__(VB) void k_xg_allgather(const double *in, double *out, XgBox xb, int *ok_out)
+{
+    __shared__ double mine[MAXR];
+    __shared__ double got[MAXR][XG_MAXP];
+    if ((int)threadIdx.x < MAXR) mine[threadIdx.x] = in[threadIdx.x];
+    __syncthreads();
+    const bool ok = xg_exchange<MAXR>(xb, mine, got);
+    if (ok)
+        for (int i = threadIdx.x; i < MAXR * xb.P; i += VB) out[i] = got[i % MAXR][i / MAXR];
+    if (threadIdx.x == 0) *ok_out = ok ? 1 : 0;
+}
+
+// host form (collective, synchronises): words = 8 x 64 bit in, P x 8 out.  Doubles only carry the
+// bits (plain 64-bit loads and stores end to end).
+static int xg_allgather_host(const unsigned long long *in8, unsigned long long *outP8)
+{
+    Ctx &c = ctx();
+    XgBox xb;
+    if (!xg_box(&xb)) { c.err = "direct exchange needs the mailboxes (lcg_hip_p2p_enable)"; return LCG_HIP_E_COMM; }
+    double *d = nullptr; int *dok = nullptr;
+    HIPCHK(hipMalloc(&d, sizeof(double) * MAXR * (size_t)(xb.P + 1)));
+    HIPCHK(hipMalloc(&dok, sizeof(int)));
+    int hok = 0;
+    hipError_t e = hipMemcpyAsync(d, in8, sizeof(double) * MAXR, hipMemcpyHostToDevice, c.stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_xg_allgather, dim3(1), dim3(VB), 0, c.stream, d, d + MAXR, xb, dok);
+        e = hipMemcpyAsync(outP8, d + MAXR, sizeof(double) * MAXR * (size_t)xb.P, hipMemcpyDeviceToHost, c.stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&hok, dok, sizeof(int), hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    hipFree(d); hipFree(dok);
+    if (e != hipSuccess) return fail(e, "mailbox all-gather", __FILE__, __LINE__);
+    if (!hok) { c.err = "mailbox all-gather: a peer did not answer in time"; return LCG_HIP_E_COMM; }
+    return 0;
+}
+
+// any number of words per rank (rounds of 8): out[q*nwords + i]
+static int xg_allgather_words(const unsigned long long *in, int nwords, std::vector<unsigned long long> &out)
+{
+    const int P = g_xg.P;
+    out.assign((size_t)P * nwords, 0);
+    std::vector<unsigned long long> rnd((size_t)P * MAXR);
+    for (int w0 = 0; w0 < nwords; w0 += MAXR) {
+        unsigned long long buf[MAXR] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < MAXR && w0 + i < nwords; i++) buf[i] = in[w0 + i];
+        int rc = xg_allgather_host(buf, rnd.data());
+        if (rc) return rc;
+        for (int q = 0; q < P; q++)
+            for (int i = 0; i < MAXR && w0 + i < nwords; i++) out[(size_t)q * nwords + w0 + i] = rnd[(size_t)q * MAXR + i];
+    }
+    return 0;
+}
+
+// true only if every rank passed true (collective)
+static int xg_agree(bool mine, bool *all)
+{
+    unsigned long long w = mine ? 1 : 0;
+    std::vector<unsigned long long> out;
+    int rc = xg_allgather_words(&w, 1, out);
+    if (rc) return rc;
+    *all = true;
+    for (unsigned long long v : out) *all = *all && v == 1;
+    return 0;
 }
 
 int comm_allreduce(double *dev, int count, hipStream_t s)
@@ -293,8 +375,201 @@ static int halo_exchange(lcg_hip_csr *A, const double *x, hipStream_t s)
     return 0;
 }
 
+
+// ---- direct neighbour exchange over peer mappings (dist mode 2) ------------------------------------
+// Same plan as the neighbour exchange above (contiguous ranges per owner), but no collective call
+// and no second stream: the OWNER writes its range of x into the neighbours' receive buffers
+// (pushing blocks ride in front of the local product's grid: csr.hip) and raises its flag word
+// there; the remote-column product of a neighbour waits for the flags of the same call.
+//   recv   : [2][P*rpr] doubles (x w), ordinary device memory, addressed by GLOBAL column; the two
+//            halves alternate per call -- a neighbour can be one call ahead, never two, because its
+//            next push needs my flag of this call first (neighbourhood is made symmetric for that)
+//   flags  : [XG_MAXP] 64-bit words by source rank, uncached memory (polled while peers write)
+struct Direct {
+    double *recv = nullptr;
+    unsigned long long *flags = nullptr;
+    unsigned int *ticket = nullptr;
+    size_t half = 0;                    // doubles per half of recv
+    unsigned long long calls = 0;       // A.x calls made with this matrix (same on every rank)
+    int nnb = 0;
+    int nb_rank[XG_MAXSEG];
+    double *nb_recv[XG_MAXSEG];         // neighbour's recv as mapped here
+    unsigned long long *nb_flags[XG_MAXSEG];
+    long long give_lo[XG_MAXSEG], give_hi[XG_MAXSEG];   // global rows of mine the neighbour reads (may be empty)
+    std::vector<void *> opened;
+    long long recv_total = 0;
+    PushPlan push;      // src/dst/seq filled per call
+    WaitPlan wait;
+};
+
+__global__ __launch_bounds__(VB) void k_push(PushPlan pp) { push_block(pp, blockIdx.x); }
+
+// Remote-column product of the rows that have remote columns: waits for the neighbours' flags, then
+// y[rows[j]] += sum_k val[k] * xrecv[col[k]], 4 lanes per row (this part is a few % of the shard).
+template <class V>
+__global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                               const V *__restrict__ val, const int *__restrict__ rows,
+                                               const V *__restrict__ xrecv, V *__restrict__ y, WaitPlan wp, DevState *st,
+                                               const int *done)
+{
+    if (!wait_flags(wp)) {
+        if (st && blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->status = ST_COMM; }
+        return;
+    }
+    if (done && *done) return;
+    constexpr int T = 4;
+    const long gt = (long)blockIdx.x * VB + threadIdx.x;
+    const long j = gt / T;
+    const int lane = (int)(gt % T);
+    V acc = vzero(V());
+    if (j < nr)
+        for (int k = rowptr[j] + lane; k < rowptr[j + 1]; k += T) acc = mac(val[k], xrecv[col[k]], acc);
+#pragma unroll
+    for (int off = T / 2; off > 0; off >>= 1) acc = vadd(acc, shfl_down_v(acc, off, T));
+    if (j < nr && lane == 0) { const int i = rows[j]; y[i] = vadd(y[i], acc); }
+}
+
+static void direct_free(lcg_hip_csr *A)
+{
+    Direct *D = static_cast<Direct *>(A->direct);
+    if (!D) return;
+    if (ctx().inited) (void)hipDeviceSynchronize();
+    for (void *p : D->opened) (void)hipIpcCloseMemHandle(p);
+    if (D->recv) (void)hipFree(D->recv);
+    if (D->flags) (void)hipFree(D->flags);
+    if (D->ticket) (void)hipFree(D->ticket);
+    delete D;
+    A->direct = nullptr;
+}
+
+// Collective over the mailboxes.  Every rank takes the same decision at every step (xg_agree), so
+// a rank that cannot go on makes all of them return LCG_HIP_E_COMM and the caller picks another mode.
+static int direct_setup(lcg_hip_csr *A)
+{
+    Ctx &c = ctx();
+    XgBox xb;
+    if (!xg_box(&xb)) { c.err = "direct exchange needs the mailboxes (lcg_hip_p2p_connect + enable)"; return LCG_HIP_E_COMM; }
+    const int P = xb.P, me = xb.me;
+    const size_t w = A->is_complex ? 2 : 1;
+    Direct *D = new Direct();
+    A->direct = D;
+    auto give_up = [&](int rc, const char *why) { if (why) c.err = why; direct_free(A); return rc; };
+
+    // 1. what I need from each owner; everybody learns everybody's needs
+    std::vector<long long> need;
+    int rc = need_ranges(A, P, need);
+    bool all = false;
+    int rc2 = xg_agree(rc == 0, &all);
+    if (rc2) return give_up(rc2, nullptr);
+    if (!all) return give_up(rc ? rc : LCG_HIP_E_COMM, rc ? nullptr : "direct exchange: a peer could not scan its columns");
+    std::vector<unsigned long long> table;
+    rc = xg_allgather_words(reinterpret_cast<const unsigned long long *>(need.data()), 2 * P, table);
+    if (rc) return give_up(rc, nullptr);
+    auto T = [&](int q, int p, int k) { return (long long)table[(size_t)q * 2 * P + 2 * p + k]; };   // what q needs from p
+    // 2. neighbours: anybody I give to or take from (symmetric by construction)
+    for (int q = 0; q < P; q++) {
+        if (q == me) continue;
+        const bool take = need[2 * q + 1] > need[2 * q];
+        const bool give = T(q, me, 1) > T(q, me, 0);
+        if (!take && !give) continue;
+        if (D->nnb < XG_MAXSEG) {
+            const int s = D->nnb;
+            D->nb_rank[s] = q;
+            D->give_lo[s] = give ? T(q, me, 0) : 0; D->give_hi[s] = give ? T(q, me, 1) : 0;
+            if (take) D->recv_total += need[2 * q + 1] - need[2 * q];
+        }
+        D->nnb++;
+    }
+    const bool fits = D->nnb <= XG_MAXSEG;
+    rc = xg_agree(fits, &all);
+    if (rc) return give_up(rc, nullptr);
+    if (!all) return give_up(LCG_HIP_E_COMM, "direct exchange: a rank has more than 8 neighbours (use mode 1 or 0)");
+    // 3. buffers and their IPC handles
+    D->half = (size_t)A->rows_per_rank * P * w;
+    hipError_t e = hipMalloc(&D->recv, sizeof(double) * 2 * D->half);
+    if (e == hipSuccess) e = hipMemsetAsync(D->recv, 0, sizeof(double) * 2 * D->half, c.stream);
+    if (e == hipSuccess) {
+        void *p = nullptr;
+        e = hipExtMallocWithFlags(&p, sizeof(unsigned long long) * XG_MAXP, hipDeviceMallocUncached);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, sizeof(unsigned long long) * XG_MAXP, hipDeviceMallocFinegrained); }
+        D->flags = static_cast<unsigned long long *>(p);
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(D->flags, 0, sizeof(unsigned long long) * XG_MAXP, c.stream);
+    if (e == hipSuccess) e = hipMalloc(&D->ticket, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemsetAsync(D->ticket, 0, sizeof(unsigned int), c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    unsigned long long hw[16] = {0};
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    if (e == hipSuccess) { hipIpcMemHandle_t h; e = hipIpcGetMemHandle(&h, D->recv); std::memcpy(hw, &h, 64); }
+    if (e == hipSuccess) { hipIpcMemHandle_t h; e = hipIpcGetMemHandle(&h, D->flags); std::memcpy(hw + 8, &h, 64); }
+    if (e != hipSuccess) (void)fail(e, "direct exchange buffers", __FILE__, __LINE__);
+    rc = xg_agree(e == hipSuccess, &all);
+    if (rc) return give_up(rc, nullptr);
+    if (!all) return give_up(LCG_HIP_E_COMM, e == hipSuccess ? "direct exchange: a peer could not allocate or export its buffers" : nullptr);
+    std::vector<unsigned long long> handles;
+    rc = xg_allgather_words(hw, 16, handles);
+    if (rc) return give_up(rc, nullptr);
+    // 4. map the neighbours' buffers
+    e = hipSuccess;
+    for (int s = 0; s < D->nnb && e == hipSuccess; s++) {
+        const int q = D->nb_rank[s];
+        hipIpcMemHandle_t h; void *p = nullptr;
+        std::memcpy(&h, &handles[(size_t)q * 16], 64);
+        e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) break;
+        D->opened.push_back(p); D->nb_recv[s] = static_cast<double *>(p);
+        std::memcpy(&h, &handles[(size_t)q * 16 + 8], 64);
+        e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) break;
+        D->opened.push_back(p); D->nb_flags[s] = static_cast<unsigned long long *>(p);
+    }
+    if (e != hipSuccess) (void)fail(e, "hipIpcOpenMemHandle (neighbour buffers)", __FILE__, __LINE__);
+    rc = xg_agree(e == hipSuccess, &all);
+    if (rc) return give_up(rc, nullptr);
+    if (!all) return give_up(LCG_HIP_E_COMM, e == hipSuccess ? "direct exchange: a peer could not map a neighbour" : nullptr);
+    // 5. the per-call plans (pointers that depend on the call's parity are filled in dist_spmv)
+    PushPlan &pp = D->push;
+    pp.ticket = D->ticket;
+    int nb = 0;
+    for (int s = 0; s < D->nnb; s++) {
+        pp.flag[pp.nflag++] = D->nb_flags[s] + me;
+        D->wait.flag[D->wait.n++] = D->flags + D->nb_rank[s];
+        const long long cnt = (D->give_hi[s] - D->give_lo[s]) * (long long)w;
+        if (cnt <= 0) continue;
+        pp.count[pp.nseg] = (long)cnt;
+        pp.first_block[pp.nseg] = nb;
+        nb += (int)((cnt + PUSH_CHUNK - 1) / PUSH_CHUNK);
+        pp.nseg++;
+    }
+    pp.first_block[pp.nseg] = nb;
+    pp.nblocks = nb > 0 ? nb : (pp.nflag > 0 ? 1 : 0);     // flags go out even when no data does
+    D->wait.timeout_ticks = xb.timeout_ticks;
+    D->wait.fail = xb.fail;
+    return 0;
+}
+
+// per call: the pushing plan with this call's number and parity
+static void direct_plans(lcg_hip_csr *A, const double *x, PushPlan *pp, WaitPlan *wp, const double **xrecv)
+{
+    Direct *D = static_cast<Direct *>(A->direct);
+    const size_t w = A->is_complex ? 2 : 1;
+    const unsigned long long k = ++D->calls;
+    const size_t par = (size_t)(k & 1);
+    *pp = D->push; *wp = D->wait;
+    pp->seq = k; wp->seq = k;
+    int seg = 0;
+    for (int s = 0; s < D->nnb; s++) {
+        if (D->give_hi[s] <= D->give_lo[s]) continue;
+        pp->src[seg] = x + w * (size_t)(D->give_lo[s] - A->row0);
+        pp->dst[seg] = D->nb_recv[s] + par * D->half + w * (size_t)D->give_lo[s];
+        seg++;
+    }
+    *xrecv = D->recv + par * D->half;
+}
+
 void dist_free(lcg_hip_csr *A)
 {
+    direct_free(A);
     if (A->halo) { delete static_cast<HaloPlan *>(A->halo); A->halo = nullptr; }
     if (!A->distributed) return;
     free_part(A->loc); free_part(A->rem);
@@ -380,6 +655,28 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
     Ctx &c = ctx();
     const size_t w = A->is_complex ? 2 : 1;
     const int *done = c.in_solve ? &c.state->done : nullptr;
+    if (A->dist_mode == 2 && A->direct) {
+        // one stream, no collective: [push blocks + local product] | [wait for flags + remote product]
+        PushPlan pp; WaitPlan wp; const double *xrecv = nullptr;
+        direct_plans(A, x, &pp, &wp, &xrecv);
+        const double mean_l = A->n_rows ? (double)A->loc.nnz / A->n_rows : 0.0;
+        int rc = spmv_launch_push(A->loc, A->is_complex, A->variant, mean_l, x, y, c.stream, done, pp);
+        if (rc) return rc;
+        if (A->remc.n_rows > 0 || wp.n > 0) {
+            const int nr = A->remc.n_rows;
+            const unsigned g = (unsigned)std::max<long>(1, ((long)nr * 4 + VB - 1) / VB);
+            DevState *st = c.in_solve ? c.state : nullptr;
+            if (A->is_complex)
+                hipLaunchKernelGGL((k_remote<double2>), dim3(g), dim3(VB), 0, c.stream, nr, A->remc.rowptr, A->remc.col,
+                                   reinterpret_cast<const double2 *>(A->remc.val), A->rem_rows,
+                                   reinterpret_cast<const double2 *>(xrecv), reinterpret_cast<double2 *>(y), wp, st, done);
+            else
+                hipLaunchKernelGGL((k_remote<double>), dim3(g), dim3(VB), 0, c.stream, nr, A->remc.rowptr, A->remc.col,
+                                   A->remc.val, A->rem_rows, xrecv, y, wp, st, done);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
+    }
     double *mine = A->xfull + w * (size_t)(A->row0);
     // gather on the second stream ...
     HIPCHK(hipEventRecord(c.ev_a, c.stream));
@@ -465,10 +762,19 @@ int lcg_hip_comm_size(void) { return g_comm.nranks; }
 int lcg_hip_csr_distribute(lcg_hip_csr_t A, int64_t n_global, int mode)
 {
     if (!A || n_global <= 0) return LCG_HIP_E_ARG;
+    if (mode < 0 || mode > 2) return LCG_HIP_E_ARG;
+    if (mode != 2 && !g_comm.comm && world_size() > 1) {
+        ctx().err = "modes 0 and 1 move x with RCCL: no communicator (lcg_hip_comm_init)";
+        return LCG_HIP_E_COMM;
+    }
     A->dist_mode = mode;
-    int rc = dist_split(A, n_global, g_comm.nranks, g_comm.rank);
+    int rc = dist_split(A, n_global, world_size(), world_rank());
     if (rc) return rc;
     if (mode == 1 && g_comm.comm) rc = halo_setup(A);
+    if (mode == 2) {
+        rc = direct_setup(A);
+        if (rc) A->dist_mode = 0;       // split stays; the caller distributes again under another mode
+    }
     return rc;
 }
 
@@ -477,7 +783,8 @@ int64_t lcg_hip_csr_exchange_volume(lcg_hip_csr_t A)
 {
     if (!A || !A->distributed) return 0;
     if (A->dist_mode == 1 && A->halo) return static_cast<const HaloPlan *>(A->halo)->recv_total;
-    return (int64_t)A->rows_per_rank * (g_comm.nranks - 1);
+    if (A->dist_mode == 2 && A->direct) return static_cast<const Direct *>(A->direct)->recv_total;
+    return (int64_t)A->rows_per_rank * (world_size() - 1);
 }
 
 // test hook: the [lo,hi) column range needed from each of `nranks` owners (after split_for_test)

@@ -25,27 +25,20 @@
 
 namespace lcgh {
 
-// ------------------------------------------------------------------------------ value ops
-__device__ __forceinline__ double vzero(double) { return 0.0; }
-__device__ __forceinline__ double2 vzero(double2) { return make_double2(0.0, 0.0); }
-__device__ __forceinline__ double mac(double a, double x, double acc) { return fma(a, x, acc); }
-__device__ __forceinline__ double2 mac(double2 a, double2 x, double2 acc) { return cfma(a, x, acc); }
-__device__ __forceinline__ double shfl_down_v(double v, int off, int w) { return __shfl_down(v, off, w); }
-__device__ __forceinline__ double2 shfl_down_v(double2 v, int off, int w)
-{
-    return make_double2(__shfl_down(v.x, off, w), __shfl_down(v.y, off, w));
-}
-
 // ------------------------------------------------------------------- wave-per-row family
-template <class V, int T, bool ACC>
+// PUSH: the first pp.nblocks blocks of the grid do not multiply; they carry this rank's boundary
+// entries of x to the neighbours (devcommon.hpp: push_block) while the rest of the grid works.
+template <class V, int T, bool ACC, bool PUSH = false>
 __global__ __launch_bounds__(VB) void k_spmv_wave(int n, const int *__restrict__ rowptr,
                                                   const int *__restrict__ col, const V *__restrict__ val,
                                                   const V *__restrict__ x, V *__restrict__ y,
-                                                  const int *done)
+                                                  const int *done, PushPlan pp)
 {
+    if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
+    const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
     if (done && *done) return;
     const int sub = threadIdx.x % T;
-    const long row = ((long)blockIdx.x * VB + threadIdx.x) / T;
+    const long row = ((long)bid * VB + threadIdx.x) / T;
     V acc = vzero(V());
     if (row < n) {
         const int s = rowptr[row], e = rowptr[row + 1];
@@ -87,12 +80,14 @@ __global__ void k_max_slice(int n, int R, const int *rowptr, int *out)
 // ---- one-window kernel: the host has verified (k_max_slice) that every block's slice fits one
 // LDS window.  ALL of the block's HBM loads are issued before the first LDS store, 16 B per
 // lane per access (~25 KB in flight per block); then every lane keeps UNR gathers of x in flight.
-template <class V, int R, bool ACC>
+template <class V, int R, bool ACC, bool PUSH = false>
 __global__ __launch_bounds__(VB) void k_spmv_lds1(int n, long nnz, const int *__restrict__ rowptr,
                                                   const int *__restrict__ col, const V *__restrict__ val,
                                                   const V *__restrict__ x, V *__restrict__ y,
-                                                  const int *done)
+                                                  const int *done, PushPlan pp)
 {
+    if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
+    const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
     constexpr int T = VB / R;
     constexpr int CH = LdsCfg<V>::CH;                       // entries per LDS window (multiple of 4)
     constexpr int NRND = (CH + VB * 4 - 1) / (VB * 4);      // 4-entry units per lane
@@ -105,7 +100,7 @@ __global__ __launch_bounds__(VB) void k_spmv_lds1(int n, long nnz, const int *__
     if (done && *done) return;
 
     const int tid = threadIdx.x;
-    const int row0 = blockIdx.x * R;
+    const int row0 = bid * R;
     const int nrows = min(R, n - row0);
     const int rl = tid % R, j0 = tid / R;
     const int base = rowptr[row0] & ~3;
@@ -169,12 +164,14 @@ __global__ __launch_bounds__(VB) void k_spmv_lds1(int n, long nnz, const int *__
 
 // ---- windowed kernel: some block's rows are too long for one window; the slice is walked
 // window by window (same mapping, general row clipping)
-template <class V, int R, bool ACC>
+template <class V, int R, bool ACC, bool PUSH = false>
 __global__ __launch_bounds__(VB) void k_spmv_ldsw(int n, long nnz, const int *__restrict__ rowptr,
                                                   const int *__restrict__ col, const V *__restrict__ val,
                                                   const V *__restrict__ x, V *__restrict__ y,
-                                                  const int *done)
+                                                  const int *done, PushPlan pp)
 {
+    if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
+    const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
     constexpr int T = VB / R;
     constexpr int CH = LdsCfg<V>::CH;
     constexpr int VU = sizeof(V) / 4;
@@ -184,7 +181,7 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsw(int n, long nnz, const int *__
     if (done && *done) return;
 
     const int tid = threadIdx.x;
-    const int row0 = blockIdx.x * R;
+    const int row0 = bid * R;
     const int nrows = min(R, n - row0);
     const int rl = tid % R, j0 = tid / R;
     const int s = rowptr[row0], e = rowptr[row0 + nrows];
@@ -230,12 +227,20 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsw(int n, long nnz, const int *__
     }
 }
 
-template <class V, bool ACC>
+template <class V, bool ACC, bool PUSH = false>
 static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V *x, V *y, hipStream_t s,
-                         const int *done)
+                         const int *done, const PushPlan &pp = PushPlan())
 {
     const int n = P.n_rows;
-    if (n == 0) return 0;
+    const unsigned xb = PUSH ? (unsigned)pp.nblocks : 0u;       // pushing blocks in front of the grid
+    if (n == 0) {
+        if (PUSH && xb > 0) {       // nothing to multiply, but the neighbours still wait for x and the flags
+            hipLaunchKernelGGL((k_spmv_wave<V, 1, ACC, PUSH>), dim3(xb), dim3(VB), 0, s, 0, P.rowptr, P.col,
+                               reinterpret_cast<const V *>(P.val), x, y, done, pp);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
+    }
     const V *val = reinterpret_cast<const V *>(P.val);
     const bool al16 = (((uintptr_t)P.val | (uintptr_t)P.col) & 15) == 0;
     if (variant == 0) {
@@ -266,11 +271,11 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
 #define LDS_CASE(RR)                                                                                   \
     case RR:                                                                                           \
         if (onewin)                                                                                    \
-            hipLaunchKernelGGL((k_spmv_lds1<V, RR, ACC>), dim3((n + RR - 1) / RR), dim3(VB), 0, s, n,    \
-                               (long)P.nnz, P.rowptr, P.col, val, x, y, done);                         \
+            hipLaunchKernelGGL((k_spmv_lds1<V, RR, ACC, PUSH>), dim3((n + RR - 1) / RR + xb), dim3(VB), 0, s, n, \
+                               (long)P.nnz, P.rowptr, P.col, val, x, y, done, pp);                     \
         else                                                                                           \
-            hipLaunchKernelGGL((k_spmv_ldsw<V, RR, ACC>), dim3((n + RR - 1) / RR), dim3(VB), 0, s, n,   \
-                               (long)P.nnz, P.rowptr, P.col, val, x, y, done);                         \
+            hipLaunchKernelGGL((k_spmv_ldsw<V, RR, ACC, PUSH>), dim3((n + RR - 1) / RR + xb), dim3(VB), 0, s, n, \
+                               (long)P.nnz, P.rowptr, P.col, val, x, y, done, pp);                     \
         break;
         switch (R) {
             LDS_CASE(256) LDS_CASE(128) LDS_CASE(64) LDS_CASE(32) LDS_CASE(16)
@@ -281,8 +286,8 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
 #define WAVE_CASE(TT)                                                                                  \
     case TT: {                                                                                         \
         const long threads = (long)n * TT;                                                             \
-        hipLaunchKernelGGL((k_spmv_wave<V, TT, ACC>), dim3((unsigned)((threads + VB - 1) / VB)), dim3(VB), 0, s, \
-                           n, P.rowptr, P.col, val, x, y, done);                                       \
+        hipLaunchKernelGGL((k_spmv_wave<V, TT, ACC, PUSH>), dim3((unsigned)((threads + VB - 1) / VB) + xb), dim3(VB), 0, s, \
+                           n, P.rowptr, P.col, val, x, y, done, pp);                                   \
     } break;
         switch (variant) {
             WAVE_CASE(1) WAVE_CASE(2) WAVE_CASE(4) WAVE_CASE(8) WAVE_CASE(16) WAVE_CASE(32) WAVE_CASE(64)
@@ -305,6 +310,15 @@ int spmv_launch(const CsrPart &P, bool is_complex, int variant, double mean_row,
     }
     return accumulate ? spmv_dispatch<double, true>(P, variant, mean_row, x, y, s, done)
                       : spmv_dispatch<double, false>(P, variant, mean_row, x, y, s, done);
+}
+
+int spmv_launch_push(const CsrPart &P, bool is_complex, int variant, double mean_row, const double *x, double *y,
+                     hipStream_t s, const int *done, const PushPlan &pp)
+{
+    if (is_complex)
+        return spmv_dispatch<double2, false, true>(P, variant, mean_row, reinterpret_cast<const double2 *>(x),
+                                                   reinterpret_cast<double2 *>(y), s, done, pp);
+    return spmv_dispatch<double, false, true>(P, variant, mean_row, x, y, s, done, pp);
 }
 
 // ------------------------------------------------------------------------- Jacobi / diagonal

@@ -130,6 +130,17 @@ __device__ __forceinline__ double2 cdiv(double2 a, double2 b)
 }
 __device__ __forceinline__ double cnorm(double2 a) { return a.x * a.x + a.y * a.y; }
 
+// value ops shared by the A.x kernels (csr.hip, comm.hip)
+__device__ __forceinline__ double vzero(double) { return 0.0; }
+__device__ __forceinline__ double2 vzero(double2) { return make_double2(0.0, 0.0); }
+__device__ __forceinline__ double mac(double a, double x, double acc) { return fma(a, x, acc); }
+__device__ __forceinline__ double2 mac(double2 a, double2 x, double2 acc) { return cfma(a, x, acc); }
+__device__ __forceinline__ double shfl_down_v(double v, int off, int w) { return __shfl_down(v, off, w); }
+__device__ __forceinline__ double2 shfl_down_v(double2 v, int off, int w)
+{
+    return make_double2(__shfl_down(v.x, off, w), __shfl_down(v.y, off, w));
+}
+
 // ---- scalar step ----------------------------------------------------------------------------
 // mode 0: reduce partials and run fin (single GPU)   1: reduce only -> st->red
 // mode 2: fin only, sums taken from st->red (after the all-reduce)
@@ -145,10 +156,9 @@ enum { SC_FUSED = 0, SC_REDUCE = 1, SC_FIN = 2, SC_XGMI = 3 };
 // a rank can finish call k+1 only after every peer has entered k+1, i.e. finished reading call k.
 // A contribution that does not arrive within timeout_ticks raises *fail; the call returns false.
 template <int NR>
-__device__ __forceinline__ bool xg_allreduce(const XgBox &xb, double *sums)
+__device__ __forceinline__ bool xg_exchange(const XgBox &xb, const double *sums, double (*got)[XG_MAXP])
 {
     __shared__ unsigned long long sq;
-    __shared__ double got[NR][XG_MAXP];
     __shared__ int bad;
     if (threadIdx.x == 0) { sq = *xb.seq + 1; *xb.seq = sq; bad = *xb.fail; }
     __syncthreads();
@@ -176,13 +186,74 @@ __device__ __forceinline__ bool xg_allreduce(const XgBox &xb, double *sums)
         for (int r = 0; r < NR; r++) got[r][q] = tmp[r];
     }
     __syncthreads();
+    return bad == 0;
+}
+
+template <int NR>
+__device__ __forceinline__ bool xg_allreduce(const XgBox &xb, double *sums)
+{
+    __shared__ double got[NR][XG_MAXP];
+    if (!xg_exchange<NR>(xb, sums, got)) return false;
     if ((int)threadIdx.x < NR) {
         double v = 0.0;
         for (int q = 0; q < xb.P; q++) v += got[threadIdx.x][q];
         sums[threadIdx.x] = v;
     }
     __syncthreads();
-    return bad == 0;
+    return true;
+}
+
+// ---- direct neighbour exchange (dist mode 2) ----------------------------------------------------
+// Block b of the pushing blocks copies its chunk of a segment of x into the neighbour's receive
+// buffer (peer-mapped memory), makes it visible there (release, system scope) and takes a ticket;
+// the block that takes the last ticket raises this rank's flag word at every neighbour.
+__device__ __forceinline__ void push_block(const PushPlan &pp, int b)
+{
+    int s = 0;
+    while (s + 1 < pp.nseg && b >= pp.first_block[s + 1]) s++;
+    if (pp.nseg > 0) {
+        const long off = (long)(b - pp.first_block[s]) * PUSH_CHUNK;
+        const long cnt = min((long)PUSH_CHUNK, pp.count[s] - off);
+        const double *src = pp.src[s] + off;
+        double *dst = pp.dst[s] + off;
+        if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+            for (long i = 2L * threadIdx.x; i + 1 < cnt; i += 2L * VB)
+                *reinterpret_cast<double2 *>(dst + i) = *reinterpret_cast<const double2 *>(src + i);
+            if ((cnt & 1) && threadIdx.x == 0 && cnt > 0) dst[cnt - 1] = src[cnt - 1];
+        } else {
+            for (long i = threadIdx.x; i < cnt; i += VB) dst[i] = src[i];
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_RELEASE);    // system scope: write back and wait for this lane's stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(pp.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (unsigned)pp.nblocks - 1u) {
+            __hip_atomic_store(pp.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int f = 0; f < pp.nflag; f++)
+                __hip_atomic_store(pp.flag[f], pp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// Every block of the consuming kernel: wait until all neighbours have raised their flag to this
+// call's number (they only grow), then drop whatever this XCD's caches hold of the receive buffer.
+__device__ __forceinline__ bool wait_flags(const WaitPlan &wp)
+{
+    __shared__ int wbad;
+    if (threadIdx.x == 0) wbad = *wp.fail;
+    __syncthreads();
+    if (wbad) return false;
+    if ((int)threadIdx.x < wp.n) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(wp.flag[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < wp.seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > wp.timeout_ticks) { wbad = 1; *wp.fail = 1; break; }
+        }
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);    // system scope
+    return wbad == 0;
 }
 
 __device__ __forceinline__ void publish(DevState *st)

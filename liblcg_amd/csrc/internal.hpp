@@ -31,6 +31,29 @@ struct XgBox {
     int P = 0, me = 0;
 };
 
+// Direct neighbour exchange (comm.hip, dist mode 2): the rank that OWNS a piece of x writes it into
+// the neighbours' receive buffers over the peer mappings and then raises a flag word there; the
+// neighbour's remote-column product waits for the flags of the call it belongs to.
+constexpr int XG_MAXSEG = 8;        // most neighbours of a rank under this mode
+constexpr int PUSH_CHUNK = 4096;    // doubles one pushing block moves
+struct PushPlan {
+    int nseg = 0, nflag = 0, nblocks = 0;
+    unsigned long long seq = 0;         // number of this A.x call (same on every rank)
+    unsigned int *ticket = nullptr;     // blocks finished so far (the last one raises the flags)
+    const double *src[XG_MAXSEG];
+    double *dst[XG_MAXSEG];             // peer memory
+    long count[XG_MAXSEG];              // doubles
+    int first_block[XG_MAXSEG + 1];
+    unsigned long long *flag[XG_MAXSEG];        // my flag word in each neighbour's flag array
+};
+struct WaitPlan {
+    int n = 0;
+    unsigned long long seq = 0;
+    long long timeout_ticks = 0;
+    int *fail = nullptr;
+    const unsigned long long *flag[XG_MAXSEG];  // the neighbours' flag words in MY flag array
+};
+
 // Mirror of the stop state in host-mapped pinned memory; written by the scalar kernels,
 // polled by the host without touching the stream.
 struct HostStatus {
@@ -138,6 +161,7 @@ struct lcg_hip_csr {
     double *rem_y = nullptr;    // remc . xfull, scattered into y after the local product
     double *xfull = nullptr;    // gather buffer
     void *halo = nullptr;       // neighbour-exchange plan (comm.hip)
+    void *direct = nullptr;     // direct (peer-mapped) exchange state (comm.hip, mode 2)
 };
 
 namespace lcgh {
@@ -145,6 +169,9 @@ namespace lcgh {
 // csr.hip
 int spmv_launch(const CsrPart &P, bool is_complex, int variant, double mean_row, const double *x,
                 double *y, bool accumulate, hipStream_t s, const int *done_flag);
+// the same product with `pp.nblocks` pushing blocks in front of the grid (comm.hip, dist mode 2)
+int spmv_launch_push(const CsrPart &P, bool is_complex, int variant, double mean_row, const double *x, double *y,
+                     hipStream_t s, const int *done_flag, const PushPlan &pp);
 int jacobi_launch(const lcg_hip_csr *A, const double *x, double *z, int n, hipStream_t s);
 int op_part(lcg_hip_csr *A, int layout, int conjugate, const CsrPart **out);
 

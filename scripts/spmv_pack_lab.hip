@@ -254,6 +254,36 @@ __global__ __launch_bounds__(VB) void k_pipe(int n, int CHUNKS, const int *__res
     }
 }
 
+
+// ---- no LDS at all: T lanes per row, each lane takes 4 consecutive entries per round with ONE
+// 16-byte column load and two 16-byte value loads straight from HBM at 4-byte alignment (the
+// hardware allows it), so that occupancy is not bound by a staging buffer.
+struct __attribute__((packed, aligned(4))) u4i { int v[4]; };
+struct __attribute__((packed, aligned(8))) u2d { double v[2]; };
+template <int T>
+__global__ __launch_bounds__(VB) void k_direct(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                               const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y)
+{
+    const int row = (int)(((long)blockIdx.x * VB + threadIdx.x) / T);
+    const int j = threadIdx.x % T;
+    if (row >= n) return;
+    const int rs = rowptr[row], re = rowptr[row + 1];
+    double acc = 0.0;
+    for (int k = rs + 4 * j; k < re; k += 4 * T) {
+        const u4i c = *reinterpret_cast<const u4i *>(col + k);
+        const u2d v0 = *reinterpret_cast<const u2d *>(val + k);
+        const u2d v1 = *reinterpret_cast<const u2d *>(val + k + 2);
+        const int c0 = c.v[0];
+        const int c1 = k + 1 < re ? c.v[1] : c0, c2 = k + 2 < re ? c.v[2] : c0, c3 = k + 3 < re ? c.v[3] : c0;
+        const double a1 = k + 1 < re ? v0.v[1] : 0.0, a2 = k + 2 < re ? v1.v[0] : 0.0, a3 = k + 3 < re ? v1.v[1] : 0.0;
+        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+        acc = fma(v0.v[0], x0, acc); acc = fma(a1, x1, acc); acc = fma(a2, x2, acc); acc = fma(a3, x3, acc);
+    }
+#pragma unroll
+    for (int off = T / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, T);
+    if (j == 0) y[row] = acc;
+}
+
 int main(int argc, char **argv)
 {
     const long n = argc > 1 ? atol(argv[1]) : 10000000;
@@ -298,11 +328,18 @@ int main(int argc, char **argv)
     const double bytes = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
     struct Var { const char *name; int id; std::vector<double> ms; double dev; };
     std::vector<Var> vs = {{"shipped (lcg_hip_spmv)", 0, {}, 0}, {"packed unr4", 1, {}, 0}, {"packed unr8", 2, {}, 0},
-                           {"pipe unr9 1 tile", 9001, {}, 0}, {"pipe unr9 4 tiles", 9004, {}, 0}, {"pipe unr9 16 tiles", 9016, {}, 0},
-                           {"pipe unr9 64 tiles", 9064, {}, 0}, {"pipe unr9 102 tiles", 9102, {}, 0}, {"pipe unr9 128 tiles", 9128, {}, 0},
-                           {"pipe unr8 16 tiles", 8016, {}, 0}, {"pipe unr8 102 tiles", 8102, {}, 0},
-                           {"pipe unr10 16 tiles", 10016, {}, 0}, {"pipe unr10 102 tiles", 10102, {}, 0}};
+                           {"direct T=4", 50004, {}, 0}, {"direct T=8", 50008, {}, 0}, {"direct T=16", 50016, {}, 0}, {"direct T=2", 50002, {}, 0},
+                           {"pipe unr9 1 tile", 9001, {}, 0}, {"pipe unr9 4 tiles", 9004, {}, 0}, {"pipe unr9 16 tiles", 9016, {}, 0}};
     auto run = [&](int id) {
+        if (id >= 50000) {
+            const int T = id - 50000;
+            const int g = (int)(((long)n * T + VB - 1) / VB);
+            if (T == 2) hipLaunchKernelGGL((k_direct<2>), dim3(g), dim3(VB), 0, s, (int)n, rowptr, col, val, x, y);
+            else if (T == 4) hipLaunchKernelGGL((k_direct<4>), dim3(g), dim3(VB), 0, s, (int)n, rowptr, col, val, x, y);
+            else if (T == 8) hipLaunchKernelGGL((k_direct<8>), dim3(g), dim3(VB), 0, s, (int)n, rowptr, col, val, x, y);
+            else hipLaunchKernelGGL((k_direct<16>), dim3(g), dim3(VB), 0, s, (int)n, rowptr, col, val, x, y);
+            return;
+        }
         if (id >= 100) {
             const int unr = id / 1000, ch = id % 1000;
             const int g = (nb + ch - 1) / ch;

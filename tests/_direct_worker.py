@@ -1,0 +1,78 @@
+"""Helper process of tests/test_gpu_direct.py (not collected by pytest): rank RANK of WORLD_SIZE
+processes on GPU 0 running the REAL multi-rank sharded path with no RCCL at all -- sums over the
+peer mailboxes, x over the direct neighbour exchange (dist mode 2).  Every rank owns its row block
+of a generated system, multiplies and solves, and compares its slice with the single-process
+results the parent test computed (REF.npz).
+
+usage: RANK=r WORLD_SIZE=p MASTER_PORT=... python tests/_direct_worker.py REF.npz OUT.json
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main(ref_path, out_path):
+    import torch
+    import torch.distributed as dist
+    from liblcg_amd import _lib, api, partition
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    lib = _lib.load()
+    assert lib.lcg_hip_init(0) == 0
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok, why = partition.init_p2p_from_torch(lib, rounds=16)
+    assert ok, why
+    assert lib.lcg_hip_comm_size() == 1            # no RCCL communicator anywhere in this test
+    ref = np.load(ref_path)
+    res = {"rank": rank}
+
+    for tag in ("band", "scr", "nsym"):
+        n = int(ref[f"{tag}/n"]); band = int(ref[f"{tag}/band"]); sym = bool(ref[f"{tag}/sym"])
+        r0, r1 = partition.shard_range(n, world, rank)
+        A = api.CsrMatrix.generate(n, 16, band, sym, 3, 0.01, r0, r1)
+        A.distribute(n, 2)
+        res[f"{tag}/recv"] = int(lib.lcg_hip_csr_exchange_volume(A.h))
+        x1 = torch.from_numpy(ref[f"{tag}/x1"][r0:r1]).cuda()
+        x2 = torch.from_numpy(ref[f"{tag}/x2"][r0:r1]).cuda()
+        y = torch.empty_like(x1)
+        errs = []
+        # alternate two inputs back to back, no reduction in between: a stale or overtaken receive
+        # buffer (the neighbours run ahead or behind by one call) would show here
+        for it in range(12):
+            xin, want = (x1, ref[f"{tag}/y1"]) if it % 2 == 0 else (x2, ref[f"{tag}/y2"])
+            A.spmv(xin, y)
+            api.synchronize()
+            w = want[r0:r1]
+            errs.append(float(np.abs(y.cpu().numpy() - w).max() / np.abs(w).max()))
+        res[f"{tag}/spmv_err"] = max(errs)
+        b = torch.from_numpy(ref[f"{tag}/b"][r0:r1]).cuda()
+        para = api.lcg_default_parameters(epsilon=1e-10, abs_diff=1)
+        for name, sid in (("cg", api.LCG_CG), ("bicgstab", api.LCG_BICGSTAB), ("cgs", api.LCG_CGS)):
+            if name == "cg" and not sym:
+                continue
+            m = torch.zeros(r1 - r0, dtype=torch.float64, device="cuda")
+            info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, r1 - r0, para, A, sid)
+            xt = ref[f"{tag}/x1"][r0:r1]
+            res[f"{tag}/{name}"] = [int(info.ret), int(info.iterations), float(np.abs(m.cpu().numpy() - xt).max())]
+        if sym:
+            A.build_jacobi()
+            m = torch.zeros(r1 - r0, dtype=torch.float64, device="cuda")
+            info = api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, b, r1 - r0, para, A)
+            res[f"{tag}/pcg"] = [int(info.ret), int(info.iterations), float(np.abs(m.cpu().numpy() - ref[f"{tag}/x1"][r0:r1]).max())]
+        assert lib.lcg_hip_barrier() == 0
+        dist.barrier()
+        A.destroy()
+    dist.barrier()
+    lib.lcg_hip_p2p_disconnect()
+    dist.destroy_process_group()
+    json.dump(res, open(out_path, "w"))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

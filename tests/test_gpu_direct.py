@@ -1,0 +1,89 @@
+"""-m gpu: the sharded path with MORE THAN ONE RANK, on one GPU.
+
+Three processes share GPU 0.  They have no RCCL communicator (RCCL refuses two ranks on one
+device); sums travel over the peer mailboxes (lcg_hip_p2p_*) and x over the direct neighbour
+exchange (lcg_hip_csr_distribute mode 2: owners write into the neighbours' receive buffers through
+HIP IPC mappings, flags order it).  That makes this the one place where the multi-rank logic --
+row split, neighbour plan, lock-step loop, rank-ordered sums -- runs for real before an 8-GPU node
+sees it: every rank's slice of A.x and of the solutions is compared with the single-process run.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _reference(path):
+    from liblcg_amd import api
+    out = {}
+    for tag, n, band, sym in (("band", 60000, 700, True), ("scr", 30011, 0, True), ("nsym", 45000, 1200, False)):
+        A = api.CsrMatrix.generate(n, 16, band, sym, 3, 0.01)
+        x1 = torch.empty(n, dtype=torch.float64, device="cuda")
+        api.gen_xtrue(n, 1, 0, n, x1)
+        x2 = 2.0 * x1 + 1.0
+        y1 = torch.empty_like(x1); y2 = torch.empty_like(x1)
+        A.spmv(x1, y1); A.spmv(x2, y2)
+        api.synchronize()
+        out.update({f"{tag}/n": n, f"{tag}/band": band, f"{tag}/sym": sym, f"{tag}/x1": x1.cpu().numpy(),
+                    f"{tag}/x2": x2.cpu().numpy(), f"{tag}/y1": y1.cpu().numpy(), f"{tag}/y2": y2.cpu().numpy(),
+                    f"{tag}/b": y1.cpu().numpy()})
+        para = api.lcg_default_parameters(epsilon=1e-10, abs_diff=1)
+        for name, sid in (("cg", api.LCG_CG), ("bicgstab", api.LCG_BICGSTAB), ("cgs", api.LCG_CGS)):
+            if name == "cg" and not sym:
+                continue
+            m = torch.zeros(n, dtype=torch.float64, device="cuda")
+            info = api.lcg_solver("lcg_hip_csr_ax", None, m, y1, n, para, A, sid)
+            out[f"{tag}/{name}_its"] = info.iterations
+        A.destroy()
+    np.savez(path, **out)
+    return out
+
+
+def test_three_ranks_on_one_gpu_direct_exchange(tmp_path):
+    ref_path = str(tmp_path / "ref.npz")
+    ref = _reference(ref_path)
+    world = 3
+    procs, outs = [], []
+    for r in range(world):
+        out = str(tmp_path / f"direct_{r}.json")
+        outs.append(out)
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29571",
+                   LCG_HIP_P2P_TIMEOUT_MS="8000")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_direct_worker.py"), ref_path, out],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    logs = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(so[-1500:] + se[-3000:])
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    res = [json.load(open(o)) for o in outs]
+    for r in res:
+        # banded: only the neighbours' band-wide ranges travel; scrambled: everything does
+        assert 0 < r["band/recv"] <= 2 * 700 and r["scr/recv"] > 15000, r
+        for tag in ("band", "scr", "nsym"):
+            assert r[f"{tag}/spmv_err"] < 1e-13, (tag, r)
+            for name in ("cg", "pcg", "bicgstab", "cgs"):
+                key = f"{tag}/{name}"
+                if key not in r:
+                    continue
+                ret, its, err = r[key]
+                assert ret == 0 and err < 1e-5, (key, r[key])     # stop rule: sqrt(g.g)/N <= 1e-10
+                if name in ("cg", "cgs"):       # insensitive recurrences: the count is that of the unsharded run
+                    assert abs(its - int(ref[f"{tag}/{name}_its"])) <= 3, (key, its, int(ref[f"{tag}/{name}_its"]))
+    # lock-step: every rank reports the same counts
+    for key in res[0]:
+        if "/" in key and isinstance(res[0][key], list):
+            assert len({tuple(r[key][:2]) for r in res}) == 1, key
