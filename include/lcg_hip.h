@@ -282,6 +282,10 @@ int lcg_hip_p2p_disconnect(void);
  * (lcg_hip_csr_xfull) itself and then calls lcg_hip_spmv. */
 int lcg_hip_csr_split_for_test(lcg_hip_csr_t A, int64_t n_global, int nranks, int rank);
 double *lcg_hip_csr_xfull(lcg_hip_csr_t A);
+/* After split_for_test and after filling the gather buffer: run the direct exchange (mode 2) with
+ * this rank standing in for its neighbours -- the real kernel chain (pushing blocks in the A.x grid,
+ * flags, waiting remote-column product) on one GPU, with the true product as result. */
+int lcg_hip_csr_direct_selfloop_for_test(lcg_hip_csr_t A, int nranks, int rank);
 int64_t lcg_hip_csr_local_nnz(lcg_hip_csr_t A);
 int lcg_hip_csr_need_ranges_for_test(lcg_hip_csr_t A, int nranks, int64_t *lohi /* [2*nranks] */);
 

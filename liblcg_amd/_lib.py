@@ -95,6 +95,7 @@ SIGNATURES = {
     "lcg_hip_csr_distribute": (C.c_int, [vp, C.c_int64, C.c_int]),
     "lcg_hip_allreduce_sum": (C.c_int, [vp, C.c_int]),
     "lcg_hip_barrier": (C.c_int, []),
+    "lcg_hip_csr_direct_selfloop_for_test": (C.c_int, [vp, C.c_int, C.c_int]),
     "lcg_hip_p2p_export": (C.c_int, [vp]),
     "lcg_hip_p2p_connect": (C.c_int, [C.c_int, C.c_int, vp]),
     "lcg_hip_p2p_selftest": (C.c_int, [C.c_int]),

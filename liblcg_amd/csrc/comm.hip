@@ -381,9 +381,12 @@ static int halo_exchange(lcg_hip_csr *A, const double *x, hipStream_t s)
 // and no second stream: the OWNER writes its range of x into the neighbours' receive buffers
 // (pushing blocks ride in front of the local product's grid: csr.hip) and raises its flag word
 // there; the remote-column product of a neighbour waits for the flags of the same call.
-//   recv   : [2][P*rpr] doubles (x w), ordinary device memory, addressed by GLOBAL column; the two
-//            halves alternate per call -- a neighbour can be one call ahead, never two, because its
-//            next push needs my flag of this call first (neighbourhood is made symmetric for that)
+//   recv   : landing zone, [2][P*rpr] doubles (x w) of UNCACHED device memory addressed by GLOBAL
+//            column: it is written by peers over the fabric and read once, by this GPU, with coalesced
+//            loads (k_recv) into the ordinary gather buffer xfull that the remote-column product reads
+//            -- the same split RCCL makes (uncached transport buffer, local copy out).  The two halves
+//            alternate per call: a neighbour can be one call ahead, never two, because its next push
+//            needs my flag of this call first (the neighbourhood is made symmetric for that).
 //   flags  : [XG_MAXP] 64-bit words by source rank, uncached memory (polled while peers write)
 struct Direct {
     double *recv = nullptr;
@@ -398,35 +401,76 @@ struct Direct {
     long long give_lo[XG_MAXSEG], give_hi[XG_MAXSEG];   // global rows of mine the neighbour reads (may be empty)
     std::vector<void *> opened;
     long long recv_total = 0;
+    long long need_lo[XG_MAXSEG], need_hi[XG_MAXSEG];   // global columns I read from the neighbour (may be empty)
     PushPlan push;      // src/dst/seq filled per call
+    PushPlan copy;      // landing zone -> xfull (same shape: segments in chunks of PUSH_CHUNK)
     WaitPlan wait;
 };
 
 __global__ __launch_bounds__(VB) void k_push(PushPlan pp) { push_block(pp, blockIdx.x); }
 
-// Remote-column product of the rows that have remote columns: waits for the neighbours' flags, then
-// y[rows[j]] += sum_k val[k] * xrecv[col[k]], 4 lanes per row (this part is a few % of the shard).
-template <class V>
-__global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                               const V *__restrict__ val, const int *__restrict__ rows,
-                                               const V *__restrict__ xrecv, V *__restrict__ y, WaitPlan wp, DevState *st,
-                                               const int *done)
+// Wait for the neighbours' flags of this call, then move what they wrote from the landing zone into
+// the gather buffer (block b moves chunk b; 8-byte system-scope loads, coalesced).
+__global__ __launch_bounds__(VB) void k_recv(WaitPlan wp, PushPlan cp, DevState *st)
 {
     if (!wait_flags(wp)) {
         if (st && blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->status = ST_COMM; }
         return;
     }
+    if (cp.nseg == 0) return;
+    const int b = blockIdx.x;
+    int s = 0;
+    while (s + 1 < cp.nseg && b >= cp.first_block[s + 1]) s++;
+    const long off = (long)(b - cp.first_block[s]) * PUSH_CHUNK;
+    const long cnt = min((long)PUSH_CHUNK, cp.count[s] - off);
+    double *src = const_cast<double *>(cp.src[s]) + off;
+    double *dst = cp.dst[s] + off;
+    constexpr int PER = PUSH_CHUNK / VB;
+    double v[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const long i = threadIdx.x + (long)q * VB;
+        v[q] = __hip_atomic_load(src + (i < cnt ? i : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const long i = threadIdx.x + (long)q * VB;
+        if (i < cnt) dst[i] = v[q];
+    }
+}
+
+// Remote-column product of the rows that have remote columns (a few % of the shard):
+// y[rows[j]] += sum_k val[k] * xfull[col[k]], 4 lanes per row.
+template <class V>
+__global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                               const V *__restrict__ val, const int *__restrict__ rows,
+                                               const V *__restrict__ xfull, V *__restrict__ y, const int *done)
+{
     if (done && *done) return;
     constexpr int T = 4;
     const long gt = (long)blockIdx.x * VB + threadIdx.x;
     const long j = gt / T;
     const int lane = (int)(gt % T);
-    V acc = vzero(V());
-    if (j < nr)
-        for (int k = rowptr[j] + lane; k < rowptr[j + 1]; k += T) acc = mac(val[k], xrecv[col[k]], acc);
+    V acc = vzero(V()), yold = vzero(V());
+    int i = 0;
+    if (j < nr) {
+        // the kernel is a chain of dependent loads, not bandwidth: fetch the target row and its current
+        // y beside the row bounds and the entries instead of behind the sum
+        const int b = rowptr[j], e = rowptr[j + 1];
+        i = rows[j];
+        int k = b + lane;
+        if (lane == 0) yold = y[i];
+        for (; k + T < e; k += 2 * T) {         // two gathers in flight per lane
+            const int c0 = col[k], c1 = col[k + T];
+            const V a0 = val[k], a1 = val[k + T];
+            const V x0 = xfull[c0], x1 = xfull[c1];
+            acc = mac(a0, x0, acc); acc = mac(a1, x1, acc);
+        }
+        if (k < e) acc = mac(val[k], xfull[col[k]], acc);
+    }
 #pragma unroll
     for (int off = T / 2; off > 0; off >>= 1) acc = vadd(acc, shfl_down_v(acc, off, T));
-    if (j < nr && lane == 0) { const int i = rows[j]; y[i] = vadd(y[i], acc); }
+    if (j < nr && lane == 0) y[i] = vadd(yold, acc);
 }
 
 static void direct_free(lcg_hip_csr *A)
@@ -440,6 +484,26 @@ static void direct_free(lcg_hip_csr *A)
     if (D->ticket) (void)hipFree(D->ticket);
     delete D;
     A->direct = nullptr;
+}
+
+// landing zone -> xfull: one segment per neighbour I take from (dst fixed, src depends on the parity)
+static void direct_copy_plan(lcg_hip_csr *A, Direct *D)
+{
+    const size_t w = A->is_complex ? 2 : 1;
+    PushPlan &cp = D->copy;
+    cp = PushPlan();
+    int nb = 0;
+    for (int s = 0; s < D->nnb; s++) {
+        const long long cnt = (D->need_hi[s] - D->need_lo[s]) * (long long)w;
+        if (cnt <= 0) continue;
+        cp.count[cp.nseg] = (long)cnt;
+        cp.dst[cp.nseg] = A->xfull + w * (size_t)D->need_lo[s];
+        cp.first_block[cp.nseg] = nb;
+        nb += (int)((cnt + PUSH_CHUNK - 1) / PUSH_CHUNK);
+        cp.nseg++;
+    }
+    cp.first_block[cp.nseg] = nb;
+    cp.nblocks = nb > 0 ? nb : 1;
 }
 
 // Collective over the mailboxes.  Every rank takes the same decision at every step (xg_agree), so
@@ -476,6 +540,7 @@ static int direct_setup(lcg_hip_csr *A)
             const int s = D->nnb;
             D->nb_rank[s] = q;
             D->give_lo[s] = give ? T(q, me, 0) : 0; D->give_hi[s] = give ? T(q, me, 1) : 0;
+            D->need_lo[s] = take ? need[2 * q] : 0; D->need_hi[s] = take ? need[2 * q + 1] : 0;
             if (take) D->recv_total += need[2 * q + 1] - need[2 * q];
         }
         D->nnb++;
@@ -486,7 +551,13 @@ static int direct_setup(lcg_hip_csr *A)
     if (!all) return give_up(LCG_HIP_E_COMM, "direct exchange: a rank has more than 8 neighbours (use mode 1 or 0)");
     // 3. buffers and their IPC handles
     D->half = (size_t)A->rows_per_rank * P * w;
-    hipError_t e = hipMalloc(&D->recv, sizeof(double) * 2 * D->half);
+    hipError_t e;
+    {
+        void *p = nullptr;
+        e = hipExtMallocWithFlags(&p, sizeof(double) * 2 * D->half, hipDeviceMallocUncached);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, sizeof(double) * 2 * D->half, hipDeviceMallocFinegrained); }
+        D->recv = static_cast<double *>(p);
+    }
     if (e == hipSuccess) e = hipMemsetAsync(D->recv, 0, sizeof(double) * 2 * D->half, c.stream);
     if (e == hipSuccess) {
         void *p = nullptr;
@@ -545,26 +616,28 @@ static int direct_setup(lcg_hip_csr *A)
     pp.nblocks = nb > 0 ? nb : (pp.nflag > 0 ? 1 : 0);     // flags go out even when no data does
     D->wait.timeout_ticks = xb.timeout_ticks;
     D->wait.fail = xb.fail;
+    direct_copy_plan(A, D);
     return 0;
 }
 
 // per call: the pushing plan with this call's number and parity
-static void direct_plans(lcg_hip_csr *A, const double *x, PushPlan *pp, WaitPlan *wp, const double **xrecv)
+static void direct_plans(lcg_hip_csr *A, const double *x, PushPlan *pp, WaitPlan *wp, PushPlan *cp)
 {
     Direct *D = static_cast<Direct *>(A->direct);
     const size_t w = A->is_complex ? 2 : 1;
     const unsigned long long k = ++D->calls;
     const size_t par = (size_t)(k & 1);
-    *pp = D->push; *wp = D->wait;
+    *pp = D->push; *wp = D->wait; *cp = D->copy;
     pp->seq = k; wp->seq = k;
-    int seg = 0;
+    int seg = 0, cseg = 0;
     for (int s = 0; s < D->nnb; s++) {
-        if (D->give_hi[s] <= D->give_lo[s]) continue;
-        pp->src[seg] = x + w * (size_t)(D->give_lo[s] - A->row0);
-        pp->dst[seg] = D->nb_recv[s] + par * D->half + w * (size_t)D->give_lo[s];
-        seg++;
+        if (D->give_hi[s] > D->give_lo[s]) {
+            pp->src[seg] = x + w * (size_t)(D->give_lo[s] - A->row0);
+            pp->dst[seg] = D->nb_recv[s] + par * D->half + w * (size_t)D->give_lo[s];
+            seg++;
+        }
+        if (D->need_hi[s] > D->need_lo[s]) cp->src[cseg++] = D->recv + par * D->half + w * (size_t)D->need_lo[s];
     }
-    *xrecv = D->recv + par * D->half;
 }
 
 void dist_free(lcg_hip_csr *A)
@@ -657,22 +730,25 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
     const int *done = c.in_solve ? &c.state->done : nullptr;
     if (A->dist_mode == 2 && A->direct) {
         // one stream, no collective: [push blocks + local product] | [wait for flags + remote product]
-        PushPlan pp; WaitPlan wp; const double *xrecv = nullptr;
-        direct_plans(A, x, &pp, &wp, &xrecv);
+        PushPlan pp, cp; WaitPlan wp;
+        direct_plans(A, x, &pp, &wp, &cp);
         const double mean_l = A->n_rows ? (double)A->loc.nnz / A->n_rows : 0.0;
         int rc = spmv_launch_push(A->loc, A->is_complex, A->variant, mean_l, x, y, c.stream, done, pp);
         if (rc) return rc;
-        if (A->remc.n_rows > 0 || wp.n > 0) {
+        if (wp.n > 0) {     // flags are awaited even after a stop: the neighbours' calls stay paired with mine
+            hipLaunchKernelGGL(k_recv, dim3((unsigned)cp.nblocks), dim3(VB), 0, c.stream, wp, cp, c.in_solve ? c.state : nullptr);
+            HIPCHK(hipGetLastError());
+        }
+        if (A->remc.n_rows > 0) {
             const int nr = A->remc.n_rows;
-            const unsigned g = (unsigned)std::max<long>(1, ((long)nr * 4 + VB - 1) / VB);
-            DevState *st = c.in_solve ? c.state : nullptr;
+            const unsigned g = (unsigned)(((long)nr * 4 + VB - 1) / VB);
             if (A->is_complex)
                 hipLaunchKernelGGL((k_remote<double2>), dim3(g), dim3(VB), 0, c.stream, nr, A->remc.rowptr, A->remc.col,
                                    reinterpret_cast<const double2 *>(A->remc.val), A->rem_rows,
-                                   reinterpret_cast<const double2 *>(xrecv), reinterpret_cast<double2 *>(y), wp, st, done);
+                                   reinterpret_cast<const double2 *>(A->xfull), reinterpret_cast<double2 *>(y), done);
             else
                 hipLaunchKernelGGL((k_remote<double>), dim3(g), dim3(VB), 0, c.stream, nr, A->remc.rowptr, A->remc.col,
-                                   A->remc.val, A->rem_rows, xrecv, y, wp, st, done);
+                                   A->remc.val, A->rem_rows, A->xfull, y, done);
             HIPCHK(hipGetLastError());
         }
         return 0;
@@ -804,6 +880,68 @@ int lcg_hip_csr_split_for_test(lcg_hip_csr_t A, int64_t n_global, int nranks, in
 {
     if (!A) return LCG_HIP_E_ARG;
     return dist_split(A, n_global, nranks, rank);
+}
+
+// Test/measurement hook (one GPU, no peers): the direct exchange with every neighbour replaced by
+// this rank itself.  The pushing blocks write mirror-sized ranges of x into the rank's OWN receive
+// buffer (at its own rows' offsets, which the remote-column product never reads) and raise the
+// flags the product then waits for; both halves of the buffer are pre-filled from the gather
+// buffer (lcg_hip_csr_xfull), so the product is the true one and the kernel chain is the real one.
+int lcg_hip_csr_direct_selfloop_for_test(lcg_hip_csr_t A, int nranks, int rank)
+{
+    if (!A || !A->distributed) return LCG_HIP_E_ARG;
+    Ctx &c = ctx();
+    direct_free(A);
+    std::vector<long long> need;
+    int rc = need_ranges(A, nranks, need);
+    if (rc) return rc;
+    Direct *D = new Direct();
+    A->direct = D;
+    const size_t w = A->is_complex ? 2 : 1;
+    D->half = (size_t)A->rows_per_rank * nranks * w;
+    {
+        void *pr = nullptr;
+        HIPCHK(hipExtMallocWithFlags(&pr, sizeof(double) * 2 * D->half, hipDeviceMallocUncached));
+        D->recv = static_cast<double *>(pr);
+    }
+    HIPCHK(hipMemcpyAsync(D->recv, A->xfull, sizeof(double) * D->half, hipMemcpyDeviceToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(D->recv + D->half, A->xfull, sizeof(double) * D->half, hipMemcpyDeviceToDevice, c.stream));
+    void *p = nullptr;
+    HIPCHK(hipExtMallocWithFlags(&p, sizeof(unsigned long long) * XG_MAXP, hipDeviceMallocUncached));
+    D->flags = static_cast<unsigned long long *>(p);
+    HIPCHK(hipMemsetAsync(D->flags, 0, sizeof(unsigned long long) * XG_MAXP, c.stream));
+    HIPCHK(hipMalloc(&D->ticket, sizeof(unsigned int)));
+    HIPCHK(hipMemsetAsync(D->ticket, 0, sizeof(unsigned int), c.stream));
+    static int fail_flag_host = 0;
+    static int *fail_dev = nullptr;
+    if (!fail_dev) { HIPCHK(hipMalloc(&fail_dev, sizeof(int))); HIPCHK(hipMemcpy(fail_dev, &fail_flag_host, sizeof(int), hipMemcpyHostToDevice)); }
+    PushPlan &pp = D->push;
+    pp.ticket = D->ticket;
+    int nb = 0;
+    for (int q = 0; q < nranks && D->nnb < XG_MAXSEG; q++) {
+        if (q == rank || need[2 * q + 1] <= need[2 * q]) continue;
+        const int sidx = D->nnb++;
+        const long long cnt = std::min<long long>(need[2 * q + 1] - need[2 * q], A->n_rows);
+        D->nb_rank[sidx] = q; D->nb_recv[sidx] = D->recv; D->nb_flags[sidx] = D->flags;
+        D->give_lo[sidx] = q < rank ? A->row0 : A->row0 + A->n_rows - cnt;
+        D->give_hi[sidx] = D->give_lo[sidx] + cnt;
+        D->need_lo[sidx] = need[2 * q]; D->need_hi[sidx] = need[2 * q + 1];
+        D->recv_total += cnt;
+        pp.flag[pp.nflag++] = D->flags + q;             // "my word at the neighbour" = the word I wait on
+        D->wait.flag[D->wait.n++] = D->flags + q;
+        pp.count[pp.nseg] = (long)(cnt * (long long)w);
+        pp.first_block[pp.nseg] = nb;
+        nb += (int)((cnt * (long long)w + PUSH_CHUNK - 1) / PUSH_CHUNK);
+        pp.nseg++;
+    }
+    pp.first_block[pp.nseg] = nb;
+    pp.nblocks = nb > 0 ? nb : (pp.nflag > 0 ? 1 : 0);
+    D->wait.timeout_ticks = 200000000LL;
+    D->wait.fail = fail_dev;
+    direct_copy_plan(A, D);
+    HIPCHK(hipStreamSynchronize(c.stream));
+    A->dist_mode = 2;
+    return 0;
 }
 double *lcg_hip_csr_xfull(lcg_hip_csr_t A) { return A ? A->xfull : nullptr; }
 int64_t lcg_hip_csr_local_nnz(lcg_hip_csr_t A) { return A ? A->loc.nnz : 0; }

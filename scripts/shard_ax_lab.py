@@ -60,6 +60,16 @@ def main():
     print(f"unsplit shard, full x      : {t_whole:8.1f} us  ({bytes_ / t_whole / 1e3:7.0f} GB/s algorithmic)")
     print(f"local + copy + remote parts: {t_split:8.1f} us  max rel diff {err:.2e}")
     assert err < 1e-13
+    # the direct exchange with this rank standing in for its neighbours: pushing blocks in the local
+    # product's grid, flags, waiting remote-column product -- one stream, two kernels
+    rc = lib.lcg_hip_csr_direct_selfloop_for_test(A.h, a.ranks, a.rank)
+    assert rc == 0, lib.lcg_hip_last_error()
+    y3 = torch.empty_like(y1)
+    t_direct = timed(lambda: A.spmv(xl, y3))
+    err3 = (y1 - y3).abs().max().item() / y1.abs().max().item()
+    print(f"direct (self-loop)         : {t_direct:8.1f} us  max rel diff {err3:.2e}  "
+          f"({lib.lcg_hip_csr_exchange_volume(A.h)} doubles pushed per call)")
+    assert err3 < 1e-13
 
 
 if __name__ == "__main__":
