@@ -148,6 +148,13 @@ def main():
                 if not anybody(failed):
                     timings[mode] = ax_time()
             A.distribute(n, 0)
+        if p2p and anybody(lib.lcg_hip_p2p_status() < 0):
+            # an exchange over the peer mappings timed out somewhere: RCCL takes over everything
+            p2p = False
+            lib.lcg_hip_p2p_enable(0)
+            timings.pop(2, None)
+            if rank == 0:
+                print("[bench] direct paths switched off: an exchange timed out", file=sys.stderr)
         # the fastest validated exchange on THIS node (same decision everywhere: the timings are all-reduced)
         best = min(timings, key=lambda k: timings[k]) if want > 0 else 0
         if "LCG_HIP_DIST_MODE" in os.environ and want in timings:

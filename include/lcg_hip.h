@@ -267,7 +267,8 @@ int lcg_hip_barrier(void);
  *   lcg_hip_p2p_selftest `rounds` all-reduces of known values with a short timeout; 0 = all correct
  *   lcg_hip_p2p_enable   route the solvers' sync points (and lcg_hip_allreduce_sum) through it;
  *                        the caller makes sure all ranks pass the same value
- *   lcg_hip_p2p_status   0 = not connected, 1 = connected, 2 = enabled
+ *   lcg_hip_p2p_status   0 = not connected, 1 = connected, 2 = enabled, -1 = an exchange timed out
+ *                        (synchronises the stream; the path must not be used any more)
  * A contribution that does not arrive within the timeout (default 20 s, LCG_HIP_P2P_TIMEOUT_MS)
  * ends the solve on every rank with LCG_HIP_E_COMM instead of hanging. */
 #define LCG_HIP_P2P_HANDLE_BYTES 64

@@ -1078,7 +1078,18 @@ int lcg_hip_p2p_enable(int on)
     return 0;
 }
 
-int lcg_hip_p2p_status(void) { return g_xg.enabled ? 2 : (g_xg.connected ? 1 : 0); }
+int lcg_hip_p2p_status(void)
+{
+    if (!g_xg.connected) return 0;
+    // a timed-out exchange (mailbox or neighbour flags) leaves the failure flag up: the path is dead
+    int f = 0;
+    if (g_xg.fail && ctx().inited) {
+        if (hipMemcpyAsync(&f, g_xg.fail, sizeof f, hipMemcpyDeviceToHost, ctx().stream) != hipSuccess ||
+            hipStreamSynchronize(ctx().stream) != hipSuccess) { (void)hipGetLastError(); f = 1; }
+    }
+    if (f) return -1;
+    return g_xg.enabled ? 2 : 1;
+}
 
 int lcg_hip_barrier(void)
 {
