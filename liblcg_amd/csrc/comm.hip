@@ -440,31 +440,40 @@ __global__ __launch_bounds__(VB) void k_recv(WaitPlan wp, PushPlan cp, DevState 
 }
 
 // Remote-column product of the rows that have remote columns (a few % of the shard):
-// y[rows[j]] += sum_k val[k] * xfull[col[k]], 4 lanes per row.
-template <class V>
+// y[rows[j]] += sum_k val[k] * xfull[col[k]], T lanes per row.  The kernel is a chain of dependent
+// loads over many short rows, not bandwidth: the target row and its current y are fetched beside the
+// row bounds, and a lane keeps four entries in flight.
+template <class V, int T>
 __global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                const V *__restrict__ val, const int *__restrict__ rows,
                                                const V *__restrict__ xfull, V *__restrict__ y, const int *done)
 {
     if (done && *done) return;
-    constexpr int T = 4;
     const long gt = (long)blockIdx.x * VB + threadIdx.x;
     const long j = gt / T;
     const int lane = (int)(gt % T);
     V acc = vzero(V()), yold = vzero(V());
     int i = 0;
     if (j < nr) {
-        // the kernel is a chain of dependent loads, not bandwidth: fetch the target row and its current
-        // y beside the row bounds and the entries instead of behind the sum
         const int b = rowptr[j], e = rowptr[j + 1];
         i = rows[j];
         int k = b + lane;
         if (lane == 0) yold = y[i];
-        for (; k + T < e; k += 2 * T) {         // two gathers in flight per lane
+        for (; k + 3 * T < e; k += 4 * T) {
+            int c[4]; V a[4], xv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { c[q] = col[k + q * T]; a[q] = val[k + q * T]; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) xv[q] = xfull[c[q]];
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc = mac(a[q], xv[q], acc);
+        }
+        if (k + T < e) {
             const int c0 = col[k], c1 = col[k + T];
             const V a0 = val[k], a1 = val[k + T];
             const V x0 = xfull[c0], x1 = xfull[c1];
             acc = mac(a0, x0, acc); acc = mac(a1, x1, acc);
+            k += 2 * T;
         }
         if (k < e) acc = mac(val[k], xfull[col[k]], acc);
     }
@@ -741,14 +750,25 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
         }
         if (A->remc.n_rows > 0) {
             const int nr = A->remc.n_rows;
-            const unsigned g = (unsigned)(((long)nr * 4 + VB - 1) / VB);
-            if (A->is_complex)
-                hipLaunchKernelGGL((k_remote<double2>), dim3(g), dim3(VB), 0, c.stream, nr, A->remc.rowptr, A->remc.col,
-                                   reinterpret_cast<const double2 *>(A->remc.val), A->rem_rows,
-                                   reinterpret_cast<const double2 *>(A->xfull), reinterpret_cast<double2 *>(y), done);
-            else
-                hipLaunchKernelGGL((k_remote<double>), dim3(g), dim3(VB), 0, c.stream, nr, A->remc.rowptr, A->remc.col,
-                                   A->remc.val, A->rem_rows, A->xfull, y, done);
+            const double mean_r = (double)A->remc.nnz / nr;
+            int T = mean_r <= 8.0 ? 1 : (mean_r <= 24.0 ? 2 : 4);
+            if (const char *e = std::getenv("LCG_HIP_REMOTE_T")) T = atoi(e);
+#define REMOTE_CASE(TT)                                                                                              \
+    case TT: {                                                                                                       \
+        const unsigned g = (unsigned)(((long)nr * TT + VB - 1) / VB);                                                \
+        if (A->is_complex)                                                                                           \
+            hipLaunchKernelGGL((k_remote<double2, TT>), dim3(g), dim3(VB), 0, c.stream, nr, A->remc.rowptr, A->remc.col, \
+                               reinterpret_cast<const double2 *>(A->remc.val), A->rem_rows,                          \
+                               reinterpret_cast<const double2 *>(A->xfull), reinterpret_cast<double2 *>(y), done);   \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_remote<double, TT>), dim3(g), dim3(VB), 0, c.stream, nr, A->remc.rowptr, A->remc.col, \
+                               A->remc.val, A->rem_rows, A->xfull, y, done);                                         \
+    } break;
+            switch (T) {
+                REMOTE_CASE(1) REMOTE_CASE(2) REMOTE_CASE(4)
+            default: return fail(hipErrorInvalidValue, "bad lanes-per-row for the remote-column product", __FILE__, __LINE__);
+            }
+#undef REMOTE_CASE
             HIPCHK(hipGetLastError());
         }
         return 0;
