@@ -443,7 +443,9 @@ __global__ __launch_bounds__(VB) void k_recv(WaitPlan wp, PushPlan cp, DevState 
 // y[rows[j]] += sum_k val[k] * xfull[col[k]], T lanes per row.  The kernel is a chain of dependent
 // loads over many short rows, not bandwidth: the target row and its current y are fetched beside the
 // row bounds, and a lane keeps four entries in flight.
-template <class V, int T>
+// TOY: add into y (single-stream form) or store the compact sums out[j] (two-stream form: the sums are
+// computed beside the local product and added by k_scatter_add once both are done).
+template <class V, int T, bool TOY>
 __global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                const V *__restrict__ val, const int *__restrict__ rows,
                                                const V *__restrict__ xfull, V *__restrict__ y, const int *done)
@@ -456,9 +458,8 @@ __global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ r
     int i = 0;
     if (j < nr) {
         const int b = rowptr[j], e = rowptr[j + 1];
-        i = rows[j];
         int k = b + lane;
-        if (lane == 0) yold = y[i];
+        if (TOY) { i = rows[j]; if (lane == 0) yold = y[i]; }
         for (; k + 3 * T < e; k += 4 * T) {
             int c[4]; V a[4], xv[4];
 #pragma unroll
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ r
     }
 #pragma unroll
     for (int off = T / 2; off > 0; off >>= 1) acc = vadd(acc, shfl_down_v(acc, off, T));
-    if (j < nr && lane == 0) y[i] = vadd(yold, acc);
+    if (j < nr && lane == 0) { if (TOY) y[i] = vadd(yold, acc); else y[j] = acc; }
 }
 
 static void direct_free(lcg_hip_csr *A)
@@ -711,7 +712,7 @@ int dist_split(lcg_hip_csr *A, int64_t n_global, int nranks, int rank)
         if (!rc) {
             hipError_t e = hipMalloc(&A->remc.rowptr, sizeof(int) * ((size_t)kept + 1));
             if (e == hipSuccess) e = hipMalloc(&A->rem_rows, sizeof(int) * (size_t)kept);
-            if (e == hipSuccess) e = hipMalloc(&A->rem_y, sizeof(double) * (A->is_complex ? 2 : 1) * (size_t)kept);
+            if (e == hipSuccess) e = hipMalloc(&A->rem_y, sizeof(double) * (A->is_complex ? 2 : 1) * 2 * (size_t)kept);     // x2: the direct mode alternates halves
             if (e != hipSuccess) rc = fail(e, "remote-row compaction", __FILE__, __LINE__);
         }
         if (!rc) {
@@ -744,32 +745,60 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
         const double mean_l = A->n_rows ? (double)A->loc.nnz / A->n_rows : 0.0;
         int rc = spmv_launch_push(A->loc, A->is_complex, A->variant, mean_l, x, y, c.stream, done, pp);
         if (rc) return rc;
+        // One stream by default: product (+ pushing blocks) | k_recv | k_remote, no event at all.
+        // LCG_HIP_DIRECT_STREAMS=2 puts the receiving kernels on the second stream -- enqueued AFTER the
+        // pushing product (so that, even if both streams shared a hardware queue, my push is never behind
+        // my wait) and without a fork event (they depend on the neighbours' flags, not on this stream);
+        // their sums land in the half of rem_y that belongs to this call and are added to y behind one
+        // join event.  Measured equal on the 8-way shard (114.2 vs 114.6 us): the join costs what it hides.
+        static const bool one_stream = [] { const char *e = std::getenv("LCG_HIP_DIRECT_STREAMS"); return !(e && atoi(e) == 2); }();
+        hipStream_t rs = one_stream ? c.stream : c.comm_stream;
+        Direct *D = static_cast<Direct *>(A->direct);
         if (wp.n > 0) {     // flags are awaited even after a stop: the neighbours' calls stay paired with mine
-            hipLaunchKernelGGL(k_recv, dim3((unsigned)cp.nblocks), dim3(VB), 0, c.stream, wp, cp, c.in_solve ? c.state : nullptr);
+            hipLaunchKernelGGL(k_recv, dim3((unsigned)cp.nblocks), dim3(VB), 0, rs, wp, cp, c.in_solve ? c.state : nullptr);
             HIPCHK(hipGetLastError());
         }
         if (A->remc.n_rows > 0) {
             const int nr = A->remc.n_rows;
+            const size_t w = A->is_complex ? 2 : 1;
+            double *sums = A->rem_y + (size_t)(D->calls & 1) * w * (size_t)nr;
             const double mean_r = (double)A->remc.nnz / nr;
             int T = mean_r <= 8.0 ? 1 : (mean_r <= 24.0 ? 2 : 4);
             if (const char *e = std::getenv("LCG_HIP_REMOTE_T")) T = atoi(e);
-#define REMOTE_CASE(TT)                                                                                              \
-    case TT: {                                                                                                       \
+#define REMOTE_LAUNCH(TT, TOY, OUT)                                                                                  \
+    do {                                                                                                             \
         const unsigned g = (unsigned)(((long)nr * TT + VB - 1) / VB);                                                \
         if (A->is_complex)                                                                                           \
-            hipLaunchKernelGGL((k_remote<double2, TT>), dim3(g), dim3(VB), 0, c.stream, nr, A->remc.rowptr, A->remc.col, \
+            hipLaunchKernelGGL((k_remote<double2, TT, TOY>), dim3(g), dim3(VB), 0, rs, nr, A->remc.rowptr, A->remc.col, \
                                reinterpret_cast<const double2 *>(A->remc.val), A->rem_rows,                          \
-                               reinterpret_cast<const double2 *>(A->xfull), reinterpret_cast<double2 *>(y), done);   \
+                               reinterpret_cast<const double2 *>(A->xfull), reinterpret_cast<double2 *>(OUT), done); \
         else                                                                                                         \
-            hipLaunchKernelGGL((k_remote<double, TT>), dim3(g), dim3(VB), 0, c.stream, nr, A->remc.rowptr, A->remc.col, \
-                               A->remc.val, A->rem_rows, A->xfull, y, done);                                         \
-    } break;
+            hipLaunchKernelGGL((k_remote<double, TT, TOY>), dim3(g), dim3(VB), 0, rs, nr, A->remc.rowptr, A->remc.col, \
+                               A->remc.val, A->rem_rows, A->xfull, OUT, done);                                       \
+    } while (0)
+#define REMOTE_CASE(TT) case TT: if (one_stream) REMOTE_LAUNCH(TT, true, y); else REMOTE_LAUNCH(TT, false, sums); break;
             switch (T) {
                 REMOTE_CASE(1) REMOTE_CASE(2) REMOTE_CASE(4)
             default: return fail(hipErrorInvalidValue, "bad lanes-per-row for the remote-column product", __FILE__, __LINE__);
             }
 #undef REMOTE_CASE
+#undef REMOTE_LAUNCH
             HIPCHK(hipGetLastError());
+            if (!one_stream) {
+                HIPCHK(hipEventRecord(c.ev_b, rs));
+                HIPCHK(hipStreamWaitEvent(c.stream, c.ev_b, 0));
+                const unsigned g = (unsigned)((nr + VB - 1) / VB);
+                if (A->is_complex)
+                    hipLaunchKernelGGL((k_scatter_add<double2>), dim3(g), dim3(VB), 0, c.stream, nr, A->rem_rows,
+                                       reinterpret_cast<const double2 *>(sums), reinterpret_cast<double2 *>(y), done);
+                else
+                    hipLaunchKernelGGL((k_scatter_add<double>), dim3(g), dim3(VB), 0, c.stream, nr, A->rem_rows, sums, y, done);
+                HIPCHK(hipGetLastError());
+            }
+        } else if (wp.n > 0 && !one_stream) {
+            // flag-only neighbours: the main stream must still not run ahead of the receive
+            HIPCHK(hipEventRecord(c.ev_b, rs));
+            HIPCHK(hipStreamWaitEvent(c.stream, c.ev_b, 0));
         }
         return 0;
     }
