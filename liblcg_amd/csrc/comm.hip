@@ -445,11 +445,24 @@ __global__ __launch_bounds__(VB) void k_recv(WaitPlan wp, PushPlan cp, DevState 
 // row bounds, and a lane keeps four entries in flight.
 // TOY: add into y (single-stream form) or store the compact sums out[j] (two-stream form: the sums are
 // computed beside the local product and added by k_scatter_add once both are done).
-template <class V, int T, bool TOY>
+__device__ __forceinline__ double ld_land(const double *p) { return __hip_atomic_load(const_cast<double *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double2 ld_land(const double2 *p)
+{
+    const double *q = reinterpret_cast<const double *>(p);
+    return make_double2(ld_land(q), ld_land(q + 1));
+}
+// LAND: no k_recv in front -- every block waits for the neighbours' flags itself and gathers x straight
+// from the uncached landing zone with system-scope loads (xfull then IS the landing-zone half of this call).
+template <class V, int T, bool TOY, bool LAND = false>
 __global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                const V *__restrict__ val, const int *__restrict__ rows,
-                                               const V *__restrict__ xfull, V *__restrict__ y, const int *done)
+                                               const V *__restrict__ xfull, V *__restrict__ y, const int *done,
+                                               WaitPlan wp = WaitPlan(), DevState *st = nullptr)
 {
+    if (LAND && !wait_flags(wp)) {
+        if (st && blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->status = ST_COMM; }
+        return;
+    }
     if (done && *done) return;
     const long gt = (long)blockIdx.x * VB + threadIdx.x;
     const long j = gt / T;
@@ -465,18 +478,18 @@ __global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ r
 #pragma unroll
             for (int q = 0; q < 4; q++) { c[q] = col[k + q * T]; a[q] = val[k + q * T]; }
 #pragma unroll
-            for (int q = 0; q < 4; q++) xv[q] = xfull[c[q]];
+            for (int q = 0; q < 4; q++) xv[q] = LAND ? ld_land(xfull + c[q]) : xfull[c[q]];
 #pragma unroll
             for (int q = 0; q < 4; q++) acc = mac(a[q], xv[q], acc);
         }
         if (k + T < e) {
             const int c0 = col[k], c1 = col[k + T];
             const V a0 = val[k], a1 = val[k + T];
-            const V x0 = xfull[c0], x1 = xfull[c1];
+            const V x0 = LAND ? ld_land(xfull + c0) : xfull[c0], x1 = LAND ? ld_land(xfull + c1) : xfull[c1];
             acc = mac(a0, x0, acc); acc = mac(a1, x1, acc);
             k += 2 * T;
         }
-        if (k < e) acc = mac(val[k], xfull[col[k]], acc);
+        if (k < e) { const int c0 = col[k]; acc = mac(val[k], LAND ? ld_land(xfull + c0) : xfull[c0], acc); }
     }
 #pragma unroll
     for (int off = T / 2; off > 0; off >>= 1) acc = vadd(acc, shfl_down_v(acc, off, T));
@@ -754,7 +767,18 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
         static const bool one_stream = [] { const char *e = std::getenv("LCG_HIP_DIRECT_STREAMS"); return !(e && atoi(e) == 2); }();
         hipStream_t rs = one_stream ? c.stream : c.comm_stream;
         Direct *D = static_cast<Direct *>(A->direct);
-        if (wp.n > 0) {     // flags are awaited even after a stop: the neighbours' calls stay paired with mine
+        // The remote-column product can gather straight from the landing zone (every block waits for the
+        // flags itself, system-scope loads): one launch less, 113 -> 109 us per A.x on the 8-way shard.  Used
+        // when the halo is genuinely sparse (for a banded matrix a wave's gather is one contiguous run even
+        // uncached; scattered columns are better served by the cached copy k_recv makes).  LCG_HIP_DIRECT_LAND=0/1 forces.
+        static const int land_env = [] { const char *e = std::getenv("LCG_HIP_DIRECT_LAND"); return e ? atoi(e) : -1; }();
+        const bool sparse_halo = D->recv_total * 4 <= (long long)(A->n_global - A->n_rows);
+        const bool land = (land_env < 0 ? sparse_halo : land_env == 1) && one_stream && A->remc.n_rows > 0;
+        if (std::getenv("LCG_HIP_DEBUG_DIRECT") && D->calls == 1)
+            std::fprintf(stderr, "[lcg_hip] direct: land=%d (env %d, sparse %d, recv %lld, n_global %lld, rows %d) one_stream=%d\n", (int)land,
+                         land_env, (int)sparse_halo, D->recv_total, (long long)A->n_global, A->n_rows, (int)one_stream);
+        const double *landing = D->recv + (size_t)(D->calls & 1) * D->half;
+        if (wp.n > 0 && !land) {    // flags are awaited even after a stop: the neighbours' calls stay paired with mine
             hipLaunchKernelGGL(k_recv, dim3((unsigned)cp.nblocks), dim3(VB), 0, rs, wp, cp, c.in_solve ? c.state : nullptr);
             HIPCHK(hipGetLastError());
         }
@@ -776,12 +800,25 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
             hipLaunchKernelGGL((k_remote<double, TT, TOY>), dim3(g), dim3(VB), 0, rs, nr, A->remc.rowptr, A->remc.col, \
                                A->remc.val, A->rem_rows, A->xfull, OUT, done);                                       \
     } while (0)
-#define REMOTE_CASE(TT) case TT: if (one_stream) REMOTE_LAUNCH(TT, true, y); else REMOTE_LAUNCH(TT, false, sums); break;
+#define REMOTE_LAND(TT)                                                                                              \
+    do {                                                                                                             \
+        const unsigned g = (unsigned)(((long)nr * TT + VB - 1) / VB);                                                \
+        DevState *st = c.in_solve ? c.state : nullptr;                                                               \
+        if (A->is_complex)                                                                                           \
+            hipLaunchKernelGGL((k_remote<double2, TT, true, true>), dim3(g), dim3(VB), 0, rs, nr, A->remc.rowptr, A->remc.col, \
+                               reinterpret_cast<const double2 *>(A->remc.val), A->rem_rows,                          \
+                               reinterpret_cast<const double2 *>(landing), reinterpret_cast<double2 *>(y), done, wp, st); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_remote<double, TT, true, true>), dim3(g), dim3(VB), 0, rs, nr, A->remc.rowptr, A->remc.col, \
+                               A->remc.val, A->rem_rows, landing, y, done, wp, st);                                  \
+    } while (0)
+#define REMOTE_CASE(TT) case TT: if (land) REMOTE_LAND(TT); else if (one_stream) REMOTE_LAUNCH(TT, true, y); else REMOTE_LAUNCH(TT, false, sums); break;
             switch (T) {
                 REMOTE_CASE(1) REMOTE_CASE(2) REMOTE_CASE(4)
             default: return fail(hipErrorInvalidValue, "bad lanes-per-row for the remote-column product", __FILE__, __LINE__);
             }
 #undef REMOTE_CASE
+#undef REMOTE_LAND
 #undef REMOTE_LAUNCH
             HIPCHK(hipGetLastError());
             if (!one_stream) {
