@@ -68,6 +68,30 @@ def main(ref_path, out_path):
         assert lib.lcg_hip_barrier() == 0
         dist.barrier()
         A.destroy()
+    # complex system (bundled case_10K_cA, complex symmetric): row slice with GLOBAL columns, 16-byte
+    # elements through the pushes, the landing zone and the remote-column product
+    from liblcg_amd.coo_io import coo_to_csr_host, read_coo_system
+    nc, row, col, val, bc = read_coo_system(os.path.join(ROOT, "tests", "golden", "case_10K_cA"), True)
+    rp, ci, v = coo_to_csr_host(nc, row, col, val)
+    r0, r1 = partition.shard_range(nc, world, rank)
+    lo, hi = int(rp[r0]), int(rp[r1])
+    Ac = api.CsrMatrix.from_csr((rp[r0:r1 + 1] - rp[r0]).astype(np.int32), ci[lo:hi], v[lo:hi], n_cols=nc)
+    Ac.distribute(nc, 2)
+    xc = torch.from_numpy(ref["cplx/x1"][r0:r1]).cuda()
+    yc = torch.empty_like(xc)
+    Ac.spmv(xc, yc); api.synchronize()
+    w = ref["cplx/y1"][r0:r1]
+    res["cplx/spmv_err"] = float(np.abs(yc.cpu().numpy() - w).max() / np.abs(w).max())
+    bcd = torch.from_numpy(bc[r0:r1]).cuda()
+    cpara = api.clcg_default_parameters(epsilon=1e-10, abs_diff=1)
+    for name, sid in (("bicg_sym", api.CLCG_BICG_SYM), ("tfqmr", api.CLCG_TFQMR)):
+        m = torch.zeros(r1 - r0, dtype=torch.complex128, device="cuda")
+        info = api.clcg_solver("clcg_hip_csr_ax", None, m, bcd, r1 - r0, cpara, Ac, sid, shadow_seed=7)
+        xs = ref["cplx/xsol"][r0:r1]
+        res[f"cplx/{name}"] = [int(info.ret), int(info.iterations), float(np.abs(m.cpu().numpy() - xs).max())]
+    assert lib.lcg_hip_barrier() == 0
+    dist.barrier()
+    Ac.destroy()
     dist.barrier()
     lib.lcg_hip_p2p_disconnect()
     dist.destroy_process_group()
