@@ -767,13 +767,15 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
         static const bool one_stream = [] { const char *e = std::getenv("LCG_HIP_DIRECT_STREAMS"); return !(e && atoi(e) == 2); }();
         hipStream_t rs = one_stream ? c.stream : c.comm_stream;
         Direct *D = static_cast<Direct *>(A->direct);
-        // The remote-column product can gather straight from the landing zone (every block waits for the
-        // flags itself, system-scope loads): one launch less, 113 -> 109 us per A.x on the 8-way shard.  Used
-        // when the halo is genuinely sparse (for a banded matrix a wave's gather is one contiguous run even
-        // uncached; scattered columns are better served by the cached copy k_recv makes).  LCG_HIP_DIRECT_LAND=0/1 forces.
-        static const int land_env = [] { const char *e = std::getenv("LCG_HIP_DIRECT_LAND"); return e ? atoi(e) : -1; }();
+        // LCG_HIP_DIRECT_LAND=1: the remote-column product gathers straight from the landing zone (every block
+        // waits for the flags itself, system-scope loads): one launch less, 113 -> 109 us per A.x on the 8-way
+        // shard.  Opt-in, because every block of that grid then SPINS until the neighbours' data is there:
+        // with one rank per GPU that is harmless, but ranks that share a GPU (the 4-rank stress of
+        // scripts/direct_stress.py) fill every CU slot with spinning blocks and starve the product whose
+        // pushing blocks they wait for.  k_recv spins with a few dozen blocks only.
+        static const int land_env = [] { const char *e = std::getenv("LCG_HIP_DIRECT_LAND"); return e ? atoi(e) : 0; }();
         const bool sparse_halo = D->recv_total * 4 <= (long long)(A->n_global - A->n_rows);
-        const bool land = (land_env < 0 ? sparse_halo : land_env == 1) && one_stream && A->remc.n_rows > 0;
+        const bool land = land_env == 1 && one_stream && A->remc.n_rows > 0;
         if (std::getenv("LCG_HIP_DEBUG_DIRECT") && D->calls == 1)
             std::fprintf(stderr, "[lcg_hip] direct: land=%d (env %d, sparse %d, recv %lld, n_global %lld, rows %d) one_stream=%d\n", (int)land,
                          land_env, (int)sparse_halo, D->recv_total, (long long)A->n_global, A->n_rows, (int)one_stream);

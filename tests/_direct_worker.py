@@ -9,6 +9,7 @@ usage: RANK=r WORLD_SIZE=p MASTER_PORT=... python tests/_direct_worker.py REF.np
 import json
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -32,7 +33,15 @@ def main(ref_path, out_path):
     ref = np.load(ref_path)
     res = {"rank": rank}
 
+    verbose = bool(os.environ.get("LCG_DIRECT_VERBOSE"))
+
+    def say(*a):
+        if verbose:
+            print(f"[rank {rank}]", *a, file=sys.stderr, flush=True)
+
     for tag in ("band", "scr", "nsym"):
+        if f"{tag}/n" not in ref.files:
+            continue
         n = int(ref[f"{tag}/n"]); band = int(ref[f"{tag}/band"]); sym = bool(ref[f"{tag}/sym"])
         r0, r1 = partition.shard_range(n, world, rank)
         A = api.CsrMatrix.generate(n, 16, band, sym, 3, 0.01, r0, r1)
@@ -46,20 +55,26 @@ def main(ref_path, out_path):
         # buffer (the neighbours run ahead or behind by one call) would show here
         for it in range(12):
             xin, want = (x1, ref[f"{tag}/y1"]) if it % 2 == 0 else (x2, ref[f"{tag}/y2"])
+            t0 = time.perf_counter()
             A.spmv(xin, y)
             api.synchronize()
+            if time.perf_counter() - t0 > 0.5:
+                say(tag, f"call {it} took {time.perf_counter() - t0:.2f} s")
             w = want[r0:r1]
             errs.append(float(np.abs(y.cpu().numpy() - w).max() / np.abs(w).max()))
         res[f"{tag}/spmv_err"] = max(errs)
+        say(tag, "products: max err", max(errs), "per call", ["%.1e" % e for e in errs], "p2p status", lib.lcg_hip_p2p_status())
         b = torch.from_numpy(ref[f"{tag}/b"][r0:r1]).cuda()
         para = api.lcg_default_parameters(epsilon=1e-10, abs_diff=1)
         for name, sid in (("cg", api.LCG_CG), ("bicgstab", api.LCG_BICGSTAB), ("cgs", api.LCG_CGS)):
             if name == "cg" and not sym:
                 continue
             m = torch.zeros(r1 - r0, dtype=torch.float64, device="cuda")
+            say(tag, name, "...")
             info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, r1 - r0, para, A, sid)
             xt = ref[f"{tag}/x1"][r0:r1]
             res[f"{tag}/{name}"] = [int(info.ret), int(info.iterations), float(np.abs(m.cpu().numpy() - xt).max())]
+            say(tag, name, res[f"{tag}/{name}"])
         if sym:
             A.build_jacobi()
             m = torch.zeros(r1 - r0, dtype=torch.float64, device="cuda")

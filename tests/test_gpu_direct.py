@@ -21,10 +21,13 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def _reference(path):
+CASES = (("band", 60000, 700, True), ("scr", 30011, 0, True), ("nsym", 45000, 1200, False))
+
+
+def _reference(path, cases=CASES):
     from liblcg_amd import api
     out = {}
-    for tag, n, band, sym in (("band", 60000, 700, True), ("scr", 30011, 0, True), ("nsym", 45000, 1200, False)):
+    for tag, n, band, sym in cases:
         A = api.CsrMatrix.generate(n, 16, band, sym, 3, 0.01)
         x1 = torch.empty(n, dtype=torch.float64, device="cuda")
         api.gen_xtrue(n, 1, 0, n, x1)
