@@ -68,6 +68,7 @@ SIGNATURES = {
     "lcg_hip_csr_nnz": (C.c_int64, [vp]),
     "lcg_hip_csr_arrays": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "lcg_hip_csr_set_kernel": (C.c_int, [vp, C.c_int]),
+    "lcg_hip_csr_set_packed": (C.c_int, [vp, C.c_int]),
     "lcg_hip_csr_build_jacobi": (C.c_int, [vp, vp]),
     "lcg_hip_csr_ax": (None, [vp, vp, vp, C.c_int]),
     "lcg_hip_jacobi_mx": (None, [vp, vp, vp, C.c_int]),

@@ -135,6 +135,11 @@ struct CsrPart {
     bool padded = false;           // >= 64 readable bytes follow col[nnz] and val[nnz]
     mutable int slice_R = 0;       // rows per block the next field was computed for (0 = not yet)
     mutable int max_slice = 0;     // largest block slice, entries (csr.hip: k_max_slice)
+    // packed column indices for the one-window kernel (csr.hip: "packed columns"), built on first use
+    mutable int pk_mode = -1;      // -1 auto (large real matrices), 0 never, 1 whenever eligible
+    mutable int pk_state = 0;      // 0 not tried, 1 ready, -1 not eligible
+    mutable int *pk_base = nullptr, *pk_ofs = nullptr;     // per block of 64 rows: smallest column, first group
+    mutable void *pk_data = nullptr;                        // 16 bytes per group of 6 entries
 };
 
 } // namespace lcgh

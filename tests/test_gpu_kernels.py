@@ -45,6 +45,45 @@ def test_spmv_all_variants_ragged(api, port, cplx):
         assert np.abs(yd.cpu().numpy() - ref).max() <= 1e-12 * scale, var
 
 
+def test_packed_columns_are_bit_identical(api, port):
+    """The packed-column form of the one-window kernel (21-bit block-relative columns) against the plain
+    one on the same matrix: same rows per block, same summation order => identical bits.  Ragged rows
+    (empty rows, a block that is almost one window), generated banded system, and a system whose blocks
+    span more than 2^21 columns (not eligible: the plain kernel must answer)."""
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(21)
+    n = 20000
+    lens = rng.integers(20, 34, n); lens[rng.integers(0, n, n // 15)] = 0; lens[64:128] = 34
+    rp = np.zeros(n + 1, np.int32); np.cumsum(lens, out=rp[1:])
+    col = np.concatenate([np.sort(rng.choice(min(n, 5000) if ln else 1, ln, replace=False)) + rng.integers(0, n - 5000) for ln in lens if ln]).astype(np.int32)
+    val = rng.standard_normal(rp[-1])
+    x = rng.standard_normal(n)
+    ref = port.csr_matvec(rp, col, val, x)
+    A = api.CsrMatrix.from_csr(rp, col, val)
+    xd = torch.from_numpy(x).cuda()
+    y0 = torch.empty_like(xd); y1 = torch.empty_like(xd)
+    A.set_kernel(-64)
+    assert lib.lcg_hip_csr_set_packed(A.h, 0) == 0
+    A.spmv(xd, y0); api.synchronize()
+    assert lib.lcg_hip_csr_set_packed(A.h, 1) == 0
+    A.spmv(xd, y1); api.synchronize()
+    assert torch.equal(y0, y1)
+    assert np.abs(y1.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    # generated banded system, automatic R
+    for band, eligible in ((3000, True), (0, False)):
+        nn = 400000 if band else 3_000_000
+        B = api.CsrMatrix.generate(nn, 16, band, True, 5, 0.01)
+        xb = torch.empty(nn, dtype=torch.float64, device="cuda"); api.gen_xtrue(nn, 3, 0, nn, xb)
+        z0 = torch.empty_like(xb); z1 = torch.empty_like(xb)
+        assert lib.lcg_hip_csr_set_packed(B.h, 0) == 0
+        B.spmv(xb, z0); api.synchronize()
+        assert lib.lcg_hip_csr_set_packed(B.h, 1) == 0
+        B.spmv(xb, z1); B.spmv(xb, z1); api.synchronize()
+        assert torch.equal(z0, z1), band
+        B.destroy()
+
+
 @pytest.mark.parametrize("cplx", [False, True])
 def test_spmv_transpose_and_conjugate(api, port, cplx):
     """op(A).x for the (layout, conjugate) pairs of clcg_axfunc_ptr (clcg.h:40-41): A^T, A^H, conj(A)."""
