@@ -670,6 +670,9 @@ void dist_free(lcg_hip_csr *A)
     if (!A->distributed) return;
     free_part(A->loc); free_part(A->rem);
     if (A->remc.rowptr) hipFree(A->remc.rowptr);
+    if (A->remc.pk_base) hipFree(A->remc.pk_base);      // packed columns, had the compacted part qualified (csr.hip)
+    if (A->remc.pk_ofs) hipFree(A->remc.pk_ofs);
+    if (A->remc.pk_data) hipFree(A->remc.pk_data);
     A->remc = CsrPart();
     if (A->rem_rows) hipFree(A->rem_rows);
     if (A->rem_y) hipFree(A->rem_y);
