@@ -140,6 +140,7 @@ struct CsrPart {
     mutable int pk_state = 0;      // 0 not tried, 1 ready, -1 not eligible
     mutable int *pk_base = nullptr, *pk_ofs = nullptr;     // per block of 64 rows: smallest column, first group
     mutable void *pk_data = nullptr;                        // 16 bytes per group of 6 entries
+    mutable int pk_maxrow = 0;                              // longest row (chooses the gather batch of the kernel)
 };
 
 } // namespace lcgh

@@ -121,6 +121,21 @@ __global__ __launch_bounds__(VB) void k_spmv_p(int n, const int *__restrict__ ro
     __syncthreads();
     double acc = 0.0;
     int k = rs + j0;
+    if (UNR > 8) {      // one predicated batch of UNR slots: no serial tail for rows of up to UNR*T entries
+        int c[UNR]; double a[UNR], xv[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; q++) {
+            const int kk = k + q * T;
+            const bool ok = kk < re;
+            c[q] = scol[ok ? kk - s : 0];
+            a[q] = ok ? sval[kk - bv] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < UNR; q++) xv[q] = x[c[q]];
+#pragma unroll
+        for (int q = 0; q < UNR; q++) acc = fma(a[q], xv[q], acc);
+        k += UNR * T;
+    }
     for (; k + (UNR - 1) * T < re; k += UNR * T) {
         int c[UNR]; double a[UNR], xv[UNR];
 #pragma unroll
@@ -327,9 +342,8 @@ int main(int argc, char **argv)
 
     const double bytes = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
     struct Var { const char *name; int id; std::vector<double> ms; double dev; };
-    std::vector<Var> vs = {{"shipped (lcg_hip_spmv)", 0, {}, 0}, {"packed unr4", 1, {}, 0}, {"packed unr8", 2, {}, 0},
-                           {"direct T=4", 50004, {}, 0}, {"direct T=8", 50008, {}, 0}, {"direct T=16", 50016, {}, 0}, {"direct T=2", 50002, {}, 0},
-                           {"pipe unr9 1 tile", 9001, {}, 0}, {"pipe unr9 4 tiles", 9004, {}, 0}, {"pipe unr9 16 tiles", 9016, {}, 0}};
+    std::vector<Var> vs = {{"shipped (lcg_hip_spmv)", 0, {}, 0}, {"packed unr4", 1, {}, 0}, {"packed unr8", 2, {}, 0}, {"packed pred9", 3, {}, 0}, {"packed pred10", 4, {}, 0},
+                           };
     auto run = [&](int id) {
         if (id >= 50000) {
             const int T = id - 50000;
@@ -350,7 +364,9 @@ int main(int argc, char **argv)
         }
         if (id == 0) lcg_hip_spmv(A, x, y);
         else if (id == 1) hipLaunchKernelGGL((k_spmv_p<R, 4>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
-        else hipLaunchKernelGGL((k_spmv_p<R, 8>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
+        else if (id == 2) hipLaunchKernelGGL((k_spmv_p<R, 8>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
+        else if (id == 3) hipLaunchKernelGGL((k_spmv_p<R, 9>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
+        else hipLaunchKernelGGL((k_spmv_p<R, 10>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
     };
     run(0); CK(hipStreamSynchronize(s));
     std::vector<double> href(n), hy(n);
