@@ -54,6 +54,11 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world > 1:
+        # one rank per GPU here (LOCAL_RANK picks the device): the remote-column product may wait for its
+        # neighbours with every block and gather straight from the landing zone (one launch less per A.x).
+        # Left off by default in the library because ranks SHARING a GPU starve each other that way.
+        os.environ.setdefault("LCG_HIP_DIRECT_LAND", "1")
     torch.cuda.set_device(local_rank)
     lib = _lib.load()
     rc = lib.lcg_hip_init(local_rank)
