@@ -299,6 +299,102 @@ __global__ __launch_bounds__(VB) void k_direct(int n, const int *__restrict__ ro
     if (j == 0) y[row] = acc;
 }
 
+// ---- 18-bit fields, seven per 16 bytes (2.29 B per entry) -- for blocks spanning < 2^18 columns
+__device__ __forceinline__ int f18(u64 lo, u64 hi, int j)
+{
+    const int sh = 18 * j;
+    u64 v;
+    if (sh + 18 <= 64) v = lo >> sh;
+    else if (sh >= 64) v = hi >> (sh - 64);
+    else v = (lo >> sh) | (hi << (64 - sh));
+    return (int)(v & 0x3ffff);
+}
+__global__ __launch_bounds__(VB) void k_pack18(int n, int R, const int *rowptr, const int *col, const int *base, const int *pofs, v4i *packed)
+{
+    const int b = blockIdx.x;
+    const long row0 = (long)b * R;
+    const int r1 = (int)min((long)n, row0 + R);
+    const int s = rowptr[row0], e = rowptr[r1];
+    const int ng = (e - s + 6) / 7, bs = base[b];
+    for (int g = threadIdx.x; g < ng; g += VB) {
+        u64 lo = 0, hi = 0;
+        for (int j = 0; j < 7; j++) {
+            const int k = s + 7 * g + j;
+            const u64 c = k < e ? (u64)(col[k] - bs) : 0;
+            const int sh = 18 * j;
+            if (sh < 64) { lo |= c << sh; if (sh + 18 > 64) hi |= c >> (64 - sh); }
+            else hi |= c << (sh - 64);
+        }
+        v4i o; o.x = (int)(unsigned)lo; o.y = (int)(unsigned)(lo >> 32); o.z = (int)(unsigned)hi; o.w = (int)(unsigned)(hi >> 32);
+        packed[pofs[b] + g] = o;
+    }
+}
+template <int R, int UNR>
+__global__ __launch_bounds__(VB) void k_spmv_p18(int n, const int *__restrict__ rowptr, const v4i *__restrict__ packed,
+                                                 const int *__restrict__ pofs, const int *__restrict__ pbase,
+                                                 const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y)
+{
+    constexpr int T = VB / R;
+    constexpr int CH = 2240;
+    constexpr int NG = (CH + 6) / 7;                    // 320 groups
+    constexpr int GR = (NG + VB - 1) / VB;
+    constexpr int VR = (CH / 2 + 1 + VB - 1) / VB;
+    __shared__ __attribute__((aligned(16))) double sval[CH + 2];
+    __shared__ __attribute__((aligned(16))) int scol[NG * 7 + 1];
+    double(*sred)[R] = reinterpret_cast<double(*)[R]>(sval);
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * R;
+    const int nrows = min(R, n - row0);
+    const int rl = tid % R, j0 = tid / R;
+    const int s = rowptr[row0], e = rowptr[row0 + nrows];
+    const int cnt = e - s, ng = (cnt + 6) / 7;
+    const int po = pofs[blockIdx.x], bs = pbase[blockIdx.x];
+    const int bv = s & ~1, cntv = e - bv;
+    v4i pg[GR]; v2d pv[VR];
+#pragma unroll
+    for (int r = 0; r < GR; r++) { const int gi = tid + r * VB; pg[r] = packed[po + (gi < ng ? gi : 0)]; }
+#pragma unroll
+    for (int r = 0; r < VR; r++) { const int u = 2 * (tid + r * VB); pv[r] = *reinterpret_cast<const v2d *>(val + (long)bv + (u < cntv ? u : 0)); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < GR; r++) {
+        const int gi = tid + r * VB;
+        if (gi < ng) {
+            const u64 lo = (u64)(unsigned)pg[r].x | ((u64)(unsigned)pg[r].y << 32);
+            const u64 hi = (u64)(unsigned)pg[r].z | ((u64)(unsigned)pg[r].w << 32);
+#pragma unroll
+            for (int j = 0; j < 7; j++) scol[7 * gi + j] = bs + f18(lo, hi, j);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < VR; r++) { const int u = 2 * (tid + r * VB); if (u < cntv) *reinterpret_cast<v2d *>(sval + u) = pv[r]; }
+    int rs = 0, re = 0;
+    if (rl < nrows) { rs = rowptr[row0 + rl]; re = rowptr[row0 + rl + 1]; }
+    __syncthreads();
+    double acc = 0.0;
+    int k = rs + j0;
+    {
+        int c[UNR]; double a[UNR], xv[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; q++) { const int kk = k + q * T; const bool ok = kk < re; c[q] = scol[ok ? kk - s : 0]; a[q] = sval[ok ? kk - bv : 0]; }
+#pragma unroll
+        for (int q = 0; q < UNR; q++) xv[q] = x[c[q]];
+#pragma unroll
+        for (int q = 0; q < UNR; q++) acc = (k + q * T < re) ? fma(a[q], xv[q], acc) : acc;
+        k += UNR * T;
+    }
+    for (; k < re; k += T) acc = fma(sval[k - bv], x[scol[k - s]], acc);
+    __syncthreads();
+    sred[j0][rl] = acc;
+    __syncthreads();
+    if (j0 == 0 && rl < nrows) {
+        double v = sred[0][rl];
+#pragma unroll
+        for (int j = 1; j < T; j++) v += sred[j][rl];
+        y[row0 + rl] = v;
+    }
+}
+
 int main(int argc, char **argv)
 {
     const long n = argc > 1 ? atol(argv[1]) : 10000000;
@@ -340,9 +436,23 @@ int main(int argc, char **argv)
     float bms; CK(hipEventElapsedTime(&bms, e0, e1));
     printf("pack build: %.1f ms\n", bms);
 
+    // 18-bit build (same base; groups of 7)
+    v4i *packed18 = nullptr; int *pofs18 = nullptr;
+    const bool ok18 = hstat[0] < (1 << 18);
+    if (ok18) {
+        std::vector<int> hpo18(nb); long tot18 = 0;
+        std::vector<int> rp_h(n + 1);
+        CK(hipMemcpy(rp_h.data(), rowptr, 4L * (n + 1), hipMemcpyDeviceToHost));
+        for (int b = 0; b < nb; b++) { hpo18[b] = (int)tot18; const long r1 = std::min<long>(n, (long)(b + 1) * R); tot18 += (rp_h[r1] - rp_h[(long)b * R] + 6) / 7; }
+        CK(hipMalloc(&packed18, 16L * (tot18 + 4))); CK(hipMalloc(&pofs18, 4L * nb));
+        CK(hipMemcpyAsync(pofs18, hpo18.data(), 4L * nb, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_pack18, dim3(nb), dim3(VB), 0, s, (int)n, R, rowptr, col, base, pofs18, packed18);
+        CK(hipStreamSynchronize(s));
+        printf("18-bit groups %ld (%.3f B/entry)\n", tot18, 16.0 * tot18 / nnz);
+    } else printf("span too wide for 18 bits\n");
     const double bytes = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
     struct Var { const char *name; int id; std::vector<double> ms; double dev; };
-    std::vector<Var> vs = {{"shipped (lcg_hip_spmv)", 0, {}, 0}, {"packed unr4", 1, {}, 0}, {"packed unr8", 2, {}, 0}, {"packed pred9", 3, {}, 0}, {"packed pred10", 4, {}, 0},
+    std::vector<Var> vs = {{"shipped (lcg_hip_spmv)", 0, {}, 0}, {"packed unr4", 1, {}, 0}, {"packed unr8", 2, {}, 0}, {"packed pred9", 3, {}, 0}, {"packed18 pred9", 5, {}, 0},
                            };
     auto run = [&](int id) {
         if (id >= 50000) {
@@ -365,6 +475,7 @@ int main(int argc, char **argv)
         if (id == 0) lcg_hip_spmv(A, x, y);
         else if (id == 1) hipLaunchKernelGGL((k_spmv_p<R, 4>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
         else if (id == 2) hipLaunchKernelGGL((k_spmv_p<R, 8>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
+        else if (id == 5) { if (ok18) hipLaunchKernelGGL((k_spmv_p18<R, 9>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed18, pofs18, base, val, x, y); else lcg_hip_spmv(A, x, y); }
         else if (id == 3) hipLaunchKernelGGL((k_spmv_p<R, 9>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
         else hipLaunchKernelGGL((k_spmv_p<R, 10>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
     };
