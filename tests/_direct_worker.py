@@ -46,6 +46,8 @@ def main(ref_path, out_path):
         r0, r1 = partition.shard_range(n, world, rank)
         A = api.CsrMatrix.generate(n, 16, band, sym, 3, 0.01, r0, r1)
         A.distribute(n, 2)
+        if tag != "scr":        # also drive the packed-column product with pushing blocks (auto only from 4M entries up)
+            assert lib.lcg_hip_csr_set_packed(A.h, 1) == 0
         res[f"{tag}/recv"] = int(lib.lcg_hip_csr_exchange_volume(A.h))
         x1 = torch.from_numpy(ref[f"{tag}/x1"][r0:r1]).cuda()
         x2 = torch.from_numpy(ref[f"{tag}/x2"][r0:r1]).cuda()
