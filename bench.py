@@ -145,21 +145,30 @@ def main():
                 failed = True
             if not anybody(failed):         # phase 2: all ranks exchange, or none does
                 t1 = torch.empty_like(b); t2 = torch.empty_like(b); t3 = torch.empty_like(b)
-                A.spmv(xt, t1); A.spmv(x2, t2); A.spmv(xt, t3); api.synchronize()    # alternating inputs expose stale buffers
-                if mode == 1:
-                    failed = not (torch.equal(t1, b) and torch.equal(t2, b2) and torch.equal(t3, b))
-                else:
-                    failed = not (close(t1, b) and close(t2, b2) and close(t3, b))
+                try:
+                    A.spmv(xt, t1); A.spmv(x2, t2); A.spmv(xt, t3); api.synchronize()    # alternating inputs expose stale buffers
+                    if mode == 1:
+                        failed = not (torch.equal(t1, b) and torch.equal(t2, b2) and torch.equal(t3, b))
+                    else:
+                        failed = not (close(t1, b) and close(t2, b2) and close(t3, b))
+                except Exception as exc:        # a timed-out exchange surfaces in synchronize()
+                    print(f"[rank {rank}] exchange mode {mode} failed its check: {exc}", file=sys.stderr)
+                    failed = True
                 if not anybody(failed):
-                    timings[mode] = ax_time()
+                    try:
+                        timings[mode] = ax_time()
+                    except Exception as exc:
+                        print(f"[rank {rank}] exchange mode {mode} failed while timed: {exc}", file=sys.stderr)
+                        raise
             A.distribute(n, 0)
-        if p2p and anybody(lib.lcg_hip_p2p_status() < 0):
-            # an exchange over the peer mappings timed out somewhere: RCCL takes over everything
-            p2p = False
-            lib.lcg_hip_p2p_enable(0)
-            timings.pop(2, None)
-            if rank == 0:
-                print("[bench] direct paths switched off: an exchange timed out", file=sys.stderr)
+            if p2p and anybody(lib.lcg_hip_p2p_status() < 0):
+                # an exchange over the peer mappings timed out somewhere: tear the direct paths down on every
+                # rank (no matrix uses them at this point) and let RCCL do everything
+                p2p = False
+                lib.lcg_hip_p2p_disconnect()
+                timings.pop(2, None)
+                if rank == 0:
+                    print("[bench] direct paths switched off: an exchange timed out", file=sys.stderr)
         # the fastest validated exchange on THIS node (same decision everywhere: the timings are all-reduced)
         best = min(timings, key=lambda k: timings[k]) if want > 0 else 0
         if "LCG_HIP_DIST_MODE" in os.environ and want in timings:

@@ -100,7 +100,7 @@ typedef int (*clcg_hip_progress_ptr)(void *instance, const double *m, const doub
 int  lcg_hip_init(int device);                 /* selects the device; idempotent. */
 int  lcg_hip_set_stream(void *hip_stream);     /* NULL = the library's own stream */
 void *lcg_hip_get_stream(void);                /* stream callbacks must launch on */
-int  lcg_hip_synchronize(void);
+int  lcg_hip_synchronize(void);   /* also where a timed-out direct exchange (multi-GPU) surfaces: LCG_HIP_E_COMM */
 /* Blocking copy on the library stream.  kind: 1 host->device, 2 device->host, 3 device->device
  * (the cudaMemcpy calls of the reference's GPU samples, e.g. sample8.cu:160-166). */
 int  lcg_hip_memcpy(void *dst, const void *src, uint64_t bytes, int kind);

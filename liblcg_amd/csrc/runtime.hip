@@ -169,6 +169,12 @@ int lcg_hip_synchronize(void)
 {
     int rc = ensure_init(); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx().stream));
+    // a product over the direct exchange cannot return its own failure (it only enqueues): a timed-out
+    // wait for a neighbour leaves the failure flag up, and this is where a caller learns of it
+    if (lcg_hip_p2p_status() < 0) {
+        ctx().err = "direct exchange: a neighbour's data or sums did not arrive in time (results since then are invalid)";
+        return LCG_HIP_E_COMM;
+    }
     return 0;
 }
 
