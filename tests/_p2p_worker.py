@@ -85,6 +85,7 @@ def lonely():
         print("RC", rc, "DT", round(dt, 2), lib.lcg_hip_last_error().decode())
         assert rc == -2002 and dt < 5.0
         assert lib.lcg_hip_p2p_status() == -1       # the path reports itself dead
+        assert lib.lcg_hip_synchronize() == -2002   # ... and that is what a caller's synchronisation returns
         lib.lcg_hip_p2p_disconnect()
     finally:
         child.stdin.write("bye\n"); child.stdin.flush(); child.wait(timeout=30)
