@@ -394,6 +394,7 @@ struct Direct {
     unsigned int *ticket = nullptr;
     size_t half = 0;                    // doubles per half of recv
     unsigned long long calls = 0;       // A.x calls made with this matrix (same on every rank)
+    bool uses_mailbox = true;           // plans point into the mailbox state (false for the self-loop rehearsal)
     int nnb = 0;
     int nb_rank[XG_MAXSEG];
     double *nb_recv[XG_MAXSEG];         // neighbour's recv as mapped here
@@ -756,6 +757,10 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
     const int *done = c.in_solve ? &c.state->done : nullptr;
     if (A->dist_mode == 2 && A->direct) {
         // one stream, no collective: [push blocks + local product] | [wait for flags + remote product]
+        if (static_cast<Direct *>(A->direct)->uses_mailbox && !g_xg.connected) {
+            c.err = "direct exchange: the mailboxes were disconnected while this matrix still uses them (distribute it again)";
+            return LCG_HIP_E_COMM;
+        }
         PushPlan pp, cp; WaitPlan wp;
         direct_plans(A, x, &pp, &wp, &cp);
         const double mean_l = A->n_rows ? (double)A->loc.nnz / A->n_rows : 0.0;
@@ -1029,6 +1034,7 @@ int lcg_hip_csr_direct_selfloop_for_test(lcg_hip_csr_t A, int nranks, int rank)
     pp.nblocks = nb > 0 ? nb : (pp.nflag > 0 ? 1 : 0);
     D->wait.timeout_ticks = 200000000LL;
     D->wait.fail = fail_dev;
+    D->uses_mailbox = false;
     direct_copy_plan(A, D);
     HIPCHK(hipStreamSynchronize(c.stream));
     A->dist_mode = 2;
