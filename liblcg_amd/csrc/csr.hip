@@ -354,7 +354,8 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
         for (int q = 0; q < UNR; q++) {
             const int kk = k + q * T;
             const bool ok = kk < re;
-            c[q] = scol[ok ? kk - s : 0];
+            const int cc = scol[ok ? kk - s : 0];
+            c[q] = ok ? cc : 0;         // an empty block never wrote scol[0]: column 0 is always a valid address
             a[q] = sval[ok ? kk - bv : 0];
         }
 #pragma unroll
