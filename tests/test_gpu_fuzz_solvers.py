@@ -1,0 +1,44 @@
+"""-m gpu: the insensitive recurrences (CG, PCG + Jacobi, CGS) on RANDOM generated systems against the oracle --
+sizes from a few hundred to 60,000 rows, bands from 1 to n/3, scrambled columns, both stop rules -- with the plain and
+with the packed-column A.x.  Bands: x to 1e-9 of the oracle's, iteration counts within +-3 (tests/test_gpu_solvers.py
+derives them on the bundled system; the generated ones are better conditioned)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_random_systems_against_the_oracle(port):
+    from liblcg_amd import _lib, api
+    from oracle import pyoracle as po
+    lib = _lib.load()
+    rng = np.random.default_rng(99)
+    for case in range(10):
+        n = int(rng.integers(300, 60000))
+        band = 0 if case % 4 == 3 else int(rng.integers(1, max(2, n // 3)))
+        abs_diff = int(case % 2)
+        eps = 1e-12 if abs_diff else 1e-14
+        seed = int(rng.integers(1, 1000))
+        A = api.CsrMatrix.generate(n, 16, band, True, seed, 0.01)
+        A.build_jacobi()
+        rp, ci, v = A.arrays_to_host()
+        xt = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, seed, 0, n, xt)
+        b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
+        bh = b.cpu().numpy()
+        for sid, name in ((api.LCG_CG, "cg"), (api.LCG_PCG, "pcg"), (api.LCG_CGS, "cgs")):
+            ref = port.solve(sid, rp, ci, v, bh, para=po.default_para(epsilon=eps, abs_diff=abs_diff), jacobi=(sid == api.LCG_PCG))
+            for packed in (0, 1):
+                assert lib.lcg_hip_csr_set_packed(A.h, packed) == 0
+                m = torch.zeros(n, dtype=torch.float64, device="cuda")
+                para = api.lcg_default_parameters(epsilon=eps, abs_diff=abs_diff)
+                if sid == api.LCG_PCG:
+                    info = api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, b, n, para, A)
+                else:
+                    info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, para, A, sid)
+                x = m.cpu().numpy()
+                tag = (case, n, band, abs_diff, name, packed)
+                assert info.ret == ref["ret"], (tag, info.ret, ref["ret"])
+                assert abs(info.iterations - ref["iters"]) <= 3, (tag, info.iterations, ref["iters"])
+                assert np.linalg.norm(x - ref["x"]) <= 1e-9 * np.linalg.norm(ref["x"]), tag
+        A.destroy()
