@@ -62,7 +62,7 @@ __global__ __launch_bounds__(VB) void k_pack(int n, int R, const int *rowptr, co
     }
 }
 
-template <int R, int UNR>
+template <int R, int UNR, int PRIO = 0>
 __global__ __launch_bounds__(VB) void k_spmv_p(int n, const int *__restrict__ rowptr, const v4i *__restrict__ packed,
                                                const int *__restrict__ pofs, const int *__restrict__ pbase,
                                                const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y)
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(VB) void k_spmv_p(int n, const int *__restrict__ ro
     const int po = pofs[blockIdx.x], bs = pbase[blockIdx.x];
     const int bv = s & ~1, cntv = e - bv;
 
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(3);     // issue this block's stream loads ahead of the gathering waves
     v4i pg[GR]; v2d pv[VR];
 #pragma unroll
     for (int r = 0; r < GR; r++) {
@@ -116,6 +117,8 @@ __global__ __launch_bounds__(VB) void k_spmv_p(int n, const int *__restrict__ ro
         const int u = 2 * (tid + r * VB);
         if (u < cntv) *reinterpret_cast<v2d *>(sval + u) = pv[r];
     }
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    if (PRIO == 2) __builtin_amdgcn_s_setprio(3);     // or: let the gathering waves finish first
     int rs = 0, re = 0;
     if (rl < nrows) { rs = rowptr[row0 + rl]; re = rowptr[row0 + rl + 1]; }
     __syncthreads();
@@ -452,7 +455,7 @@ int main(int argc, char **argv)
     } else printf("span too wide for 18 bits\n");
     const double bytes = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
     struct Var { const char *name; int id; std::vector<double> ms; double dev; };
-    std::vector<Var> vs = {{"shipped (lcg_hip_spmv)", 0, {}, 0}, {"packed unr4", 1, {}, 0}, {"packed unr8", 2, {}, 0}, {"packed pred9", 3, {}, 0}, {"packed18 pred9", 5, {}, 0},
+    std::vector<Var> vs = {{"shipped (lcg_hip_spmv)", 0, {}, 0}, {"packed unr4", 1, {}, 0}, {"packed unr8", 2, {}, 0}, {"packed pred9", 3, {}, 0}, {"packed18 pred9", 5, {}, 0}, {"packed pred9 prio-load", 6, {}, 0}, {"packed pred9 prio-gather", 7, {}, 0},
                            };
     auto run = [&](int id) {
         if (id >= 50000) {
@@ -476,6 +479,8 @@ int main(int argc, char **argv)
         else if (id == 1) hipLaunchKernelGGL((k_spmv_p<R, 4>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
         else if (id == 2) hipLaunchKernelGGL((k_spmv_p<R, 8>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
         else if (id == 5) { if (ok18) hipLaunchKernelGGL((k_spmv_p18<R, 9>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed18, pofs18, base, val, x, y); else lcg_hip_spmv(A, x, y); }
+        else if (id == 7) hipLaunchKernelGGL((k_spmv_p<R, 9, 2>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
+        else if (id == 6) hipLaunchKernelGGL((k_spmv_p<R, 9, 1>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
         else if (id == 3) hipLaunchKernelGGL((k_spmv_p<R, 9>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
         else hipLaunchKernelGGL((k_spmv_p<R, 10>), dim3(nb), dim3(VB), 0, s, (int)n, rowptr, packed, pofs, base, val, x, y);
     };
