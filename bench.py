@@ -271,7 +271,7 @@ def main():
                 traffic = json.load(open(pmc)).get("spmv_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "k_spmv_ldsp / k_spmv_lds1 (LDS-staged CSR A.x; packed 21-bit columns when eligible)" if world == 1 else "A.x (local product + x exchange + remote columns)",
+        out["roofline"] = {"bound": "hbm", "kernel": "k_spmv_ldsp / k_spmv_lds1 (LDS-staged CSR A.x; packed 18/21-bit columns when eligible)" if world == 1 else "A.x (local product + x exchange + remote columns)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "bytes_per_launch": shard_bytes, "avg_launch_us": ax_us, "launches": ax_calls}
 

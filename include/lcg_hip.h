@@ -186,9 +186,9 @@ int lcg_hip_csr_arrays(lcg_hip_csr_t A, const int **rowptr, const int **col, con
 /* Select the SpMV kernel: 0 auto, otherwise lanes per row (2,4,...,64) for the
  * wavefront kernel, or -1 for the LDS-staged variant. */
 int lcg_hip_csr_set_kernel(lcg_hip_csr_t A, int variant);
-/* Packed column indices for the LDS-staged real A.x (64 rows per block, 21-bit block-relative
- * columns, six per 16 bytes: 10.67 instead of 12 bytes of stream per entry, -4.6 % time on the
- * headline system, bit-identical y).  Built on the device at the first product, kept beside the plain
+/* Packed column indices for the LDS-staged real A.x (64 rows per block, block-relative columns of 18
+ * or 21 bits, seven or six per 16 bytes: 10.3 / 10.7 instead of 12 bytes of stream per entry, -9 % time
+ * on the headline system, bit-identical y).  Built on the device at the first product, kept beside the plain
  * column array (+2.67 B per entry).  mode: -1 automatic (matrices of >= 4M entries whose blocks
  * span < 2^21 columns), 0 never (frees the packed copy), 1 whenever eligible.  LCG_HIP_PACKED=0/1
  * overrides for the whole process. */

@@ -241,7 +241,7 @@ constexpr int PK_R = 64;
 constexpr int PK_SPAN = 1 << 21;
 
 __global__ __launch_bounds__(64) void k_pk_meta(int n, const int *rowptr, const int *col, int *base, int *ngroups, int *maxspan)
-{   // maxspan[0] = widest block (columns), maxspan[1] = longest row
+{   // ngroups[b] = entries of block b for now (k_pk_groups turns them into groups); maxspan[0] = widest block, [1] = longest row
     const int b = blockIdx.x;
     const long row0 = (long)b * PK_R;
     const int r1 = (int)min((long)n, row0 + PK_R);
@@ -255,26 +255,53 @@ __global__ __launch_bounds__(64) void k_pk_meta(int n, const int *rowptr, const 
     }
     if (threadIdx.x == 0) {
         if (e == s) { lo = 0; hi = 0; }
-        base[b] = lo; ngroups[b] = (e - s + 5) / 6;
+        base[b] = lo; ngroups[b] = e - s;
         atomicMax(maxspan, hi - lo); atomicMax(maxspan + 1, len);
     }
 }
 
+__global__ void k_pk_groups(int nb, int per, int *ngroups)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nb) ngroups[b] = (ngroups[b] + per - 1) / per;
+}
+
+// Field j of a 128-bit group (lo, hi): BITS = 21 -> six fields, three per 64-bit half; BITS = 18 -> seven
+// fields, the fourth straddling the halves.
+template <int BITS> __device__ __forceinline__ int pk_field(u64 lo, u64 hi, int j);
+template <> __device__ __forceinline__ int pk_field<21>(u64 lo, u64 hi, int j)
+{
+    return (int)(((j < 3 ? lo : hi) >> (21 * (j % 3))) & 0x1fffff);
+}
+template <> __device__ __forceinline__ int pk_field<18>(u64 lo, u64 hi, int j)
+{
+    const int sh = 18 * j;
+    const u64 v = sh + 18 <= 64 ? lo >> sh : (sh >= 64 ? hi >> (sh - 64) : (lo >> sh) | (hi << (64 - sh)));
+    return (int)(v & 0x3ffff);
+}
+
+template <int BITS>
 __global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const int *col, const int *base, const int *pofs, v4i *packed)
 {
+    constexpr int PER = 128 / BITS;
     const int b = blockIdx.x;
     const long row0 = (long)b * PK_R;
     const int r1 = (int)min((long)n, row0 + PK_R);
     const int s = rowptr[row0], e = rowptr[r1];
-    const int ng = (e - s + 5) / 6, bs = base[b];
+    const int ng = (e - s + PER - 1) / PER, bs = base[b];
     for (int g = threadIdx.x; g < ng; g += VB) {
-        u64 w[2] = {0, 0};
-        for (int j = 0; j < 6; j++) {
-            const int k = s + 6 * g + j;
+        u64 lo = 0, hi = 0;
+        for (int j = 0; j < PER; j++) {
+            const int k = s + PER * g + j;
             const u64 c = k < e ? (u64)(col[k] - bs) : 0;
-            w[j / 3] |= c << (21 * (j % 3));
+            if (BITS == 21) { if (j < 3) lo |= c << (21 * j); else hi |= c << (21 * (j - 3)); }
+            else {
+                const int sh = BITS * j;
+                if (sh < 64) { lo |= c << sh; if (sh + BITS > 64) hi |= c >> (64 - sh); }
+                else hi |= c << (sh - 64);
+            }
         }
-        v4i o; o.x = (int)(unsigned)w[0]; o.y = (int)(unsigned)(w[0] >> 32); o.z = (int)(unsigned)w[1]; o.w = (int)(unsigned)(w[1] >> 32);
+        v4i o; o.x = (int)(unsigned)lo; o.y = (int)(unsigned)(lo >> 32); o.z = (int)(unsigned)hi; o.w = (int)(unsigned)(hi >> 32);
         packed[pofs[b] + g] = o;
     }
 }
@@ -283,7 +310,7 @@ __global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const 
 // NS > 8: the FIRST batch is predicated (slots past the row's end read entry 0 with a zero
 // coefficient), so rows of up to NS*T entries -- 33 entries on 4 lanes are 9 for one lane, 8 for the
 // others -- are done in one round without a serial tail (0.706 vs 0.722 ms on the headline system).
-template <bool PUSH, int NS>
+template <bool PUSH, int NS, int BITS>
 __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__ rowptr, const v4i *__restrict__ packed,
                                                   const int *__restrict__ pofs, const int *__restrict__ pbase,
                                                   const double *__restrict__ val, const double *__restrict__ x,
@@ -295,11 +322,12 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     constexpr int T = VB / R;
     constexpr int UNR = NS;
     constexpr int CH = LdsCfg<double>::CH;              // entries per block at most (checked by the host)
-    constexpr int NG = (CH + 5) / 6;                    // groups
+    constexpr int PER = 128 / BITS;                     // columns per 16-byte group: 6 (21 bits) or 7 (18 bits)
+    constexpr int NG = (CH + PER - 1) / PER;            // groups
     constexpr int GR = (NG + VB - 1) / VB;              // rounds of 16-byte group loads
     constexpr int VR = (CH / 2 + 1 + VB - 1) / VB;      // rounds of 16-byte val loads
     __shared__ __attribute__((aligned(16))) double sval[CH + 2];
-    __shared__ __attribute__((aligned(16))) int scol[NG * 6];
+    __shared__ __attribute__((aligned(16))) int scol[NG * PER];
     double(*sred)[R] = reinterpret_cast<double(*)[R]>(sval);
     if (done && *done) return;
 
@@ -308,7 +336,7 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     const int nrows = min(R, n - row0);
     const int rl = tid % R, j0 = tid / R;
     const int s = rowptr[row0], e = rowptr[row0 + nrows];
-    const int cnt = e - s, ng = (cnt + 5) / 6;
+    const int cnt = e - s, ng = (cnt + PER - 1) / PER;
     const int po = pofs[bid], bs = pbase[bid];
     const int bv = s & ~1, cntv = e - bv;
 
@@ -330,12 +358,17 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
         if (gi < ng) {
             const u64 lo = (u64)(unsigned)pg[r].x | ((u64)(unsigned)pg[r].y << 32);
             const u64 hi = (u64)(unsigned)pg[r].z | ((u64)(unsigned)pg[r].w << 32);
-            v2i a, b, c;
-            a.x = bs + (int)(lo & 0x1fffff); a.y = bs + (int)((lo >> 21) & 0x1fffff);
-            b.x = bs + (int)((lo >> 42) & 0x1fffff); b.y = bs + (int)(hi & 0x1fffff);
-            c.x = bs + (int)((hi >> 21) & 0x1fffff); c.y = bs + (int)((hi >> 42) & 0x1fffff);
-            v2i *dst = reinterpret_cast<v2i *>(scol + 6 * gi);
-            dst[0] = a; dst[1] = b; dst[2] = c;
+            if (BITS == 21) {
+                v2i a, b, c;
+                a.x = bs + (int)(lo & 0x1fffff); a.y = bs + (int)((lo >> 21) & 0x1fffff);
+                b.x = bs + (int)((lo >> 42) & 0x1fffff); b.y = bs + (int)(hi & 0x1fffff);
+                c.x = bs + (int)((hi >> 21) & 0x1fffff); c.y = bs + (int)((hi >> 42) & 0x1fffff);
+                v2i *dst = reinterpret_cast<v2i *>(scol + 6 * gi);
+                dst[0] = a; dst[1] = b; dst[2] = c;
+            } else {
+#pragma unroll
+                for (int j = 0; j < PER; j++) scol[PER * gi + j] = bs + pk_field<BITS>(lo, hi, j);
+            }
         }
     }
 #pragma unroll
@@ -406,13 +439,22 @@ static bool packed_ready(const CsrPart &P, hipStream_t s)
               hipMemsetAsync(span, 0, 2 * sizeof(int), s) == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(k_pk_meta, dim3(nb), dim3(64), 0, s, n, P.rowptr, P.col, P.pk_base, ngr, span);
-        ok = device_exclusive_scan(nb, ngr, P.pk_ofs, s, &total) == 0 &&
-             hipMemcpyAsync(hspan, span, 2 * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        ok = hipMemcpyAsync(hspan, span, 2 * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     }
-    if (ok) ok = hspan[0] < PK_SPAN && total > 0 && total < 0x7fffffffL;
+    if (ok) ok = hspan[0] < PK_SPAN;
+    static const int force_bits = [] { const char *e = std::getenv("LCG_HIP_PACKED_BITS"); return e ? atoi(e) : 0; }();   // 21: A/B runs
+    const int bits = (hspan[0] < (1 << 18) && force_bits != 21) ? 18 : 21;     // seven 18-bit columns per group where the blocks are narrow enough
+    if (ok) {
+        hipLaunchKernelGGL(k_pk_groups, dim3((nb + VB - 1) / VB), dim3(VB), 0, s, nb, 128 / bits, ngr);
+        ok = device_exclusive_scan(nb, ngr, P.pk_ofs, s, &total) == 0;
+    }
+    if (ok) ok = total > 0 && total < 0x7fffffffL;
     if (ok) ok = hipMalloc(&P.pk_data, 16 * ((size_t)total + 4)) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(k_pk_pack, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data));
+        if (bits == 18)
+            hipLaunchKernelGGL(k_pk_pack<18>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data));
+        else
+            hipLaunchKernelGGL(k_pk_pack<21>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data));
         ok = hipGetLastError() == hipSuccess;
     }
     if (ngr) hipFree(ngr);
@@ -426,6 +468,7 @@ static bool packed_ready(const CsrPart &P, hipStream_t s)
         return false;
     }
     P.pk_maxrow = hspan[1];
+    P.pk_bits = bits;
     P.pk_state = 1;
     return true;
 }
@@ -476,13 +519,16 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
                 // gathers per lane in the first batch: enough for the longest row when that is 9..12 per lane
                 const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);
                 const int ns = per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
+#define PK_LAUNCH(NSS, BB)                                                                                          \
+        hipLaunchKernelGGL((k_spmv_ldsp<PUSH, NSS, BB>), dim3((n + PK_R - 1) / PK_R + xb), dim3(VB), 0, s, n, P.rowptr, \
+                           static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, reinterpret_cast<const double *>(val), \
+                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, pp)
 #define PK_CASE(NSS)                                                                                                \
     case NSS:                                                                                                       \
-        hipLaunchKernelGGL((k_spmv_ldsp<PUSH, NSS>), dim3((n + PK_R - 1) / PK_R + xb), dim3(VB), 0, s, n, P.rowptr, \
-                           static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, reinterpret_cast<const double *>(val), \
-                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, pp);           \
+        if (P.pk_bits == 18) PK_LAUNCH(NSS, 18); else PK_LAUNCH(NSS, 21);                                          \
         break;
                 switch (ns) { PK_CASE(8) PK_CASE(9) PK_CASE(10) PK_CASE(12) }
+#undef PK_LAUNCH
 #undef PK_CASE
                 HIPCHK(hipGetLastError());
                 return 0;

@@ -141,6 +141,7 @@ struct CsrPart {
     mutable int *pk_base = nullptr, *pk_ofs = nullptr;     // per block of 64 rows: smallest column, first group
     mutable void *pk_data = nullptr;                        // 16 bytes per group of 6 entries
     mutable int pk_maxrow = 0;                              // longest row (chooses the gather batch of the kernel)
+    mutable int pk_bits = 21;                               // width of a packed column: 18 (seven per group) or 21 (six)
 };
 
 } // namespace lcgh
