@@ -70,6 +70,19 @@ int main(int argc, char **argv)
         e = 0; for (int i = 0; i < n; i++) e += (m[i] - ans[i]) * (m[i] - ans[i]);
         std::printf("class PCG (silent): iterations=%d error=%.3e\n", lcg_hip_last_iterations(), std::sqrt(e));
         if (!(std::sqrt(e) < 1e-4)) bad++;
+        // sample2.cpp:143-149: the box-constrained solvers through the class (box [-5, 8] cuts the known answer)
+        std::vector<double> low(n, -5.0), hig(n, 8.0);
+        p.max_iterations = 40;
+        s.set_lcg_parameter(p);
+        for (lcg_solver_enum id : {LCG_PG, LCG_SPG}) {
+            std::fill(m.begin(), m.end(), 0.0);
+            s.MinimizeConstrained(m.data(), b.data(), low.data(), hig.data(), n, id, false);
+            double mn = m[0], mx = m[0];
+            for (double v : m) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+            std::printf("class %s: iterations=%d residual=%.10e min=%g max=%g\n", id == LCG_PG ? "PG" : "SPG", lcg_hip_last_iterations(),
+                        lcg_hip_last_residual(), mn, mx);
+            if (lcg_hip_last_iterations() != 40 || mn < -5.0 || mx > 8.0) bad++;
+        }
         lcg_hip_csr_destroy(s.A);
     }
     {

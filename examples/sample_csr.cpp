@@ -61,7 +61,7 @@ int main(int argc, char **argv)
     para.epsilon = 1e-10; para.abs_diff = 1;
     std::vector<double> m(n);
     int bad = 0;
-    struct { const char *name; int id; } runs[] = {{"CG", LCG_CG}, {"CGS", LCG_CGS}, {"BICGSTAB", LCG_BICGSTAB}, {"PCG", LCG_PCG}};
+    struct { const char *name; lcg_solver_enum id; } runs[] = {{"CG", LCG_CG}, {"CGS", LCG_CGS}, {"BICGSTAB", LCG_BICGSTAB}, {"PCG", LCG_PCG}};
     for (auto &r : runs) {
         std::fill(m.begin(), m.end(), 0.0);
         int ret = r.id == LCG_PCG

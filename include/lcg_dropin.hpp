@@ -32,8 +32,7 @@ typedef std::complex<lcg_float> lcg_complex;    // lcg_complex.h:33 (LibLCG_STD_
 
 enum lcg_matrix_e { MatNormal, MatTranspose };          // algebra.h:31-35
 enum clcg_complex_e { NonConjugate, Conjugate };        // algebra.h:40-44
-typedef int lcg_solver_enum;                            // values LCG_CG ... LCG_SPG  (util.h:32-64)
-typedef int clcg_solver_enum;                           // values CLCG_BICG ... CLCG_PBICG (util.h:187-221)
+// lcg_solver_enum / clcg_solver_enum (util.h:32-64, 187-221) are the enum types of lcg_hip.h
 
 // clcg.h:40-41 / 56-57 with the reference's C++ types
 typedef void (*clcg_axfunc_ptr)(void *instance, const lcg_complex *x, lcg_complex *prod_Ax,
@@ -114,33 +113,60 @@ inline int lcgs(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, lcg_float *m, const lc
 }
 
 // ---- complex -----------------------------------------------------------------------------------
-// std::complex<double> is layout-compatible with double[2]; the enums of the callback are ints
-// at the ABI, so a clcg_axfunc_ptr can be handed over unchanged.
+// The reference's complex callbacks take std::complex pointers and two enums (clcg.h:40-41); the C ABI takes
+// doubles and ints.  std::complex<double> is layout-compatible with double[2] (so the vectors pass through),
+// but a function pointer is not cast across signatures: the caller's callbacks are reached through the
+// trampolines below, which the C ABI calls with a small record as its instance.
+namespace lcg_dropin_detail {
+struct cthunk { clcg_axfunc_ptr Afp, Mfp; clcg_progress_ptr Pfp; void *instance; };
+inline void c_ax(void *t, const double *x, double *y, const int n, int layout, int conjugate)
+{
+    const cthunk *c = static_cast<const cthunk *>(t);
+    c->Afp(c->instance, reinterpret_cast<const lcg_complex *>(x), reinterpret_cast<lcg_complex *>(y), n,
+           static_cast<lcg_matrix_e>(layout), static_cast<clcg_complex_e>(conjugate));
+}
+inline void c_mx(void *t, const double *x, double *y, const int n, int layout, int conjugate)
+{
+    const cthunk *c = static_cast<const cthunk *>(t);
+    c->Mfp(c->instance, reinterpret_cast<const lcg_complex *>(x), reinterpret_cast<lcg_complex *>(y), n,
+           static_cast<lcg_matrix_e>(layout), static_cast<clcg_complex_e>(conjugate));
+}
+inline int c_progress(void *t, const double *m, const double converge, const clcg_para *param, const int n, const int k)
+{
+    const cthunk *c = static_cast<const cthunk *>(t);
+    return c->Pfp(c->instance, reinterpret_cast<const lcg_complex *>(m), converge, param, n, k);
+}
+inline int c_solve(clcg_axfunc_ptr Afp, clcg_progress_ptr Pfp, lcg_complex *m, const lcg_complex *B, const int n_size,
+                   const clcg_para *param, void *instance, int solver_id, int mem)
+{
+    cthunk t = {Afp, nullptr, Pfp, instance};
+    return clcg_hip_solver(Afp ? c_ax : nullptr, Pfp ? c_progress : nullptr, reinterpret_cast<double *>(m),
+                           reinterpret_cast<const double *>(B), n_size, param, &t, solver_id, mem);
+}
+} // namespace lcg_dropin_detail
+
 inline int clcg_solver(clcg_axfunc_ptr Afp, clcg_progress_ptr Pfp, lcg_complex *m, const lcg_complex *B,
                        const int n_size, const clcg_para *param, void *instance,
                        clcg_solver_enum solver_id = CLCG_BICG)
 {
-    return clcg_hip_solver(reinterpret_cast<clcg_hip_axfunc_ptr>(Afp), reinterpret_cast<clcg_hip_progress_ptr>(Pfp),
-                           reinterpret_cast<double *>(m), reinterpret_cast<const double *>(B), n_size, param,
-                           instance, solver_id, LCG_HIP_MEM_HOST);
+    return lcg_dropin_detail::c_solve(Afp, Pfp, m, B, n_size, param, instance, solver_id, LCG_HIP_MEM_HOST);
 }
 inline int clcg_solver_device(clcg_axfunc_ptr Afp, clcg_progress_ptr Pfp, lcg_complex *d_m, const lcg_complex *d_B,
                               const int n_size, const clcg_para *param, void *instance,
                               clcg_solver_enum solver_id = CLCG_BICG)
 {
-    return clcg_hip_solver(reinterpret_cast<clcg_hip_axfunc_ptr>(Afp), reinterpret_cast<clcg_hip_progress_ptr>(Pfp),
-                           reinterpret_cast<double *>(d_m), reinterpret_cast<const double *>(d_B), n_size, param,
-                           instance, solver_id, LCG_HIP_MEM_DEVICE);
+    return lcg_dropin_detail::c_solve(Afp, Pfp, d_m, d_B, n_size, param, instance, solver_id, LCG_HIP_MEM_DEVICE);
 }
 // clcg_solver_preconditioned_cuda (clcg_cuda.h:105-108) without the vendor handles
 inline int clcg_solver_preconditioned(clcg_axfunc_ptr Afp, clcg_axfunc_ptr Mfp, clcg_progress_ptr Pfp, lcg_complex *m,
                                       const lcg_complex *B, const int n_size, const clcg_para *param, void *instance,
                                       clcg_solver_enum solver_id = CLCG_PCG)
 {
-    return clcg_hip_solver_preconditioned(reinterpret_cast<clcg_hip_axfunc_ptr>(Afp), reinterpret_cast<clcg_hip_axfunc_ptr>(Mfp),
-                                          reinterpret_cast<clcg_hip_progress_ptr>(Pfp), reinterpret_cast<double *>(m),
-                                          reinterpret_cast<const double *>(B), n_size, param, instance, solver_id,
-                                          LCG_HIP_MEM_HOST);
+    using namespace lcg_dropin_detail;
+    cthunk t = {Afp, Mfp, Pfp, instance};
+    return clcg_hip_solver_preconditioned(Afp ? c_ax : nullptr, Mfp ? c_mx : nullptr, Pfp ? c_progress : nullptr,
+                                          reinterpret_cast<double *>(m), reinterpret_cast<const double *>(B), n_size, param,
+                                          &t, solver_id, LCG_HIP_MEM_HOST);
 }
 // the ready-made complex CSR callback with the reference's C++ signature
 inline void clcg_csr_ax(void *instance, const lcg_complex *x, lcg_complex *prod_Ax, const int n,

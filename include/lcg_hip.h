@@ -52,11 +52,11 @@ typedef struct clcg_para {
     int    abs_diff;         /* complex residual is |<r,r>|^2/max(|<m,m>|^2,1): clcg.cpp:295-296 */
 } clcg_para;
 
-/* util.h:32-64 */
-enum { LCG_CG = 0, LCG_PCG = 1, LCG_CGS = 2, LCG_BICGSTAB = 3, LCG_BICGSTAB2 = 4, LCG_PG = 5, LCG_SPG = 6 };
+/* util.h:32-64 (the reference's own type name; the entry points below take it as int) */
+typedef enum lcg_solver_enum { LCG_CG = 0, LCG_PCG = 1, LCG_CGS = 2, LCG_BICGSTAB = 3, LCG_BICGSTAB2 = 4, LCG_PG = 5, LCG_SPG = 6 } lcg_solver_enum;
 /* util.h:187-221 */
-enum { CLCG_BICG = 0, CLCG_BICG_SYM = 1, CLCG_CGS = 2, CLCG_BICGSTAB = 3, CLCG_TFQMR = 4,
-       CLCG_PCG = 5, CLCG_PBICG = 6 };
+typedef enum clcg_solver_enum { CLCG_BICG = 0, CLCG_BICG_SYM = 1, CLCG_CGS = 2, CLCG_BICGSTAB = 3, CLCG_TFQMR = 4,
+                                CLCG_PCG = 5, CLCG_PBICG = 6 } clcg_solver_enum;
 /* util.h:69-90 */
 enum {
     LCG_SUCCESS = 0, LCG_CONVERGENCE = 0, LCG_STOP = 1, LCG_ALREADY_OPTIMIZIED = 2,
@@ -193,6 +193,23 @@ int lcg_hip_csr_set_kernel(lcg_hip_csr_t A, int variant);
  * span < 2^21 columns), 0 never (frees the packed copy), 1 whenever eligible.  LCG_HIP_PACKED=0/1
  * overrides for the whole process. */
 int lcg_hip_csr_set_packed(lcg_hip_csr_t A, int mode);
+/* Two-pass "binned" A.x for matrices whose columns are scattered over more of x than any cache holds (the
+ * arbitrary user CSR of sample8.cu:96-103 at its worst): pass 1 expands x into entry order with a 64 KB slice
+ * of x in LDS per workgroup, pass 2 streams val and the expanded x and sums the rows in LDS (one wavefront per
+ * 2048 rows, ds_add_f64) -- 28.5 streamed bytes per entry instead of 12 + a cache line per gather.  The plan
+ * (re-ordered copy of the matrix: +26.5 B per entry) is built on the device at the first product.
+ * mode: -1 automatic (real matrices of >= 4M entries and >= 1M columns whose 64-row blocks span on average
+ * >= 2^21 columns; LCG_HIP_BINNED_SPAN changes that threshold), 0 never (frees the plan), 1 whenever eligible.
+ * LCG_HIP_BINNED=0/1 overrides for the whole process.  y differs from the row-block kernels' y in the last
+ * bits (products are rounded before the add); it is bit-identical from call to call and from plan to plan. */
+int lcg_hip_csr_set_binned(lcg_hip_csr_t A, int mode);
+/* Why A has (or has not) a binned plan: "ready", or the reason it is not used (static string). */
+const char *lcg_hip_csr_binned_status(lcg_hip_csr_t A);
+/* Name of the kernel family the latest product with A used (static string; "" before the first product). */
+const char *lcg_hip_csr_last_kernel(lcg_hip_csr_t A);
+/* Bytes the latest product's kernels stream per call by construction when that is not the CSR formula
+ * (binned product: both passes, x slices and y); 0 otherwise. */
+int64_t lcg_hip_csr_last_traffic_model(lcg_hip_csr_t A);
 /* Extract the diagonal and keep its reciprocal for lcg_hip_jacobi_mx
  * (lcg_smDcsr_get_diagonal algebra_cuda.cu:40-57,85-92; clcg_smZcsr_get_diagonal
  * lcg_complex_cuda.cu:46-63).  diag_out (device, n values) may be NULL. */
@@ -232,6 +249,17 @@ int clcg_hip_vecdiv(int n, const double *a, const double *b, double *c);       /
  * GLOBAL column indices. band > 0: banded variant, band == 0: scrambled affine maps. */
 int lcg_hip_csr_generate(lcg_hip_csr_t *A, int64_t n, int npairs, int64_t band, int symmetric,
                          uint64_t seed, double diag_shift, int64_t r0, int64_t r1);
+/* The same family with the column pattern named (twin: orc_gen_init_ex):
+ *   LCG_HIP_GEN_SCRAMBLED        columns (a_k*i + c_k) mod n and the inverse maps: anywhere in the matrix
+ *   LCG_HIP_GEN_DIAGONALS        columns i +- c_k, the SAME npairs offsets c_k <= band in every row
+ *                                (2*npairs constant diagonals: a DIA matrix stored as CSR)
+ *   LCG_HIP_GEN_ROW_RANDOM_BAND  every row draws its own columns inside (i - band, i + band): rows are cut into
+ *                                blocks of the largest power of two <= band/2 and map k sends block b onto block
+ *                                b+1 by a keyed bijection of the in-block position (so the mirror entry is
+ *                                computable and A stays symmetric without a transpose) */
+enum { LCG_HIP_GEN_SCRAMBLED = 0, LCG_HIP_GEN_DIAGONALS = 1, LCG_HIP_GEN_ROW_RANDOM_BAND = 2 };
+int lcg_hip_csr_generate_ex(lcg_hip_csr_t *A, int64_t n, int npairs, int pattern, int64_t band, int symmetric,
+                            uint64_t seed, double diag_shift, int64_t r0, int64_t r1);
 int lcg_hip_gen_xtrue(int64_t n, uint64_t seed, int64_t r0, int64_t r1, double *x_dev);
 /* 5-point Laplacian on an nx x ny grid (BASELINE.json config 2), rows [r0,r1). */
 int lcg_hip_csr_laplace2d(lcg_hip_csr_t *A, int nx, int ny, int64_t r0, int64_t r1);

@@ -1,6 +1,6 @@
 // lcg_solver_classes.hpp -- liblcg's class front ends (solver.h:32-283, solver.cpp:33-310) over
 // the drop-in entry points: derive, override AxProduct / MxProduct (and Progress if wanted), call
-// Minimize / MinimizePreconditioned.  Same member names, defaults and reporting behaviour;
+// Minimize / MinimizePreconditioned / MinimizeConstrained.  Same member names, defaults and reporting behaviour;
 // as everywhere in this library the vectors handed to AxProduct / MxProduct / Progress are DEVICE
 // pointers and work is enqueued on lcg_hip_get_stream().
 #ifndef LCG_SOLVER_CLASSES_HPP
@@ -45,6 +45,13 @@ public:
     {   // solver.cpp:127-168
         run([&](lcg_progress_ptr P) { return lcg_solver_preconditioned(_AxProduct, _MxProduct, P, m, b, x_size, &param_, this, solver_id); },
             "PCG", verbose, er_throw);
+    }
+
+    void MinimizeConstrained(lcg_float *m, const lcg_float *b, const lcg_float *low, const lcg_float *hig, int x_size,
+                             lcg_solver_enum solver_id = LCG_PG, bool verbose = true, bool er_throw = false)
+    {   // solver.h:174-176, solver.cpp:171-212 (the report names PG-CG / SPG-CG, anything else "Unknown")
+        run([&](lcg_progress_ptr P) { return lcg_solver_constrained(_AxProduct, P, m, b, low, hig, x_size, &param_, this, solver_id); },
+            solver_id == LCG_PG ? "PG-CG" : (solver_id == LCG_SPG ? "SPG-CG" : "Unknown"), verbose, er_throw);
     }
 
     // thunks handed to the C entry points (solver.h:51-54,73-76,98-102)

@@ -69,6 +69,10 @@ SIGNATURES = {
     "lcg_hip_csr_arrays": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "lcg_hip_csr_set_kernel": (C.c_int, [vp, C.c_int]),
     "lcg_hip_csr_set_packed": (C.c_int, [vp, C.c_int]),
+    "lcg_hip_csr_set_binned": (C.c_int, [vp, C.c_int]),
+    "lcg_hip_csr_binned_status": (C.c_char_p, [vp]),
+    "lcg_hip_csr_last_kernel": (C.c_char_p, [vp]),
+    "lcg_hip_csr_last_traffic_model": (C.c_int64, [vp]),
     "lcg_hip_csr_build_jacobi": (C.c_int, [vp, vp]),
     "lcg_hip_csr_ax": (None, [vp, vp, vp, C.c_int]),
     "lcg_hip_jacobi_mx": (None, [vp, vp, vp, C.c_int]),
@@ -86,6 +90,7 @@ SIGNATURES = {
     "clcg_hip_axpy": (C.c_int, [C.c_int, c_double_p, vp, vp]),
     "clcg_hip_vecdiv": (C.c_int, [C.c_int, vp, vp, vp]),
     "lcg_hip_csr_generate": (C.c_int, [C.POINTER(vp), C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_double, C.c_int64, C.c_int64]),
+    "lcg_hip_csr_generate_ex": (C.c_int, [C.POINTER(vp), C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_double, C.c_int64, C.c_int64]),
     "lcg_hip_gen_xtrue": (C.c_int, [C.c_int64, C.c_uint64, C.c_int64, C.c_int64, vp]),
     "lcg_hip_csr_laplace2d": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int64, C.c_int64]),
     "lcg_hip_comm_unique_id": (C.c_int, [vp]),

@@ -18,6 +18,7 @@ from ._lib import CAXFUNC, CPROGRESS, AXFUNC, PROGRESS, ClcgPara, LcgPara  # noq
 LCG_CG, LCG_PCG, LCG_CGS, LCG_BICGSTAB, LCG_BICGSTAB2, LCG_PG, LCG_SPG = range(7)
 CLCG_BICG, CLCG_BICG_SYM, CLCG_CGS, CLCG_BICGSTAB, CLCG_TFQMR, CLCG_PCG, CLCG_PBICG = range(7)
 MEM_HOST, MEM_DEVICE = 0, 1
+GEN_SCRAMBLED, GEN_DIAGONALS, GEN_ROW_RANDOM_BAND = 0, 1, 2
 
 
 class LcgHipError(RuntimeError):
@@ -98,11 +99,15 @@ class CsrMatrix:
         return cls(h.value, n, is_c)
 
     @classmethod
-    def generate(cls, n, npairs=16, band=0, symmetric=True, seed=1, diag_shift=0.01, r0=0, r1=None):
+    def generate(cls, n, npairs=16, band=0, symmetric=True, seed=1, diag_shift=0.01, r0=0, r1=None, pattern=None):
+        """pattern: GEN_SCRAMBLED, GEN_DIAGONALS (offsets <= band, the same in every row), GEN_ROW_RANDOM_BAND
+        (columns within +-band drawn per row); None = DIAGONALS when band > 0 else SCRAMBLED."""
         lib = L.load()
         r1 = n if r1 is None else r1
+        if pattern is None:
+            pattern = GEN_DIAGONALS if band > 0 else GEN_SCRAMBLED
         h = C.c_void_p()
-        _chk(lib.lcg_hip_csr_generate(C.byref(h), n, npairs, band, int(symmetric), seed, diag_shift, r0, r1), "csr_generate")
+        _chk(lib.lcg_hip_csr_generate_ex(C.byref(h), n, npairs, pattern, band, int(symmetric), seed, diag_shift, r0, r1), "csr_generate")
         return cls(h.value, r1 - r0, False)
 
     @classmethod

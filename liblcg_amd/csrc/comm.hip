@@ -104,6 +104,7 @@ struct Xg {
     long long timeout_ticks = 2000000000LL;     // 20 s of the 100 MHz wall clock
 };
 static Xg g_xg;
+static unsigned long long g_xg_generation = 0;  // connections made so far: a Direct plan belongs to exactly one
 constexpr size_t XG_BYTES = sizeof(double) * 2 * XG_MAXP * XG_SLOT;
 
 static bool xg_world(int *P, int *me)
@@ -395,6 +396,7 @@ struct Direct {
     size_t half = 0;                    // doubles per half of recv
     unsigned long long calls = 0;       // A.x calls made with this matrix (same on every rank)
     bool uses_mailbox = true;           // plans point into the mailbox state (false for the self-loop rehearsal)
+    unsigned long long generation = 0;  // mailbox connection the plans were made under (their fail word lives there)
     int nnb = 0;
     int nb_rank[XG_MAXSEG];
     double *nb_recv[XG_MAXSEG];         // neighbour's recv as mapped here
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(VB) void k_push(PushPlan pp) { push_block(pp, block
 // the gather buffer (block b moves chunk b; 8-byte system-scope loads, coalesced).
 __global__ __launch_bounds__(VB) void k_recv(WaitPlan wp, PushPlan cp, DevState *st)
 {
-    if (!wait_flags(wp)) {
+    if (!wait_flags<true>(wp)) {
         if (st && blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->status = ST_COMM; }
         return;
     }
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ r
                                                const V *__restrict__ xfull, V *__restrict__ y, const int *done,
                                                WaitPlan wp = WaitPlan(), DevState *st = nullptr)
 {
-    if (LAND && !wait_flags(wp)) {
+    if (LAND && !wait_flags<false>(wp)) {
         if (st && blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->status = ST_COMM; }
         return;
     }
@@ -640,6 +642,7 @@ static int direct_setup(lcg_hip_csr *A)
     pp.nblocks = nb > 0 ? nb : (pp.nflag > 0 ? 1 : 0);     // flags go out even when no data does
     D->wait.timeout_ticks = xb.timeout_ticks;
     D->wait.fail = xb.fail;
+    D->generation = g_xg_generation;
     direct_copy_plan(A, D);
     return 0;
 }
@@ -709,6 +712,7 @@ int dist_split(lcg_hip_csr *A, int64_t n_global, int nranks, int rank)
     if (rc) return rc;
     rc = alloc_cols(A->loc, n, nl, A->is_complex); if (rc) return rc;
     rc = alloc_cols(A->rem, n, nr, A->is_complex); if (rc) return rc;
+    A->loc.n_cols = n; A->rem.n_cols = rpr * nranks;
     if (A->is_complex)
         hipLaunchKernelGGL((k_split_fill<double2>), dim3(g), dim3(VB), 0, c.stream, n, (long)row0, (long)(row0 + n), A->main.rowptr,
                            A->main.col, reinterpret_cast<const double2 *>(A->main.val), A->loc.rowptr, A->loc.col,
@@ -755,10 +759,24 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
     Ctx &c = ctx();
     const size_t w = A->is_complex ? 2 : 1;
     const int *done = c.in_solve ? &c.state->done : nullptr;
+    if (A->dist_mode < 0) {
+        c.err = "this matrix's exchange could not be set up (lcg_hip_csr_distribute failed): distribute it again under another mode";
+        return LCG_HIP_E_COMM;
+    }
+    if (A->dist_mode != 2 && !g_comm.comm && world_size() > 1) {
+        // mailbox-only world: modes 0 and 1 have nothing to move x with -- a product over a stale gather buffer is not an answer
+        c.err = "modes 0 and 1 move x with RCCL: no communicator (lcg_hip_comm_init)";
+        return LCG_HIP_E_COMM;
+    }
+    if (A->dist_mode == 2 && !A->direct) {
+        c.err = "direct exchange without a plan (lcg_hip_csr_distribute(A, n, 2) did not succeed)";
+        return LCG_HIP_E_COMM;
+    }
     if (A->dist_mode == 2 && A->direct) {
         // one stream, no collective: [push blocks + local product] | [wait for flags + remote product]
-        if (static_cast<Direct *>(A->direct)->uses_mailbox && !g_xg.connected) {
-            c.err = "direct exchange: the mailboxes were disconnected while this matrix still uses them (distribute it again)";
+        if (static_cast<Direct *>(A->direct)->uses_mailbox &&
+            (!g_xg.connected || static_cast<Direct *>(A->direct)->generation != g_xg_generation)) {
+            c.err = "direct exchange: the mailboxes were disconnected (or connected anew) while this matrix still uses them (distribute it again)";
             return LCG_HIP_E_COMM;
         }
         PushPlan pp, cp; WaitPlan wp;
@@ -939,15 +957,16 @@ int lcg_hip_csr_distribute(lcg_hip_csr_t A, int64_t n_global, int mode)
         ctx().err = "modes 0 and 1 move x with RCCL: no communicator (lcg_hip_comm_init)";
         return LCG_HIP_E_COMM;
     }
-    A->dist_mode = mode;
+    // the mode is recorded only once the split and the plan stand; until then (and after a failure) the handle
+    // refuses products (dist_spmv) instead of running an exchange it does not have
     int rc = dist_split(A, n_global, world_size(), world_rank());
-    if (rc) return rc;
+    if (rc) return rc;              // a rejected shard leaves the handle as it was (dist_split validates before it frees)
+    A->dist_mode = -1;
     if (mode == 1 && g_comm.comm) rc = halo_setup(A);
-    if (mode == 2) {
-        rc = direct_setup(A);
-        if (rc) A->dist_mode = 0;       // split stays; the caller distributes again under another mode
-    }
-    return rc;
+    if (mode == 2) rc = direct_setup(A);
+    if (rc) return rc;              // split stays; the caller distributes again under another mode
+    A->dist_mode = mode;
+    return 0;
 }
 
 // entries of x this rank receives per A.x (doubles; complex counts twice): plan volume
@@ -1120,6 +1139,7 @@ int lcg_hip_p2p_connect(int nranks, int rank, const void *handles)
     HIPCHK(hipDeviceSynchronize());
     if (const char *e = std::getenv("LCG_HIP_P2P_TIMEOUT_MS")) g_xg.timeout_ticks = std::max(1LL, atoll(e)) * 100000LL;
     g_xg.P = nranks; g_xg.me = rank; g_xg.connected = true;
+    g_xg_generation++;
     return 0;
 }
 

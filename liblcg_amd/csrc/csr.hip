@@ -314,7 +314,7 @@ template <bool PUSH, int NS, int BITS>
 __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__ rowptr, const v4i *__restrict__ packed,
                                                   const int *__restrict__ pofs, const int *__restrict__ pbase,
                                                   const double *__restrict__ val, const double *__restrict__ x,
-                                                  double *__restrict__ y, const int *done, PushPlan pp)
+                                                  double *__restrict__ y, const int *done, PushPlan pp, int xmode)
 {
     if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
     const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
@@ -391,8 +391,16 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
             c[q] = ok ? cc : 0;         // an empty block never wrote scol[0]: column 0 is always a valid address
             a[q] = sval[ok ? kk - bv : 0];
         }
+        if (xmode == 0) {
 #pragma unroll
-        for (int q = 0; q < UNR; q++) xv[q] = x[c[q]];
+            for (int q = 0; q < UNR; q++) xv[q] = x[c[q]];
+        } else if (xmode == 1) {        // LAB: non-temporal gathers
+#pragma unroll
+            for (int q = 0; q < UNR; q++) xv[q] = __builtin_nontemporal_load(x + c[q]);
+        } else {                        // LAB: L1-bypassing (sc1) gathers
+#pragma unroll
+            for (int q = 0; q < UNR; q++) xv[q] = __hip_atomic_load(const_cast<double *>(x) + c[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #pragma unroll
         for (int q = 0; q < UNR; q++) acc = (k + q * T < re) ? fma(a[q], xv[q], acc) : acc;   // select, not a zero product: same bits as the plain loop
         k += UNR * T;
@@ -473,12 +481,66 @@ static bool packed_ready(const CsrPart &P, hipStream_t s)
     return true;
 }
 
+// ---- scattered columns: which matrices take the two-pass binned product (csr_binned.hip) -----------------
+// mean column span (largest - smallest column) of the blocks of 64 rows
+__global__ __launch_bounds__(64) void k_span_sum(int n, const int *__restrict__ rowptr, const int *__restrict__ col, unsigned long long *sum)
+{
+    const long row0 = (long)blockIdx.x * PK_R;
+    const int r1 = (int)min((long)n, row0 + PK_R);
+    const int s = rowptr[row0], e = rowptr[r1];
+    int lo = 0x7fffffff, hi = 0;
+    for (int k = s + threadIdx.x; k < e; k += 64) { const int c = col[k]; lo = min(lo, c); hi = max(hi, c); }
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); }
+    if (threadIdx.x == 0 && e > s) atomicAdd(sum, (unsigned long long)(hi - lo));
+}
+
+static double span_threshold()
+{   // LCG_HIP_BINNED_SPAN: mean block span (columns) from which the automatic choice takes the binned product
+    static const double v = [] { const char *e = std::getenv("LCG_HIP_BINNED_SPAN"); return e ? atof(e) : (double)(1 << 19); }();
+    return v;
+}
+
+// true when P's products go through the binned format (plan built here on first use)
+static bool binned_chosen(const CsrPart &P, hipStream_t s)
+{
+    if (P.bn_state != 0) return P.bn_state > 0;
+    static const int env = [] { const char *e = std::getenv("LCG_HIP_BINNED"); return e ? atoi(e) : -1; }();
+    const int mode = env >= 0 ? env : P.bn_mode;
+    if (mode == 0 || P.n_cols <= 0 || P.nnz <= 0) { P.bn_state = -1; P.bn_why = mode == 0 ? "switched off" : "empty matrix or unknown column count"; return false; }
+    if (mode < 0) {
+        // automatic: only where x cannot sit in a cache (>= 1M columns) and the matrix is worth a second copy
+        if (P.nnz < (1 << 22) || P.n_cols < (1 << 20)) { P.bn_state = -1; P.bn_why = "automatic mode: fewer than 4M entries or 1M columns"; return false; }
+        if (P.mean_span < 0.0) {
+            unsigned long long *d = nullptr, h = 0;
+            const int nb = (P.n_rows + PK_R - 1) / PK_R;
+            bool ok = hipMalloc(&d, sizeof h) == hipSuccess && hipMemsetAsync(d, 0, sizeof h, s) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(k_span_sum, dim3(nb), dim3(64), 0, s, P.n_rows, P.rowptr, P.col, d);
+                ok = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+            }
+            if (d) hipFree(d);
+            if (!ok) { (void)hipGetLastError(); P.bn_state = -1; return false; }
+            P.mean_span = (double)h / nb;
+        }
+        if (P.mean_span < span_threshold()) { P.bn_state = -1; P.bn_why = "automatic mode: the row blocks' mean column span is below the threshold"; return false; }
+    }
+    const int rc = binned_ready(P, s);      // sets bn_state
+    if (rc <= 0) { P.bn_state = -1; return false; }
+    return true;
+}
+
 template <class V, bool ACC, bool PUSH = false>
 static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V *x, V *y, hipStream_t s,
                          const int *done, const PushPlan &pp = PushPlan())
 {
     const int n = P.n_rows;
     const unsigned xb = PUSH ? (unsigned)pp.nblocks : 0u;       // pushing blocks in front of the grid
+    if constexpr (sizeof(V) == 8 && !ACC && !PUSH) {
+        if (n > 0 && (variant == 0 || variant == -1) && binned_chosen(P, s)) {
+            P.last_kernel = "k_bin_expand + k_bin_reduce (two-pass binned product, x and row sums in LDS)";
+            return binned_launch(P, reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), s, done);
+        }
+    }
     if (n == 0) {
         if (PUSH && xb > 0) {       // nothing to multiply, but the neighbours still wait for x and the flags
             hipLaunchKernelGGL((k_spmv_wave<V, 1, ACC, PUSH>), dim3(xb), dim3(VB), 0, s, 0, P.rowptr, P.col,
@@ -519,10 +581,11 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
                 // gathers per lane in the first batch: enough for the longest row when that is 9..12 per lane
                 const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);
                 const int ns = per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
+                static const int xmode = [] { const char *e = std::getenv("LCG_HIP_X_LOAD"); return e ? atoi(e) : 0; }();   // LAB
 #define PK_LAUNCH(NSS, BB)                                                                                          \
         hipLaunchKernelGGL((k_spmv_ldsp<PUSH, NSS, BB>), dim3((n + PK_R - 1) / PK_R + xb), dim3(VB), 0, s, n, P.rowptr, \
                            static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, reinterpret_cast<const double *>(val), \
-                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, pp)
+                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, pp, xmode)
 #define PK_CASE(NSS)                                                                                                \
     case NSS:                                                                                                       \
         if (P.pk_bits == 18) PK_LAUNCH(NSS, 18); else PK_LAUNCH(NSS, 21);                                          \
@@ -531,6 +594,7 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
 #undef PK_LAUNCH
 #undef PK_CASE
                 HIPCHK(hipGetLastError());
+                P.last_kernel = P.pk_bits == 18 ? "k_spmv_ldsp (LDS-staged, 18-bit packed columns)" : "k_spmv_ldsp (LDS-staged, 21-bit packed columns)";
                 return 0;
             }
         }
@@ -548,6 +612,7 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
         default: return fail(hipErrorInvalidValue, "bad LDS A.x rows-per-block", __FILE__, __LINE__);
         }
 #undef LDS_CASE
+        P.last_kernel = onewin ? "k_spmv_lds1 (LDS-staged CSR)" : "k_spmv_ldsw (LDS-staged CSR, windowed)";
     } else {
 #define WAVE_CASE(TT)                                                                                  \
     case TT: {                                                                                         \
@@ -560,6 +625,7 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
         default: return fail(hipErrorInvalidValue, "bad A.x lanes-per-row", __FILE__, __LINE__);
         }
 #undef WAVE_CASE
+        P.last_kernel = "k_spmv_wave (lanes per row, shuffle reduction)";
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -718,7 +784,8 @@ int device_exclusive_scan(int n, const int *counts, int *rowptr, hipStream_t s, 
 // Bit-for-bit twin of oracle/csr_oracle.c (orc_gen_*): integer hashing, ascending columns,
 // diagonal = sum of |off-diagonals| in column order + shift.
 struct GenParams {
-    long n; int npairs; long a[16], ainv[16], c[16]; int banded, symmetric; unsigned long long seed; double shift;
+    long n; int npairs; long a[16], ainv[16], c[16]; int banded /* pattern 0 | 1 | 2 */, symmetric; unsigned long long seed; double shift;
+    int wb_log2;
 };
 
 __host__ __device__ inline unsigned long long splitmix64(unsigned long long x)
@@ -740,12 +807,55 @@ __device__ inline unsigned long long mulmod(unsigned long long a, unsigned long 
     return (unsigned long long)(((unsigned __int128)a * b) % n);
 }
 
+// pattern 2 (row-random band): keyed bijection of [0, 2^L), twin of blk_fwd / blk_inv in oracle/csr_oracle.c
+__device__ inline unsigned long long inv_pow2(unsigned long long a)
+{
+    unsigned long long x = a;
+    for (int it = 0; it < 6; it++) x *= 2 - a * x;
+    return x;
+}
+__device__ inline void blk_keys(const GenParams &g, int k, long b, unsigned long long *a1, unsigned long long *c1, unsigned long long *a2)
+{
+    const unsigned long long mask = (1ull << g.wb_log2) - 1;
+    const unsigned long long key = mix3((unsigned long long)g.c[k], (unsigned long long)b, g.seed);
+    *a1 = (key | 1) & mask; *c1 = (key >> 21) & mask; *a2 = ((key >> 42) | 1) & mask;
+    if (g.wb_log2 == 0) { *a1 = 1; *a2 = 1; }
+}
+__device__ inline unsigned long long blk_fwd(const GenParams &g, int k, long b, unsigned long long u)
+{
+    const int L = g.wb_log2, sh = (L + 1) / 2;
+    const unsigned long long mask = (1ull << L) - 1;
+    unsigned long long a1, c1, a2; blk_keys(g, k, b, &a1, &c1, &a2);
+    unsigned long long x = (u * a1 + c1) & mask;
+    if (sh) x ^= x >> sh;
+    x = (x * a2) & mask;
+    if (sh) x ^= x >> sh;
+    return x;
+}
+__device__ inline unsigned long long blk_inv(const GenParams &g, int k, long b, unsigned long long y)
+{
+    const int L = g.wb_log2, sh = (L + 1) / 2;
+    const unsigned long long mask = (1ull << L) - 1;
+    unsigned long long a1, c1, a2; blk_keys(g, k, b, &a1, &c1, &a2);
+    unsigned long long x = y;
+    if (sh) x ^= x >> sh;
+    x = (x * inv_pow2(a2)) & mask;
+    if (sh) x ^= x >> sh;
+    return ((x - c1) * inv_pow2(a1)) & mask;
+}
+
 __device__ int gen_row_cols(const GenParams &g, long i, long *out)
 {
     int cnt = 0;
     for (int k = 0; k < g.npairs; k++) {
         long j[2];
-        if (g.banded) { j[0] = i + g.c[k]; j[1] = i - g.c[k]; }
+        if (g.banded == 2) {
+            const int L = g.wb_log2;
+            const long b = i >> L;
+            const unsigned long long u = (unsigned long long)i & ((1ull << L) - 1);
+            j[0] = ((b + 1) << L) + (long)blk_fwd(g, k, b, u);
+            j[1] = b >= 1 ? ((b - 1) << L) + (long)blk_inv(g, k, b - 1, u) : -1;
+        } else if (g.banded) { j[0] = i + g.c[k]; j[1] = i - g.c[k]; }
         else {
             j[0] = (long)((mulmod((unsigned long long)g.a[k], (unsigned long long)i, (unsigned long long)g.n) + (unsigned long long)g.c[k]) % (unsigned long long)g.n);
             long d = i - g.c[k]; if (d < 0) d += g.n;
@@ -810,13 +920,20 @@ static long modinv(long a, long n)
     return t < 0 ? t + n : t;
 }
 
-static void gen_init(GenParams &g, long n, int npairs, long band, int symmetric, unsigned long long seed, double shift)
-{   // same draws as orc_gen_init
+static void gen_init(GenParams &g, long n, int npairs, int pattern, long band, int symmetric, unsigned long long seed, double shift)
+{   // same draws as orc_gen_init_ex
     std::memset(&g, 0, sizeof g);
-    g.n = n; g.npairs = npairs > 16 ? 16 : npairs; g.banded = band > 0; g.symmetric = symmetric; g.seed = seed; g.shift = shift;
+    g.n = n; g.npairs = npairs > 16 ? 16 : npairs; g.banded = pattern; g.symmetric = symmetric; g.seed = seed; g.shift = shift;
     unsigned long long s = splitmix64(seed ^ 0xA5A5A5A55A5A5A5Aull);
     if (band > n - 1) band = n - 1;
     if (band < 1) band = 1;
+    if (pattern == 2) {
+        int L = 0;
+        while (L < 30 && (2L << L) <= band / 2) L++;
+        g.wb_log2 = L;
+        for (int k = 0; k < g.npairs; k++) { s = splitmix64(s); g.a[k] = 1; g.ainv[k] = 1; g.c[k] = (long)(s >> 1); }
+        return;
+    }
     for (int k = 0; k < g.npairs; k++) {
         if (g.banded) {
             long c = 1;
@@ -920,6 +1037,7 @@ static int alloc_part(CsrPart &P, int n_rows, long nnz, bool cplx)
 
 void free_part(CsrPart &P)
 {
+    binned_free(P);
     if (P.owned) { hipFree(P.rowptr); hipFree(P.col); hipFree(P.val); }
     if (P.pk_base) hipFree(P.pk_base);
     if (P.pk_ofs) hipFree(P.pk_ofs);
@@ -989,6 +1107,7 @@ int op_part(lcg_hip_csr *A, int layout, int conjugate, const CsrPart **out)
     const long nnz = A->main.nnz;
     int rc = alloc_part(T, n, nnz, A->is_complex);
     if (rc) return rc;
+    T.n_cols = n;
     if (!layout) {      // conj(A): same structure
         HIPCHK(hipMemcpyAsync(T.rowptr, A->main.rowptr, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToDevice, c.stream));
         HIPCHK(hipMemcpyAsync(T.col, A->main.col, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToDevice, c.stream));
@@ -1041,10 +1160,12 @@ int lcg_hip_csr_create(lcg_hip_csr_t *out, int n_rows, int n_cols, int64_t nnz, 
     A->mean_row = (double)nnz / n_rows;
     if (mem == LCG_HIP_MEM_DEVICE && adopt) {
         A->main.n_rows = n_rows; A->main.nnz = nnz; A->main.owned = false; A->main.padded = adopt == 2;
+        A->main.n_cols = n_cols;
         A->main.rowptr = const_cast<int *>(rowptr); A->main.col = const_cast<int *>(col); A->main.val = const_cast<double *>(val);
     } else {
         rc = alloc_part(A->main, n_rows, nnz, A->is_complex);
         if (rc) { delete A; return rc; }
+        A->main.n_cols = n_cols;
         const hipMemcpyKind kind = mem == LCG_HIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
         hipError_t e = hipMemcpyAsync(A->main.rowptr, rowptr, sizeof(int) * ((size_t)n_rows + 1), kind, c.stream);
         if (e == hipSuccess && nnz) e = hipMemcpyAsync(A->main.col, col, sizeof(int) * (size_t)nnz, kind, c.stream);
@@ -1067,6 +1188,7 @@ int lcg_hip_csr_from_coo(lcg_hip_csr_t *out, int n, int64_t nnz, const int *row,
     A->n_rows = n; A->n_cols = n; A->is_complex = is_complex != 0; A->mean_row = (double)nnz / n;
     rc = alloc_part(A->main, n, nnz, A->is_complex);
     if (rc) { delete A; return rc; }
+    A->main.n_cols = n;
     int *d_row = nullptr, *d_flag = nullptr;
     const hipMemcpyKind kind = mem == LCG_HIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     auto bail = [&](int code) { if (d_row) hipFree(d_row); if (d_flag) hipFree(d_flag); free_part(A->main); delete A; return code; };
@@ -1186,6 +1308,36 @@ int lcg_hip_csr_set_packed(lcg_hip_csr_t A, int mode)
     return 0;
 }
 
+int lcg_hip_csr_set_binned(lcg_hip_csr_t A, int mode)
+{
+    if (!A || mode < -1 || mode > 1) return LCG_HIP_E_ARG;
+    for (CsrPart *P : {&A->main, &A->loc}) {
+        P->bn_mode = mode;
+        if (mode == 0) binned_free(*P);     // gives the plan's memory back
+        else if (P->bn_state < 0) P->bn_state = 0;     // decide again at the next product
+    }
+    return 0;
+}
+
+const char *lcg_hip_csr_last_kernel(lcg_hip_csr_t A)
+{
+    if (!A) return "";
+    return A->distributed ? A->loc.last_kernel : A->main.last_kernel;
+}
+
+const char *lcg_hip_csr_binned_status(lcg_hip_csr_t A)
+{
+    if (!A) return "";
+    return A->distributed ? A->loc.bn_why : A->main.bn_why;
+}
+
+int64_t lcg_hip_csr_last_traffic_model(lcg_hip_csr_t A)
+{
+    if (!A) return 0;
+    const CsrPart &P = A->distributed ? A->loc : A->main;
+    return P.bn_state > 0 ? binned_traffic_bytes(P) : 0;
+}
+
 int lcg_hip_csr_build_jacobi(lcg_hip_csr_t A, double *diag_out)
 {
     if (!A) return LCG_HIP_E_ARG;
@@ -1205,17 +1357,21 @@ int lcg_hip_csr_build_jacobi(lcg_hip_csr_t A, double *diag_out)
 }
 
 // ---- callbacks -------------------------------------------------------------------------------
+// The callback types return void (lcg.h:37-38, clcg.h:40-41): a failure is parked in Ctx::ax_rc, where the solver
+// loop picks it up right after the call (driver.hpp: timed_ax / checked_mx) and ends the solve with that code.
+static inline void park(int rc) { if (rc && !ctx().ax_rc) ctx().ax_rc = rc; }
+
 void lcg_hip_csr_ax(void *instance, const double *x, double *y, const int n)
 {
     lcg_hip_csr *A = static_cast<lcg_hip_csr *>(instance);
     (void)n;
-    lcg_hip_spmv(A, x, y);
+    park(lcg_hip_spmv(A, x, y));
 }
 
 void clcg_hip_csr_ax(void *instance, const double *x, double *y, const int n, int layout, int conjugate)
 {
     (void)n;
-    lcg_hip_spmv_op(static_cast<lcg_hip_csr *>(instance), x, y, layout, conjugate);
+    park(lcg_hip_spmv_op(static_cast<lcg_hip_csr *>(instance), x, y, layout, conjugate));
 }
 
 int lcg_hip_spmv_op(lcg_hip_csr_t A, const double *x, double *y, int layout, int conjugate)
@@ -1232,7 +1388,7 @@ int lcg_hip_spmv_op(lcg_hip_csr_t A, const double *x, double *y, int layout, int
 
 void lcg_hip_jacobi_mx(void *instance, const double *x, double *z, const int n)
 {
-    jacobi_launch(static_cast<lcg_hip_csr *>(instance), x, z, n, ctx().stream);
+    park(jacobi_launch(static_cast<lcg_hip_csr *>(instance), x, z, n, ctx().stream));
 }
 
 int lcg_hip_spmv(lcg_hip_csr_t A, const double *x, double *y)
@@ -1286,16 +1442,24 @@ static int finish_generated(lcg_hip_csr *A, int nloc, long r0, int *counts, hipS
     HIPCHK(hipStreamSynchronize(s));
     A->mean_row = (double)total / nloc;
     A->row0 = r0;
+    A->main.n_cols = A->n_cols;
     return 0;
 }
 
 int lcg_hip_csr_generate(lcg_hip_csr_t *out, int64_t n, int npairs, int64_t band, int symmetric, uint64_t seed,
                          double diag_shift, int64_t r0, int64_t r1)
 {
-    if (!out || n <= 1 || n > 0x7fffffffLL || r0 < 0 || r1 > n || r1 <= r0 || npairs < 1) return LCG_HIP_E_ARG;
+    return lcg_hip_csr_generate_ex(out, n, npairs, band > 0 ? LCG_HIP_GEN_DIAGONALS : LCG_HIP_GEN_SCRAMBLED, band, symmetric, seed,
+                                   diag_shift, r0, r1);
+}
+
+int lcg_hip_csr_generate_ex(lcg_hip_csr_t *out, int64_t n, int npairs, int pattern, int64_t band, int symmetric, uint64_t seed,
+                            double diag_shift, int64_t r0, int64_t r1)
+{
+    if (!out || n <= 1 || n > 0x7fffffffLL || r0 < 0 || r1 > n || r1 <= r0 || npairs < 1 || pattern < 0 || pattern > 2) return LCG_HIP_E_ARG;
     int rc = ensure_init(); if (rc) return rc;
     Ctx &c = ctx();
-    GenParams g; gen_init(g, n, npairs, band, symmetric, seed, diag_shift);
+    GenParams g; gen_init(g, n, npairs, pattern, band, symmetric, seed, diag_shift);
     const int nloc = (int)(r1 - r0);
     int *counts = nullptr;
     HIPCHK(hipMalloc(&counts, sizeof(int) * (size_t)nloc));

@@ -233,13 +233,15 @@ __device__ __forceinline__ void push_block(const PushPlan &pp, int b)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // all of this lane's stores acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
-        // relaxed on purpose (see above): every block's stores were acknowledged before its ticket, so
-        // whoever draws the last ticket knows all of x has landed; the flags follow it
+        // The ticket is relaxed on purpose (see above): every block's stores were acknowledged before its
+        // ticket, so whoever draws the last ticket knows all of x has landed.  The flags that follow are
+        // RELEASE stores at system scope: one lane per A.x pays for the ordering the memory model asks for
+        // (the per-block release fences measured above stay out).
         const unsigned t = __hip_atomic_fetch_add(pp.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == (unsigned)pp.nblocks - 1u) {
             __hip_atomic_store(pp.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int f = 0; f < pp.nflag; f++)
-                __hip_atomic_store(pp.flag[f], pp.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(pp.flag[f], pp.seq, f == 0 ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -248,6 +250,10 @@ __device__ __forceinline__ void push_block(const PushPlan &pp, int b)
 // call's number (they only grow).  No cache maintenance here: flags and landing zone are uncached
 // memory read with system-scope loads, and a block reads the landing zone only after it has seen the
 // flags (an acquire fence per block cost 150 us on a 4000-block grid: it invalidates the whole L2).
+// ACQ: the polling lanes close their wait with ONE acquire load of the flag at system scope (relaxed polls, then
+// the acquire -- polling with acquire loads is 2-3x slower per hop).  k_recv (a few dozen blocks) does; the
+// opt-in landing-direct product (thousands of blocks, every one of them waiting) stays relaxed, as measured.
+template <bool ACQ = false>
 __device__ __forceinline__ bool wait_flags(const WaitPlan &wp)
 {
     __shared__ int wbad;
@@ -256,10 +262,12 @@ __device__ __forceinline__ bool wait_flags(const WaitPlan &wp)
     if (wbad) return false;
     if ((int)threadIdx.x < wp.n) {
         const long long t0 = wall_clock64();
+        bool ok = true;
         while (__hip_atomic_load(wp.flag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < wp.seq) {
             __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > wp.timeout_ticks) { wbad = 1; *wp.fail = 1; break; }
+            if (wall_clock64() - t0 > wp.timeout_ticks) { wbad = 1; *wp.fail = 1; ok = false; break; }
         }
+        if (ACQ && ok) (void)__hip_atomic_load(wp.flag[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
     return wbad == 0;

@@ -28,7 +28,7 @@ struct Driver {
     int enq = 0;       // iteration bodies enqueued
 
     Driver(Ctx &c_, long n_, bool cplx_, int max_it_, double eps_, int abs_diff_)
-        : c(c_), n(n_), cplx(cplx_), max_it(max_it_), abs_diff(abs_diff_), eps(eps_) { c.in_solve = true; }
+        : c(c_), n(n_), cplx(cplx_), max_it(max_it_), abs_diff(abs_diff_), eps(eps_) { c.in_solve = true; c.ax_rc = 0; }
     ~Driver() { c.in_solve = false; }
     Driver(const Driver &) = delete;
 
@@ -108,7 +108,9 @@ struct Driver {
         return 0;
     }
 
-    // A.x callback with optional event timing
+    // A.x callback with optional event timing.  liblcg's callback types return void (lcg.h:37-38), so the built-in
+    // callbacks park their failure (a refused exchange, an RCCL error, a HIP error) in Ctx::ax_rc; it ends the
+    // solve here with that LCG_HIP_E_* code instead of letting the loop run on over a stale product.
     template <class F> int timed_ax(F &&call)
     {
         if (c.profile && (c.ax_seq++ % c.profile_every) == 0 && c.prof_used + 2 <= (int)c.prof_ev.size()) {
@@ -119,8 +121,10 @@ struct Driver {
         } else {
             call();
         }
-        return 0;
+        return c.ax_rc;
     }
+    // same for the preconditioner callback
+    template <class F> int checked_mx(F &&call) { call(); return c.ax_rc; }
 
     // ---- the loop --------------------------------------------------------------------------
     // body(): enqueue one counted iteration.  pfp(residual, t): progress callback or nullptr

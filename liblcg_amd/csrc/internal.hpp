@@ -101,6 +101,7 @@ struct Ctx {
     int last_iters = 0;
     double last_residual = 0.0;
     bool in_solve = false;             // a Driver is alive: A.x may honour DevState::done
+    int ax_rc = 0;                     // first failure of a built-in callback (void by liblcg's typedef) during this solve
     int cg_schedule = 0;               // LCG_HIP_CG_*
     bool profile = false;
     int profile_every = 1;             // time every k-th A.x only (each timed call costs ~2 x 2 us of markers)
@@ -142,6 +143,14 @@ struct CsrPart {
     mutable void *pk_data = nullptr;                        // 16 bytes per group of 6 entries
     mutable int pk_maxrow = 0;                              // longest row (chooses the gather batch of the kernel)
     mutable int pk_bits = 21;                               // width of a packed column: 18 (seven per group) or 21 (six)
+    // two-pass "binned" product for scattered columns (csr_binned.hip), plan built on first use
+    int64_t n_cols = 0;            // columns the part addresses (0 = unknown: never binned)
+    mutable int bn_mode = -1;      // -1 auto (large real matrices whose row blocks span more of x than the L2 holds), 0 never, 1 whenever eligible
+    mutable int bn_state = 0;      // 0 not tried, 1 plan ready, -1 not eligible / not chosen
+    mutable void *bn_plan = nullptr;
+    mutable const char *bn_why = "not tried";   // why the plan is (not) there
+    mutable double mean_span = -1.0;    // mean column span of a 64-row block (-1 = not measured)
+    mutable const char *last_kernel = "";   // name of the kernel family the latest product used
 };
 
 } // namespace lcgh
@@ -180,6 +189,12 @@ int spmv_launch(const CsrPart &P, bool is_complex, int variant, double mean_row,
 int spmv_launch_push(const CsrPart &P, bool is_complex, int variant, double mean_row, const double *x, double *y,
                      hipStream_t s, const int *done_flag, const PushPlan &pp);
 int jacobi_launch(const lcg_hip_csr *A, const double *x, double *z, int n, hipStream_t s);
+// csr_binned.hip
+int binned_ready(const CsrPart &P, hipStream_t s);      // 1 plan ready, 0 not eligible, < 0 failure
+int binned_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done_flag);
+void binned_free(CsrPart &P);
+long binned_traffic_bytes(const CsrPart &P);
+size_t binned_plan_bytes(const CsrPart &P);
 int op_part(lcg_hip_csr *A, int layout, int conjugate, const CsrPart **out);
 
 // comm.hip

@@ -558,7 +558,7 @@ static int solve_cpcg(clcg_hip_axfunc_ptr Afp, clcg_hip_axfunc_ptr Mfp, clcg_hip
 
     TRY(k.ax(m, Ax));                                                   // clcg_cuda.cu:441
     TRY(k.drv.vec(OpZResid{st, Ax, B, r}));                             // :442-443
-    Mfp(inst, r, d, n, 0, 0);                                           // :445
+    TRY(k.drv.checked_mx([&] { Mfp(inst, r, d, n, 0, 0); }));           // :445
     TRY(k.drv.vec(OpZPcgDots{st, m, r, d}));                            // :448-457
     TRY(k.drv.scal(FinZPcg<true>{}));
     int rc = k.run_loop([&]() -> int {
@@ -569,7 +569,7 @@ static int solve_cpcg(clcg_hip_axfunc_ptr Afp, clcg_hip_axfunc_ptr Mfp, clcg_hip
             TRY(k.drv.vec(OpZPcgUpdJacobi{st, m, r, s, d, Ax, inv, {}}));   // :504-516
         } else {
             TRY(k.drv.vec(OpZPcgUpd{st, m, r, d, Ax, {}}));             // :504-505
-            Mfp(inst, r, s, n, 0, 0);                                   // :513
+            TRY(k.drv.checked_mx([&] { Mfp(inst, r, s, n, 0, 0); }));   // :513
             TRY(k.drv.vec(OpZPcgDots{st, m, r, s}));                    // :507-516
         }
         TRY(k.drv.scal(FinZPcg<false>{}));                              // :517
@@ -763,5 +763,6 @@ extern "C" int clcg_hip_solver_preconditioned(clcg_hip_axfunc_ptr Afp, clcg_hip_
 extern "C" void clcg_hip_jacobi_mx(void *instance, const double *x, double *z, const int n, int layout, int conjugate)
 {
     (void)layout; (void)conjugate;
-    jacobi_launch(static_cast<lcg_hip_csr *>(instance), x, z, n, ctx().stream);
+    const int rc = jacobi_launch(static_cast<lcg_hip_csr *>(instance), x, z, n, ctx().stream);
+    if (rc && !ctx().ax_rc) ctx().ax_rc = rc;          // void callback: parked for the loop (driver.hpp: checked_mx)
 }

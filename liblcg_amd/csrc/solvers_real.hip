@@ -455,7 +455,7 @@ static int solve_pcg(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pf
 
     TRY(k.ax(m, Ad));                                                            // lcg.cpp:314
     TRY(k.drv.vec(OpResidual{st, Ad, B, r}, al(Ad) | al(B) | al(r)));            // :317-321
-    Mfp(inst, r, z, n);                                                          // :323
+    TRY(k.drv.checked_mx([&] { Mfp(inst, r, z, n); }));                          // :323
     TRY(k.drv.vec(OpPcgInit2{st, z, m, r, d}, al(z) | al(m) | al(r) | al(d)));   // :325-339
     TRY(k.drv.scal(FinInit{}));
     const uintptr_t a_all = al(m) | al(r) | al(z) | al(d) | al(Ad) | al(invdiag);
@@ -467,7 +467,7 @@ static int solve_pcg(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pf
             TRY(k.drv.vec(OpPcgUpdateJacobi{st, m, r, z, d, Ad, invdiag, 0.0}, a_all));   // :392-414
         } else {
             TRY(k.drv.vec(OpPcgUpdate{st, m, r, d, Ad, 0.0}, a_all));            // :392-397
-            Mfp(inst, r, z, n);                                                  // :399
+            TRY(k.drv.checked_mx([&] { Mfp(inst, r, z, n); }));                  // :399
             TRY(k.drv.vec(OpPcgDots{st, m, r, z}, a_all));                       // :401-414
         }
         TRY(k.drv.scal(FinClose<false>{}));                                      // :415-416

@@ -249,12 +249,29 @@ static int64_t modinv(int64_t a, int64_t n)
 void orc_gen_init(orc_gen *g, int64_t n, int npairs, int64_t band, int symmetric,
                   uint64_t seed, double diag_shift)
 {
+    orc_gen_init_ex(g, n, npairs, band > 0 ? 1 : 0, band, symmetric, seed, diag_shift);
+}
+
+void orc_gen_init_ex(orc_gen *g, int64_t n, int npairs, int pattern, int64_t band, int symmetric,
+                     uint64_t seed, double diag_shift)
+{
     memset(g, 0, sizeof *g);
-    g->n = n; g->npairs = npairs > 16 ? 16 : npairs; g->banded = band > 0;
+    g->n = n; g->npairs = npairs > 16 ? 16 : npairs; g->banded = pattern;
     g->symmetric = symmetric; g->seed = seed; g->diag_shift = diag_shift;
     uint64_t s = splitmix64(seed ^ 0xA5A5A5A55A5A5A5Aull);
     if (band > n - 1) band = n - 1;
     if (band < 1) band = 1;
+    if (pattern == 2) {
+        /* block = largest power of two <= band/2 (at least 1): offsets stay below 2*block <= band */
+        int L = 0;
+        while (L < 30 && ((int64_t)2 << L) <= band / 2) L++;
+        g->wb_log2 = L;
+        for (int k = 0; k < g->npairs; k++) {
+            s = splitmix64(s);
+            g->a[k] = 1; g->ainv[k] = 1; g->c[k] = (int64_t)(s >> 1);
+        }
+        return;
+    }
     for (int k = 0; k < g->npairs; k++) {
         if (g->banded) {
             /* offsets in [1, band]; k == 0 is the nearest neighbour; redraw a
@@ -279,6 +296,44 @@ void orc_gen_init(orc_gen *g, int64_t n, int npairs, int64_t band, int symmetric
     }
 }
 
+/* pattern 2: keyed bijection of [0, 2^L) (affine step, xor-shift, odd multiplier, xor-shift: every step
+ * is invertible modulo 2^L, and with 2*sh >= L the xor-shift is its own inverse) */
+static uint64_t inv_pow2(uint64_t a)    /* a odd: a^-1 modulo 2^64 (Newton) */
+{
+    uint64_t x = a;
+    for (int it = 0; it < 6; it++) x *= 2 - a * x;
+    return x;
+}
+static void blk_keys(const orc_gen *g, int k, int64_t b, uint64_t *a1, uint64_t *c1, uint64_t *a2)
+{
+    const uint64_t mask = ((uint64_t)1 << g->wb_log2) - 1;
+    const uint64_t key = mix3((uint64_t)g->c[k], (uint64_t)b, g->seed);
+    *a1 = (key | 1) & mask; *c1 = (key >> 21) & mask; *a2 = ((key >> 42) | 1) & mask;
+    if (g->wb_log2 == 0) { *a1 = 1; *a2 = 1; }
+}
+static uint64_t blk_fwd(const orc_gen *g, int k, int64_t b, uint64_t u)
+{
+    const int L = g->wb_log2, sh = (L + 1) / 2;
+    const uint64_t mask = ((uint64_t)1 << L) - 1;
+    uint64_t a1, c1, a2; blk_keys(g, k, b, &a1, &c1, &a2);
+    uint64_t x = (u * a1 + c1) & mask;
+    if (sh) x ^= x >> sh;
+    x = (x * a2) & mask;
+    if (sh) x ^= x >> sh;
+    return x;
+}
+static uint64_t blk_inv(const orc_gen *g, int k, int64_t b, uint64_t y)
+{
+    const int L = g->wb_log2, sh = (L + 1) / 2;
+    const uint64_t mask = ((uint64_t)1 << L) - 1;
+    uint64_t a1, c1, a2; blk_keys(g, k, b, &a1, &c1, &a2);
+    uint64_t x = y;
+    if (sh) x ^= x >> sh;
+    x = (x * inv_pow2(a2)) & mask;
+    if (sh) x ^= x >> sh;
+    return ((x - c1) * inv_pow2(a1)) & mask;
+}
+
 /* candidate columns of row i, deduplicated and sorted; returns their number
  * (diagonal excluded). */
 static int row_cols(const orc_gen *g, int64_t i, int64_t *out)
@@ -286,7 +341,13 @@ static int row_cols(const orc_gen *g, int64_t i, int64_t *out)
     int cnt = 0;
     for (int k = 0; k < g->npairs; k++) {
         int64_t j[2];
-        if (g->banded) {
+        if (g->banded == 2) {
+            const int L = g->wb_log2;
+            const int64_t b = i >> L;
+            const uint64_t u = (uint64_t)i & (((uint64_t)1 << L) - 1);
+            j[0] = ((b + 1) << L) + (int64_t)blk_fwd(g, k, b, u);
+            j[1] = b >= 1 ? ((b - 1) << L) + (int64_t)blk_inv(g, k, b - 1, u) : -1;
+        } else if (g->banded) {
             j[0] = i + g->c[k];
             j[1] = i - g->c[k];
         } else {

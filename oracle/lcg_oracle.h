@@ -187,13 +187,22 @@ typedef struct orc_gen {
     int64_t a[16];      /* multiplier, gcd(a,n)=1 (scrambled) or 1 (banded) */
     int64_t ainv[16];   /* a^-1 mod n */
     int64_t c[16];      /* offset */
-    int     banded;     /* 1: col = i +/- c (clipped, no wrap); 0: col = (a*i+c) mod n and inverse */
+    int     banded;     /* pattern.  0: col = (a*i+c) mod n and inverse ("scrambled");  1: col = i +/- c, the SAME
+                         * offsets for every row (npairs constant diagonals each side, clipped, no wrap);
+                         * 2: row-random band -- rows are cut into blocks of 2^wb_log2, map k sends block b onto
+                         * block b+1 by a keyed bijection of the in-block position, so every row draws its own
+                         * columns within +-2^(wb_log2+1) (c[k] = key of map k) */
     int     symmetric;  /* 1: value depends on {min,max}; 0: on the ordered pair */
     uint64_t seed;
     double  diag_shift; /* A_ii = sum|A_ij| + diag_shift */
+    int     wb_log2;    /* pattern 2 only: log2 of the block size */
 } orc_gen;
 void orc_gen_init(orc_gen *g, int64_t n, int npairs, int64_t band, int symmetric,
-                  uint64_t seed, double diag_shift);
+                  uint64_t seed, double diag_shift);      /* band > 0: pattern 1, else pattern 0 */
+/* pattern as above; band = W: pattern 1 draws offsets in [1,W]; pattern 2 uses blocks of the largest
+ * power of two <= W/2, so that every column of row i lies in (i-W, i+W) */
+void orc_gen_init_ex(orc_gen *g, int64_t n, int npairs, int pattern, int64_t band, int symmetric,
+                     uint64_t seed, double diag_shift);
 /* counts[i-r0] = entries of global row i (diagonal included) for i in [r0,r1) */
 void orc_gen_count(const orc_gen *g, int64_t r0, int64_t r1, int *counts);
 /* fills col/val of rows [r0,r1) given the local rowptr (rowptr[0]=0) */

@@ -46,7 +46,8 @@ class CsrInst(C.Structure):       # orc_csr in lcg_oracle.h
 class Gen(C.Structure):           # orc_gen in lcg_oracle.h
     _fields_ = [("n", C.c_int64), ("npairs", C.c_int), ("a", C.c_int64 * 16),
                 ("ainv", C.c_int64 * 16), ("c", C.c_int64 * 16), ("banded", C.c_int),
-                ("symmetric", C.c_int), ("seed", C.c_uint64), ("diag_shift", C.c_double)]
+                ("symmetric", C.c_int), ("seed", C.c_uint64), ("diag_shift", C.c_double),
+                ("wb_log2", C.c_int)]
 
 
 def default_para(**kw) -> Para:   # util.h:153
@@ -231,10 +232,14 @@ class Oracle:
         return d
 
     # ---- synthetic family -------------------------------------------------
-    def gen_init(self, n, npairs=16, band=0, symmetric=True, seed=1, diag_shift=0.01) -> Gen:
+    def gen_init(self, n, npairs=16, band=0, symmetric=True, seed=1, diag_shift=0.01, pattern=None) -> Gen:
+        """pattern: 0 scrambled, 1 constant diagonals (offsets <= band), 2 row-random band (columns within
+        +-band, drawn per row); None = 1 when band > 0 else 0 (the round-1 call)."""
         g = Gen()
-        self.lib.orc_gen_init(C.byref(g), C.c_int64(n), C.c_int(npairs), C.c_int64(band),
-                              C.c_int(int(symmetric)), C.c_uint64(seed), C.c_double(diag_shift))
+        if pattern is None:
+            pattern = 1 if band > 0 else 0
+        self.lib.orc_gen_init_ex(C.byref(g), C.c_int64(n), C.c_int(npairs), C.c_int(pattern), C.c_int64(band),
+                                 C.c_int(int(symmetric)), C.c_uint64(seed), C.c_double(diag_shift))
         return g
 
     def gen_rows(self, g: Gen, r0=0, r1=None):

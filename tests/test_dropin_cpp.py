@@ -56,3 +56,11 @@ def test_class_wrappers_sample():
     assert abs(int(its["CG"]) - 183) <= 3 and abs(int(its["PCG"]) - 181) <= 3 and 1500 < int(its["TFQMR"]) < 2000
     assert "Solver: CG. Time cost:" in p.stderr and "Solver: TFQMR" in p.stderr
     assert p.stderr.count("Iteration-times: 50\t") == 1     # report interval honoured
+    # LCG_Solver::MinimizeConstrained (solver.h:174-176, solver.cpp:171-212) against the real liblcg's run of the same
+    # box (tests/golden/make_golden.py, box/pg_40 and box/spg_40: 40 iterations, residual 1.2648e-2), silent mode
+    import numpy as np
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "ref_goldens.npz"))
+    box = dict((k, float(r)) for k, r in re.findall(r"^class (S?PG): iterations=40 residual=([0-9.e+-]+)", p.stdout, flags=re.M))
+    for name, tag in (("PG", "pg_40"), ("SPG", "spg_40")):
+        assert abs(box[name] - g[f"box/{tag}/fl"][1]) <= 1e-8 * g[f"box/{tag}/fl"][1], (name, box)

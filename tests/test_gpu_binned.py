@@ -1,0 +1,161 @@
+"""-m gpu: the two-pass binned A.x (liblcg_amd/csrc/csr_binned.hip) for scattered columns -- the arbitrary user CSR
+of the reference's cudaAx callback (sample8.cu:96-103) at its worst -- against the oracle's row-by-row product and
+against the row-block kernels on the same matrix.
+
+Band: the binned product rounds every a*x before adding it and sums a row in column order, the row-block kernels run
+four FMA chains per row and a tree: both are within a few ulp of |A||x| per row, so the test bounds
+|y - y_oracle| <= 1e-13 * (|A| |x|) row by row (a bound relative to max|y| would let a small row be wrong)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def api():
+    from liblcg_amd import api as a
+    assert torch.cuda.is_available()
+    return a
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from liblcg_amd import _lib
+    return _lib.load()
+
+
+def _ragged(rng, n, ncols, max_len, long_rows=()):
+    lens = rng.integers(0, max_len + 1, n)
+    lens[rng.integers(0, n, n // 10)] = 0
+    for r, ln in long_rows:
+        lens[r] = ln
+    rp = np.zeros(n + 1, np.int32); np.cumsum(lens, out=rp[1:])
+    col = rng.integers(0, ncols, rp[-1]).astype(np.int32)
+    return rp, col
+
+
+def _check(api, lib, port, rp, col, val, x, ncols, expect_binned=True):
+    n = len(rp) - 1
+    ref = port.csr_matvec(rp, col, val, x)
+    bound = port.csr_matvec(rp, col, np.abs(val), np.abs(x))
+    A = api.CsrMatrix.from_csr(rp, col, val, n_cols=ncols)
+    xd = torch.from_numpy(x).cuda()
+    y0 = torch.full((n,), 7.0, dtype=torch.float64, device="cuda"); y1 = y0.clone(); y2 = y0.clone()
+    assert lib.lcg_hip_csr_set_binned(A.h, 0) == 0
+    A.spmv(xd, y0); api.synchronize()
+    assert b"bin" not in lib.lcg_hip_csr_last_kernel(A.h)
+    assert lib.lcg_hip_csr_set_binned(A.h, 1) == 0
+    A.spmv(xd, y1); A.spmv(xd, y2); api.synchronize()
+    assert (b"k_bin_expand" in lib.lcg_hip_csr_last_kernel(A.h)) == expect_binned, lib.lcg_hip_csr_binned_status(A.h)
+    assert (lib.lcg_hip_csr_binned_status(A.h) == b"ready") == expect_binned
+    assert torch.equal(y1, y2)                                      # call to call: same bits
+    for y in (y0, y1):
+        assert np.all(np.abs(y.cpu().numpy() - ref) <= 1e-13 * bound + 1e-300)
+    if expect_binned:                                               # plan to plan: same bits
+        B = api.CsrMatrix.from_csr(rp, col, val, n_cols=ncols)
+        assert lib.lcg_hip_csr_set_binned(B.h, 1) == 0
+        y3 = torch.empty_like(y1)
+        B.spmv(xd, y3); api.synchronize()
+        assert torch.equal(y1, y3)
+        B.destroy()
+    A.destroy()
+    return y1.cpu().numpy()
+
+
+def test_ragged_fuzz_against_the_oracle(api, lib, port):
+    """Sizes on both sides of every boundary of the format: rows around multiples of the 2048-row chunk, columns
+    around multiples of the 8192-column tile, empty rows, a row of several thousand entries (groups of hundreds),
+    repeated (row, col) pairs (random columns repeat), rectangular shapes, one-row and one-column matrices."""
+    rng = np.random.default_rng(2024)
+    shapes = [(1, 1, 1), (5, 3, 3), (2047, 8191, 9), (2048, 8192, 9), (2049, 8193, 9), (4096, 70000, 33), (10000, 300, 20),
+              (300, 100000, 40), (30011, 2000003, 33), (6500, 50000, 5)]
+    for case, (n, ncols, mx) in enumerate(shapes):
+        long_rows = [(n // 2, min(5000, 4 * ncols))] if n > 100 else []
+        rp, col = _ragged(rng, n, ncols, mx, long_rows)
+        if rp[-1] == 0:
+            rp, col = np.array([0] + [1] * n, np.int32), np.zeros(1, np.int32)
+        val = rng.standard_normal(rp[-1])
+        x = rng.standard_normal(ncols)
+        _check(api, lib, port, rp, col, val, x, ncols)
+
+
+def test_padding_never_touches_x_it_does_not_own(api, lib, port):
+    """A NaN / inf in x may only reach the rows that reference that column (the padding entries of a group read
+    column 0 of their tile and must not contribute)."""
+    rng = np.random.default_rng(5)
+    n, ncols = 9000, 40000
+    rp, col = _ragged(rng, n, ncols, 12)
+    val = rng.standard_normal(rp[-1])
+    x = rng.standard_normal(ncols)
+    for bad in (0, 8192, 16384, 39999):
+        x2 = x.copy(); x2[bad] = np.nan
+        A = api.CsrMatrix.from_csr(rp, col, val, n_cols=ncols)
+        assert lib.lcg_hip_csr_set_binned(A.h, 1) == 0
+        y = torch.empty(n, dtype=torch.float64, device="cuda")
+        A.spmv(torch.from_numpy(x2).cuda(), y); api.synchronize()
+        touched = np.zeros(n, bool)
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        touched[rows[col == bad]] = True
+        assert np.array_equal(np.isnan(y.cpu().numpy()), touched), bad
+        A.destroy()
+
+
+def test_dense_groups_and_out_of_range_columns(api, lib, port):
+    """Every entry of a 3000-row matrix in ONE column tile (groups of 8192 entries, heavy row collisions inside an LDS
+    instruction) is still summed correctly; a column index outside [0, n_cols) makes the plan refuse (the row-block
+    kernel answers, as before)."""
+    rng = np.random.default_rng(6)
+    n = 3000
+    rp = np.arange(0, 4 * n + 1, 4, dtype=np.int32)
+    col = rng.integers(0, 500, rp[-1]).astype(np.int32)
+    val = rng.standard_normal(rp[-1]); x = rng.standard_normal(9000)
+    _check(api, lib, port, rp, col, val, x, 9000)
+    A = api.CsrMatrix.from_csr(rp, col, val, n_cols=400)           # lies about the width: columns up to 499
+    assert lib.lcg_hip_csr_set_binned(A.h, 1) == 0
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    A.spmv(torch.from_numpy(x).cuda(), y); api.synchronize()
+    assert b"outside" in lib.lcg_hip_csr_binned_status(A.h) and b"k_bin" not in lib.lcg_hip_csr_last_kernel(A.h)
+    assert np.abs(y.cpu().numpy() - port.csr_matvec(rp, col, val, x)).max() <= 1e-12 * np.abs(x).max() * 10
+
+
+def test_automatic_choice_and_solvers(api, lib, port):
+    """Automatic mode takes the binned product for a large scattered system and leaves a banded one alone; CG, PCG,
+    CGS and BiCGStab on a scattered system through the binned product meet the oracle's solutions."""
+    from oracle import pyoracle as po
+    n = 1_500_000
+    for pattern, band, want in ((api.GEN_SCRAMBLED, 0, True), (api.GEN_DIAGONALS, 4000, False), (api.GEN_ROW_RANDOM_BAND, 4000, False)):
+        A = api.CsrMatrix.generate(n, 16, band, True, 3, 0.01, pattern=pattern)
+        x = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 3, 0, n, x)
+        y = torch.empty_like(x); y2 = torch.empty_like(x)
+        A.spmv(x, y); api.synchronize()
+        assert (b"k_bin_expand" in lib.lcg_hip_csr_last_kernel(A.h)) == want, (pattern, lib.lcg_hip_csr_last_kernel(A.h))
+        if want:
+            assert lib.lcg_hip_csr_last_traffic_model(A.h) > 20 * A.nnz
+            assert lib.lcg_hip_csr_set_binned(A.h, 0) == 0
+            A.spmv(x, y2); api.synchronize()
+            assert ((y - y2).abs().max() <= 1e-13 * y2.abs().max()).item()
+        A.destroy()
+    n = 50_000
+    for sym, sids in ((True, (api.LCG_CG, api.LCG_PCG, api.LCG_CGS)), (False, (api.LCG_BICGSTAB, api.LCG_CGS))):
+        A = api.CsrMatrix.generate(n, 16, 0, sym, 9, 0.01)
+        A.build_jacobi()
+        assert lib.lcg_hip_csr_set_binned(A.h, 1) == 0
+        rp, ci, v = A.arrays_to_host()
+        xt = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 9, 0, n, xt)
+        b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
+        assert b"k_bin_expand" in lib.lcg_hip_csr_last_kernel(A.h)
+        bh = b.cpu().numpy()
+        for sid in sids:
+            ref = port.solve(sid, rp, ci, v, bh, para=po.default_para(epsilon=1e-12, abs_diff=1), jacobi=(sid == api.LCG_PCG))
+            m = torch.zeros(n, dtype=torch.float64, device="cuda")
+            para = api.lcg_default_parameters(epsilon=1e-12, abs_diff=1)
+            if sid == api.LCG_PCG:
+                info = api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, b, n, para, A)
+            else:
+                info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, para, A, sid)
+            xs = m.cpu().numpy()
+            assert info.ret == ref["ret"] == 0, (sym, sid)
+            assert abs(info.iterations - ref["iters"]) <= 3, (sym, sid, info.iterations, ref["iters"])
+            assert np.linalg.norm(xs - ref["x"]) <= 1e-9 * np.linalg.norm(ref["x"]), (sym, sid)
+        A.destroy()

@@ -101,3 +101,34 @@ def test_sharded_loops_converge_like_the_unsharded_ones(tmp_path, mode):
     assert np.linalg.norm(forced["cg13/x"] - plain["cg13/x"]) / np.linalg.norm(plain["cg13/x"]) <= 1e-10
     assert forced["cgpfp/meta"][0] == 0 and abs(forced["cgpfp/meta"][1] - plain["cgpfp/meta"][1]) <= 2
     assert forced["cgpfp/meta"][3] == forced["cgpfp/meta"][1] + 1          # Pfp called for k = 0..t
+
+
+def test_a_failing_product_ends_the_solve_with_its_code():
+    """liblcg's callback types return void (lcg.h:37-38).  A built-in callback that cannot make its product (here: a
+    matrix whose direct exchange could not be set up -- no mailboxes in this process) parks the failure and the solver
+    loop returns it (LCG_HIP_E_COMM = -2002) instead of iterating over a stale product and reporting an ordinary
+    liblcg code; the handle refuses products until it is distributed again under a mode that works."""
+    from liblcg_amd import _lib, api
+    lib = _lib.load()
+    n = 6000
+    A = api.CsrMatrix.generate(n, 16, 50, True, 4, 0.01)
+    A.build_jacobi()
+    xt = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 4, 0, n, xt)
+    b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
+    assert lib.lcg_hip_csr_distribute(A.h, n, 2) == -2002                  # needs the mailboxes: none connected
+    assert lib.lcg_hip_spmv(A.h, xt.data_ptr(), b.data_ptr()) == -2002     # the handle refuses, it does not guess
+    ax = _lib.fnptr(lib, "lcg_hip_csr_ax"); mx = _lib.fnptr(lib, "lcg_hip_jacobi_mx")
+    p = api.lcg_default_parameters(epsilon=1e-10, abs_diff=1)
+    m = torch.zeros_like(xt)
+    for sid in (api.LCG_CG, api.LCG_CGS, api.LCG_BICGSTAB, api.LCG_BICGSTAB2):
+        assert lib.lcg_hip_solver(ax, None, m.data_ptr(), b.data_ptr(), n, C.byref(p), A.h, sid, 1) == -2002, sid
+    assert lib.lcg_hip_solver_preconditioned(ax, mx, None, m.data_ptr(), b.data_ptr(), n, C.byref(p), A.h, 1, 1) == -2002
+    lo = torch.full_like(xt, -1.0); hi = torch.full_like(xt, 2.0)
+    assert lib.lcg_hip_solver_constrained(ax, None, m.data_ptr(), b.data_ptr(), lo.data_ptr(), hi.data_ptr(), n, C.byref(p), A.h, 5, 1) == -2002
+    assert b"distribute" in lib.lcg_hip_last_error()
+    # distributed again under a mode that works here (one rank, all-gather = a copy): products and solves are back
+    assert lib.lcg_hip_csr_distribute(A.h, n, 0) == 0
+    A.spmv(xt, b); api.synchronize()
+    m.zero_()
+    assert lib.lcg_hip_solver(ax, None, m.data_ptr(), b.data_ptr(), n, C.byref(p), A.h, api.LCG_CG, 1) == 0
+    assert ((m - xt).norm() / xt.norm()).item() < 1e-8

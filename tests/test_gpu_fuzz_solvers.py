@@ -42,3 +42,27 @@ def test_random_systems_against_the_oracle(port):
                 assert abs(info.iterations - ref["iters"]) <= 3, (tag, info.iterations, ref["iters"])
                 assert np.linalg.norm(x - ref["x"]) <= 1e-9 * np.linalg.norm(ref["x"]), tag
         A.destroy()
+        # the non-symmetric twin: lbicgstab (lcg.cpp:629-794) and lcgs (lcg.cpp:437-612) on A != A^T
+        A = api.CsrMatrix.generate(n, 16, band, False, seed, 0.01)
+        rp, ci, v = A.arrays_to_host()
+        b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
+        bh = b.cpu().numpy()
+        prng = np.random.default_rng(case)
+        for sid, name in ((api.LCG_BICGSTAB, "bicgstab"), (api.LCG_CGS, "cgs")):
+            opara = po.default_para(epsilon=eps, abs_diff=abs_diff)
+            ref = port.solve(sid, rp, ci, v, bh, para=opara)
+            sens, dit = 0.0, 0
+            for _ in range(3):
+                alt = port.solve(sid, rp, ci, v, bh * (1.0 + 1e-16 * prng.standard_normal(n)), para=opara)
+                sens = max(sens, np.linalg.norm(alt["x"] - ref["x"]) / np.linalg.norm(ref["x"]))
+                dit = max(dit, abs(alt["iters"] - ref["iters"]))
+            for packed in (0, 1):
+                assert lib.lcg_hip_csr_set_packed(A.h, packed) == 0
+                m = torch.zeros(n, dtype=torch.float64, device="cuda")
+                info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=eps, abs_diff=abs_diff), A, sid)
+                x = m.cpu().numpy()
+                tag = (case, n, band, abs_diff, name, packed, info.iterations, ref["iters"], sens, dit)
+                assert info.ret == ref["ret"] == 0, tag
+                assert abs(info.iterations - ref["iters"]) <= max(3, 3 * dit, 0.05 * ref["iters"]), tag
+                assert np.linalg.norm(x - ref["x"]) <= max(1e-9, 50 * sens) * np.linalg.norm(ref["x"]), tag
+        A.destroy()

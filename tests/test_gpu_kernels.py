@@ -252,6 +252,33 @@ def test_generator_twin_is_bit_identical(api, port, band, sym):
         assert np.all(M.diagonal() - off > 0.0099)
 
 
+@pytest.mark.parametrize("band,sym", [(600, True), (64, False), (1, True), (5000, True)])
+def test_row_random_band_generator_twin(api, port, band, sym):
+    """Pattern 2 (every row draws its own columns inside (i - band, i + band)): device generator == oracle twin bit
+    for bit, on whole matrices and on shards; symmetric pattern and values; columns inside the band."""
+    n = 9001
+    g = port.gen_init(n, 16, band, sym, 7, 0.01, pattern=2)
+    for r0, r1 in ((0, n), (2000, 5555), (n - 77, n)):
+        rp, ci, v = port.gen_rows(g, r0, r1)
+        A = api.CsrMatrix.generate(n, 16, band, sym, 7, 0.01, r0, r1, pattern=api.GEN_ROW_RANDOM_BAND)
+        rp2, ci2, v2 = A.arrays_to_host()
+        assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2) and np.array_equal(v, v2)
+    import scipy.sparse as sp
+    rp, ci, v = port.gen_rows(g)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    assert np.abs(ci - rows).max() < max(2, band)
+    M = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    P = sp.csr_matrix((np.ones_like(v), ci, rp), shape=(n, n))
+    assert abs(P - P.T).max() == 0.0                               # the pattern is symmetric either way
+    if sym:
+        assert abs(M - M.T).max() == 0.0
+        off = abs(M).sum(axis=1).A1 - M.diagonal()
+        assert np.all(M.diagonal() - off > 0.0099)
+    if band >= 600:     # rows really differ: the offsets of row i and row i+1 are not the same set
+        o0 = set((ci[rp[4000]:rp[4001]] - 4000).tolist()); o1 = set((ci[rp[4001]:rp[4002]] - 4001).tolist())
+        assert len(o0 & o1) <= 3
+
+
 def test_laplace2d_generator(api):
     import scipy.sparse as sp
     nx, ny = 37, 23

@@ -68,3 +68,49 @@ def test_complex_bicgstab_is_chaotic_on_the_bundled_systems(port, case1kc, case1
         a = port.csolve(po.CLCG_BICGSTAB, rp, ci, v, b, para=para, rbar0=rb)
         c = port.csolve(po.CLCG_BICGSTAB, rp, ci, v, _perturbed(b, 0), para=para, rbar0=rb)
         assert lo <= _rel(a["x"], c["x"]) <= hi
+
+
+# (pattern, n, band, seed) and bands of tests/test_gpu_configs.py::test_nonsymmetric_bicgstab_and_cgs_against_the_oracle
+NONSYM_SYSTEMS = [(1, 60000, 3000, 5), (0, 40000, 0, 6), (2, 50000, 2048, 7)]
+NONSYM_BANDS = {3: (1e-6, 0.15), 2: (1e-8, 0.15)}
+
+
+@pytest.mark.parametrize("pattern,n,band,seed", NONSYM_SYSTEMS)
+def test_nonsymmetric_generated_systems(port, pattern, n, band, seed):
+    """BiCGStab / CGS on A != A^T: how far the oracle's own answer and count move under 1-ulp changes of b.  The
+    converged runs move by about the error left at the stop (another iteration more or less); six capped iterations
+    do not move at all (1e-15) -- which is what lets the GPU test ask for 1e-13 there."""
+    g = port.gen_init(n, 16, band, False, seed, 0.01, pattern=pattern)
+    rp, ci, v = port.gen_rows(g)
+    b = port.csr_matvec(rp, ci, v, port.gen_xtrue(g))
+    for sid in (po.LCG_BICGSTAB, po.LCG_CGS):
+        tol, band_it = NONSYM_BANDS[sid]
+        for eps, ad, cap, loose in ((1e-12, 1, 0, 1.0), (1e-14, 0, 0, 300.0), (1e-300, 1, 6, None)):
+            para = po.default_para(epsilon=eps, abs_diff=ad, max_iterations=cap)
+            a = port.solve(sid, rp, ci, v, b, para=para)
+            for s in (1, 2):
+                c = port.solve(sid, rp, ci, v, _perturbed(b, s), para=para)
+                assert a["ret"] == c["ret"]
+                if cap:
+                    assert _rel(a["x"], c["x"]) <= 1e-13 / 20
+                else:
+                    assert _rel(a["x"], c["x"]) <= tol * loose / 20
+                    assert abs(a["iters"] - c["iters"]) <= max(3, band_it * a["iters"]) / 2
+
+
+def test_laplacian_pcg_is_insensitive(port):
+    """BASELINE configs[1] at a tenth of the size (the full size is run by the GPU test): PCG + Jacobi on the 5-point
+    Laplacian does not amplify rounding -- 1e-9 and +-3 iterations leave four orders of headroom."""
+    import scipy.sparse as sp
+    nx = ny = 316
+    T = (sp.kron(sp.eye(ny), sp.diags([-1, 2, -1], [-1, 0, 1], shape=(nx, nx))) +
+         sp.kron(sp.diags([-1, 2, -1], [-1, 0, 1], shape=(ny, ny)), sp.eye(nx))).tocsr()
+    T.sort_indices()
+    rp, ci, v = T.indptr.astype(np.int32), T.indices.astype(np.int32), T.data.astype(np.float64)
+    g = port.gen_init(nx * ny, 16, 0, True, 1, 0.01)
+    b = port.csr_matvec(rp, ci, v, port.gen_xtrue(g))
+    para = po.default_para(epsilon=1e-10, abs_diff=1)
+    a = port.solve(po.LCG_PCG, rp, ci, v, b, para=para, jacobi=True)
+    c = port.solve(po.LCG_PCG, rp, ci, v, _perturbed(b, 1), para=para, jacobi=True)
+    assert a["ret"] == c["ret"] == 0 and abs(a["iters"] - c["iters"]) <= 1
+    assert _rel(a["x"], c["x"]) <= 1e-9 / 1000
