@@ -7,14 +7,25 @@
 
 One "step" is one CG iteration (lcg.cpp:206-264: A.d, three inner products, three vector
 updates, stop test) executed by lcg_hip_lcg() through the C ABI with inputs resident in HBM.
-N > 1: the same 10M-row system is row-partitioned over the ranks (strong scaling), x is
-all-gathered and the inner products all-reduced over RCCL inside the library.
+The K-step solve is timed `--reps` times (default 5), each bracketed by barrier + synchronise;
+`value` is K / the MEDIAN time (min and max are reported beside it).  A solution check that does
+not depend on K guards the number: the residual a 25-iteration solve monitored must be the residual
+of its iterate (recomputed with a second A.x), and 100 iterations must come within 1e-3 of x_true.
+
+N = 1 also reports `variants`: the same CG on the three column patterns of the synthetic family
+(constant diagonals -- the headline --, row-random band, scrambled), so that the headline cannot be
+mistaken for the whole family.
+N > 1: the same 10M-row system is row-partitioned over the ranks (strong scaling).  The
+north-star exchange -- RCCL all-gather of x + RCCL all-reduce of the dots -- is measured FIRST and
+always reported (`value_rccl_allgather`); cheaper exchanges are then validated against its product
+and timed, and `value` is the best validated configuration (never below the baseline).
 
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for every field.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -22,10 +33,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+PATTERNS = {"constant_diagonals": 1, "row_random_band": 2, "scrambled": 0}
+AX_PER_IT = {"cg": 1, "pcg": 1, "cgs": 2, "bicgstab": 2}
+BLAS1_WORDS = {"cg": 13, "pcg": 18, "cgs": 21, "bicgstab": 22}
 
 
 def spmv_bytes(n, nnz):     # 12*nnz + 4*(N+1) + 8*N (x) + 8*N (y)
     return 12 * nnz + 4 * (n + 1) + 16 * n
+
+
+def workload_name(pattern, band, npairs, solver):
+    what = {"constant_diagonals": f"{2 * npairs + 1} constant diagonals (a DIA matrix stored as CSR; offsets <= {band}, the same in every row)",
+            "row_random_band": f"row-random band (every row draws its own ~{2 * npairs} columns within +-{band})",
+            "scrambled": f"scrambled columns (~{2 * npairs} affine maps per row, anywhere in the matrix)"}[pattern]
+    return f"synthetic SPD CSR, {what}, plain {solver.upper()} via lcg_hip_lcg (BASELINE configs[2]/[3])"
 
 
 def main():
@@ -33,12 +54,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=5, help="timed repetitions of the K-step solve (value = K / median)")
     ap.add_argument("--rows", type=int, default=10_000_000)
-    ap.add_argument("--band", type=int, default=131072, help="0 = scrambled (random-column) variant")
+    ap.add_argument("--band", type=int, default=131072)
+    ap.add_argument("--pattern", default="constant_diagonals", choices=list(PATTERNS))
     ap.add_argument("--npairs", type=int, default=16)
     ap.add_argument("--solver", default="cg", choices=["cg", "pcg", "cgs", "bicgstab"])
     ap.add_argument("--cg-schedule", default="auto", choices=["auto", "classic", "one-reduction"],
                     help="lcg_hip_set_cg_schedule: auto = classic on one GPU, one all-reduce per iteration when sharded")
+    ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -51,14 +75,8 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    if world > 1:
-        # one rank per GPU here (LOCAL_RANK picks the device): the remote-column product may wait for its
-        # neighbours with every block and gather straight from the landing zone (one launch less per A.x).
-        # Left off by default in the library because ranks SHARING a GPU starve each other that way.
-        os.environ.setdefault("LCG_HIP_DIRECT_LAND", "1")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     lib = _lib.load()
     rc = lib.lcg_hip_init(local_rank)
@@ -66,7 +84,6 @@ def main():
         raise SystemExit(f"lcg_hip_init failed: {lib.lcg_hip_last_error().decode()}")
 
     dist = None
-    exchange_probe = None
     p2p, p2p_why = False, "disabled"
     sharded = world > 1 or bool(os.environ.get("LCG_HIP_FORCE_COMM"))    # the env var rehearses the RCCL path on one GPU
     if sharded:
@@ -75,134 +92,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         partition.init_comm_from_torch(lib)
-        # the <= 8 sums of a sync point go straight into the peers' mailboxes over xGMI when every
-        # rank could map them and the self-test passed everywhere; otherwise RCCL all-reduces them
-        if os.environ.get("LCG_HIP_P2P", "1") != "0":
-            p2p, p2p_why = partition.init_p2p_from_torch(lib)
-            if not p2p and rank == 0:
-                print(f"[bench] direct all-reduce not used: {p2p_why}", file=sys.stderr)
 
     n = args.rows
     r0, r1 = partition.shard_range(n, world, rank)
     nloc = r1 - r0
     symmetric = args.solver in ("cg", "pcg")
-    A = api.CsrMatrix.generate(n, args.npairs, args.band, symmetric, 1, 0.01, r0, r1)
-    nnz_local = A.nnz
-    if args.solver == "pcg":
-        A.build_jacobi()
-    xt = torch.empty(nloc, dtype=torch.float64, device="cuda")
-    api.gen_xtrue(n, 1, r0, r1, xt)
-    b = torch.empty_like(xt)
-    exchange = "none"
-    if sharded:
-        # all-gather of x is the reference exchange; the neighbour (range) exchange moves only the
-        # column ranges the shard touches and is used when it reproduces the all-gather product
-        A.distribute(n, 0)
-        A.spmv(xt, b); api.synchronize()
-        exchange = "all-gather"
-        # Cheaper exchanges are used only when they reproduce the all-gather product on this node:
-        #   2 direct  -- owners write their boundary entries of x into the neighbours' buffers over the
-        #                peer mappings from inside the A.x kernel (no collective, no second stream)
-        #   1 ranges  -- grouped ncclSend/ncclRecv of the column ranges the shard touches
-        # Every step is agreed by all ranks (all-reduce of a failure flag): all switch, or none does.
-        want = int(os.environ.get("LCG_HIP_DIST_MODE", "2"))
-        x2 = 2.0 * xt + 1.0
-        b2 = torch.empty_like(b)
-        A.spmv(x2, b2); api.synchronize()
-        bad = torch.zeros(1, dtype=torch.float64, device="cuda")
-
-        def anybody(failed):
-            bad[0] = 1.0 if failed else 0.0
-            dist.all_reduce(bad)
-            return bad.item() != 0.0
-
-        def close(u, v):    # the direct path adds a row's remote part in another order: rounding only
-            return bool(((u - v).abs().max() <= 1e-12 * v.abs().max()).item())
-
-        def ax_time(reps=30):   # A.x incl. its exchange, slowest rank (dependent back-to-back calls)
-            t1 = torch.empty_like(b)
-            for _ in range(5):
-                A.spmv(xt, t1)
-            api.synchronize(); dist.barrier()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                A.spmv(xt, t1)
-            api.synchronize()
-            t = torch.tensor([(time.perf_counter() - t0) / reps * 1e6], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
-
-        labels = {0: "all-gather", 1: "neighbour ranges", 2: "direct peer writes"}
-        timings = {0: ax_time()}
-        for mode in (2, 1):
-            if mode > want or (mode == 2 and not p2p):
-                continue
-            failed = False
-            try:                            # phase 1: every rank builds its plan (collective inside)
-                A.distribute(n, mode)
-            except Exception as exc:
-                print(f"[rank {rank}] exchange mode {mode} unavailable: {exc}", file=sys.stderr)
-                failed = True
-            if not anybody(failed):         # phase 2: all ranks exchange, or none does
-                t1 = torch.empty_like(b); t2 = torch.empty_like(b); t3 = torch.empty_like(b)
-                try:
-                    A.spmv(xt, t1); A.spmv(x2, t2); A.spmv(xt, t3); api.synchronize()    # alternating inputs expose stale buffers
-                    if mode == 1:
-                        failed = not (torch.equal(t1, b) and torch.equal(t2, b2) and torch.equal(t3, b))
-                    else:
-                        failed = not (close(t1, b) and close(t2, b2) and close(t3, b))
-                except Exception as exc:        # a timed-out exchange surfaces in synchronize()
-                    print(f"[rank {rank}] exchange mode {mode} failed its check: {exc}", file=sys.stderr)
-                    failed = True
-                if not anybody(failed):
-                    try:
-                        timings[mode] = ax_time()
-                    except Exception as exc:
-                        print(f"[rank {rank}] exchange mode {mode} failed while timed: {exc}", file=sys.stderr)
-                        raise
-            A.distribute(n, 0)
-            if p2p and anybody(lib.lcg_hip_p2p_status() < 0):
-                # an exchange over the peer mappings timed out somewhere: tear the direct paths down on every
-                # rank (no matrix uses them at this point) and let RCCL do everything
-                p2p = False
-                lib.lcg_hip_p2p_disconnect()
-                timings.pop(2, None)
-                if rank == 0:
-                    print("[bench] direct paths switched off: an exchange timed out", file=sys.stderr)
-        # the fastest validated exchange on THIS node (same decision everywhere: the timings are all-reduced)
-        best = min(timings, key=lambda k: timings[k]) if want > 0 else 0
-        if "LCG_HIP_DIST_MODE" in os.environ and want in timings:
-            best = want                     # an explicit request wins when it validated
-        if best != 0:
-            A.distribute(n, best)
-        exchange = labels[best]
-        exchange_probe = {labels[k]: round(v, 1) for k, v in timings.items()}
-        del x2, b2
-    else:
-        A.spmv(xt, b)
-    api.synchronize()
-    nnz = nnz_local
-    if sharded:
-        t = torch.tensor([nnz_local], dtype=torch.int64, device="cuda")
-        dist.all_reduce(t)
-        nnz = int(t.item())
-
-    m = torch.zeros_like(xt)
-    ws = [torch.empty_like(xt) for _ in range(7)]
     api.set_cg_schedule({"auto": api.CG_AUTO, "classic": api.CG_CLASSIC, "one-reduction": api.CG_ONE_REDUCTION}[args.cg_schedule])
     one_red = args.solver == "cg" and (args.cg_schedule == "one-reduction" or (args.cg_schedule == "auto" and sharded))
-
-    def solve(iters):
-        m.zero_()
-        torch.cuda.synchronize()
-        p = api.lcg_default_parameters(epsilon=1e-300, max_iterations=iters)
-        if args.solver == "cg":
-            return api.lcg("lcg_hip_csr_ax", None, m, b, nloc, p, A, ws[0], ws[1], ws[2])
-        if args.solver == "pcg":
-            return api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, b, nloc, p, A)
-        if args.solver == "cgs":
-            return api.lcgs("lcg_hip_csr_ax", None, m, b, nloc, p, A, *ws)
-        return api.lcg_solver("lcg_hip_csr_ax", None, m, b, nloc, p, A, api.LCG_BICGSTAB)
 
     def barrier():
         torch.cuda.synchronize()
@@ -210,106 +106,158 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        solve(args.warmup)
-    # HIP events around A.x: every call on one GPU (0.3 % of a 10M-row iteration); every 8th call when
-    # sharded, where the two stream markers of a timed call are ~3 % of a 150 us iteration
-    lib.lcg_hip_set_profiling(0 if os.environ.get("LCG_BENCH_NO_EVENTS") else (8 if sharded else 1))
-    barrier()
-    t0 = time.perf_counter()
-    info = solve(args.steps)
-    api.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ax_us = lib.lcg_hip_last_ax_mean_us()
-    ax_calls = lib.lcg_hip_last_ax_calls()
-    lib.lcg_hip_set_profiling(0)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    def allmax(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if info.iterations != args.steps:
-        raise SystemExit(f"timed solve ran {info.iterations} iterations, expected {args.steps} (ret={info.ret})")
+        return float(t.item())
 
-    # accuracy after the timed iterations (the system is solved to the fp64 floor well before 200)
-    err = torch.tensor([(m - xt).pow(2).sum().item(), xt.pow(2).sum().item()], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(err)
-    rel_err = float((err[0] / err[1]).sqrt().item())
-    # a fast wrong answer is not a result: CG on this system is at 1e-9 of x_true after 100 iterations
-    if args.solver == "cg" and args.band and args.steps >= 100 and not rel_err < 1e-8:
-        raise SystemExit(f"solution check failed: |m - x_true|/|x_true| = {rel_err:.3e} after {args.steps} iterations")
+    def allsum(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(t)
+        return [float(v) for v in t.tolist()]
 
-    ax_per_it = {"cg": 1, "pcg": 1, "cgs": 2, "bicgstab": 2}[args.solver]
-    blas1_words = {"cg": 13, "pcg": 18, "cgs": 21, "bicgstab": 22}[args.solver]
-    iter_bytes = ax_per_it * spmv_bytes(n, nnz) + 8 * blas1_words * n
-    out = {
-        "metric": "cg_iterations_per_sec", "value": args.steps / elapsed, "unit": "iter/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"synthetic SPD CSR, {'banded-random W=%d' % args.band if args.band else 'scrambled affine maps'}, "
-                               f"plain {args.solver.upper()} via lcg_hip_lcg (BASELINE configs[2]/[3])",
-                   "rows": n, "nnz": nnz, "nnz_per_row": nnz / n, "solver": args.solver, "index": "int32",
+    class System:
+        """One generated system resident in HBM: A (this rank's rows), x_true, b = A.x_true, workspaces."""
+
+        def __init__(self, pattern):
+            band = args.band if PATTERNS[pattern] else 0
+            self.pattern = pattern
+            self.A = api.CsrMatrix.generate(n, args.npairs, band, symmetric, 1, 0.01, r0, r1, pattern=PATTERNS[pattern])
+            if args.solver == "pcg":
+                self.A.build_jacobi()
+            self.xt = torch.empty(nloc, dtype=torch.float64, device="cuda")
+            api.gen_xtrue(n, 1, r0, r1, self.xt)
+            self.b = torch.empty_like(self.xt)
+            self.m = torch.zeros_like(self.xt)
+            self.ws = [torch.empty_like(self.xt) for _ in range(7)]
+            self.nnz_local = self.A.nnz
+            self.nnz = int(allsum([self.nnz_local])[0])
+
+        def rhs(self):
+            self.A.spmv(self.xt, self.b); api.synchronize()
+
+        def solve(self, iters):
+            self.m.zero_()
+            torch.cuda.synchronize()
+            p = api.lcg_default_parameters(epsilon=1e-300, max_iterations=iters)
+            A, m, b, ws = self.A, self.m, self.b, self.ws
+            if args.solver == "cg":
+                return api.lcg("lcg_hip_csr_ax", None, m, b, nloc, p, A, ws[0], ws[1], ws[2])
+            if args.solver == "pcg":
+                return api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, b, nloc, p, A)
+            if args.solver == "cgs":
+                return api.lcgs("lcg_hip_csr_ax", None, m, b, nloc, p, A, *ws)
+            return api.lcg_solver("lcg_hip_csr_ax", None, m, b, nloc, p, A, api.LCG_BICGSTAB)
+
+        def timed(self, steps, reps, events):
+            """`reps` timed K-step solves.  Returns (times [s, max over ranks], ax_us, ax_calls) of the median run."""
+            runs = []
+            for _ in range(reps):
+                lib.lcg_hip_set_profiling(events)
+                barrier()
+                t0 = time.perf_counter()
+                info = self.solve(steps)
+                api.synchronize()
+                barrier()
+                el = allmax(time.perf_counter() - t0)
+                runs.append((el, lib.lcg_hip_last_ax_mean_us(), lib.lcg_hip_last_ax_calls()))
+                lib.lcg_hip_set_profiling(0)
+                if info.iterations != steps:
+                    raise RuntimeError(f"timed solve ran {info.iterations} iterations, expected {steps} (ret={info.ret})")
+            runs.sort()
+            return [r[0] for r in runs], runs[len(runs) // 2][1], runs[len(runs) // 2][2]
+
+        def rel_err(self):
+            e = allsum([(self.m - self.xt).pow(2).sum().item(), self.xt.pow(2).sum().item()])
+            return (e[0] / e[1]) ** 0.5
+
+        def residual_check(self, info):
+            """|A m - b| / N recomputed with a second A.x against the residual the solve monitored (abs_diff = 0 reports
+            |g|^2 / max(|m|^2, 1): lcg.cpp:209) -- a stale halo or a broken kernel cannot pass this."""
+            r = self.ws[6]
+            self.A.spmv(self.m, r); api.synchronize()
+            g2, m2 = allsum([(r - self.b).pow(2).sum().item(), self.m.pow(2).sum().item()])
+            mine = g2 / max(m2, 1.0)
+            return mine, info.residual, abs(mine - info.residual) <= 1e-6 * max(mine, info.residual) + 1e-300
+
+        def residual_ok(self):
+            """25 iterations (the recurrence's residual and the true one still agree to rounding there; at the fp64 floor
+            the recurrence keeps falling and the true residual does not)."""
+            info = self.solve(25)
+            api.synchronize()
+            return self.residual_check(info)
+
+        def guard(self):
+            """A fast wrong answer is not a result, whatever --steps is.  (1) The residual the solver monitored after 25
+            iterations is the residual of its iterate, recomputed with a second A.x (to 1e-6 relative: a stale halo, a
+            broken kernel or a wrong coefficient cannot pass); (2) 100 iterations from m = 0 have brought the iterate
+            within 1e-3 of x_true (the family's condition number is ~3e3: CG gains ~3.5 % per iteration, 1.6e-5 after
+            100 on the headline system)."""
+            mine, theirs, ok = self.residual_ok()
+            self.solve(100)
+            api.synchronize()
+            err = self.rel_err()
+            out = {"rel_err_vs_x_true_after_100_iterations": err, "residual_recomputed_after_25": mine, "residual_monitored_after_25": theirs}
+            if not ok or not err < 1e-3:
+                raise RuntimeError(f"solution check failed on {self.pattern}: {out}")
+            return out
+
+    def iteration_bytes(nnz):
+        return AX_PER_IT[args.solver] * spmv_bytes(n, nnz) + 8 * BLAS1_WORDS[args.solver] * n
+
+    out = {"metric": "cg_iterations_per_sec", "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+    S = System(args.pattern)
+    exchange, comm_probe = "none", None
+
+    try:
+        if not sharded:
+            S.rhs()
+            if args.warmup > 0:
+                S.solve(args.warmup)
+            check = S.guard()
+            times, ax_us, ax_calls = S.timed(args.steps, args.reps, 1)
+        else:
+            times, ax_us, ax_calls, check, exchange, comm_probe, p2p = run_sharded(args, S, lib, api, partition, dist, torch, n, rank,
+                                                                                  barrier, allmax, allsum, out)
+    except Exception as exc:        # every rank still leaves a JSON line behind (rank 0 prints it)
+        out.update({"value": 0.0, "ms_per_step": None, "error": f"{type(exc).__name__}: {exc}",
+                    "config": {"workload": workload_name(args.pattern, args.band, args.npairs, args.solver)}})
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        raise
+
+    med = statistics.median(times)
+    nnz = S.nnz
+    out.update({
+        "value": args.steps / med, "ms_per_step": 1e3 * med / args.steps,
+        "value_min": args.steps / max(times), "value_max": args.steps / min(times), "timed_repetitions": len(times),
+        "config": {"workload": workload_name(args.pattern, args.band, args.npairs, args.solver),
+                   "rows": n, "nnz": nnz, "nnz_per_row": nnz / n, "solver": args.solver, "index": "int32", "pattern": args.pattern,
                    "cg_schedule": ("one reduction per iteration (Chronopoulos-Gear)" if one_red else "classic, two reductions per iteration"),
                    "partition": "single" if not sharded else f"row-block x{world}, x exchange = {exchange} "
-                                f"({lib.lcg_hip_csr_exchange_volume(A.h)} doubles received per rank per A.x) + "
+                                f"({lib.lcg_hip_csr_exchange_volume(S.A.h)} doubles received per rank per A.x) + "
                                 + ("direct all-reduce(dots) over peer-mapped mailboxes, fused into the scalar step" if p2p else "RCCL all-reduce(dots)")},
-        "whole_iteration_algorithmic_GBs": iter_bytes / (elapsed / args.steps) / 1e9,
-        "frac_of_hbm_peak_whole_iteration": iter_bytes / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
-        "rel_err_vs_x_true": rel_err,
-    }
-    # dominant kernel: the CSR A.x.  Duration from HIP events on the solver stream around every
-    # A.x of the timed region; bytes = algorithmic bytes of this rank's shard.
+        "whole_iteration_algorithmic_GBs": iteration_bytes(nnz) / (med / args.steps) / 1e9,
+        "frac_of_hbm_peak_whole_iteration": iteration_bytes(nnz) / (med / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
+        "solution_check": check,
+    })
+    # dominant kernel: the CSR A.x.  Duration from HIP events on the solver stream around every A.x of the timed
+    # region (median repetition); bytes = algorithmic bytes of this rank's shard.
     if ax_calls > 0 and ax_us > 0:
-        shard_bytes = spmv_bytes(nloc, nnz_local) if world == 1 else 12 * nnz_local + 4 * (nloc + 1) + 8 * n + 8 * nloc
+        shard_bytes = spmv_bytes(nloc, S.nnz_local) if world == 1 else 12 * S.nnz_local + 4 * (nloc + 1) + 8 * n + 8 * nloc
         achieved = shard_bytes / (ax_us * 1e-6) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if world == 1 and os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("spmv_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "k_spmv_ldsp / k_spmv_lds1 (LDS-staged CSR A.x; packed 18/21-bit columns when eligible)" if world == 1 else "A.x (local product + x exchange + remote columns)",
+        kernel = lib.lcg_hip_csr_last_kernel(S.A.h).decode()
+        traffic, source = pmc_traffic(args.pattern, kernel) if world == 1 else (None, "not collected for sharded runs")
+        out["roofline"] = {"bound": "hbm", "kernel": kernel if world == 1 else "A.x (local product + x exchange + remote columns): " + kernel,
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": traffic, "bytes_per_launch": shard_bytes, "avg_launch_us": ax_us, "launches": ax_calls}
-
-    if sharded:
-        # outside the timed region: what the two collectives of an iteration cost on this node's links
-        # (dependent back-to-back calls; all ranks take part).  Diagnostic fields for the next tuning step.
-        probe = torch.ones(8, dtype=torch.float64, device="cuda")
-        xs = torch.rand(nloc, dtype=torch.float64, device="cuda"); ys = torch.empty_like(xs)
-        res = {}
-        for name, call, reps in (("allreduce_4_doubles_us", lambda: lib.lcg_hip_allreduce_sum(probe.data_ptr(), 4), 200),
-                                 ("ax_with_exchange_us", lambda: A.spmv(xs, ys), 50)):
-            for _ in range(5):
-                call()
-            api.synchronize(); barrier()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                call()
-            api.synchronize()
-            t = torch.tensor([(time.perf_counter() - t0) / reps * 1e6], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            res[name] = float(t.item())
-        if p2p:     # the same all-reduce through RCCL, for comparison (all ranks switch together)
-            lib.lcg_hip_p2p_enable(0)
-            call = lambda: lib.lcg_hip_allreduce_sum(probe.data_ptr(), 4)
-            for _ in range(5):
-                call()
-            api.synchronize(); barrier()
-            t0 = time.perf_counter()
-            for _ in range(200):
-                call()
-            api.synchronize()
-            t = torch.tensor([(time.perf_counter() - t0) / 200 * 1e6], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            res["allreduce_4_doubles_rccl_us"] = float(t.item())
-            lib.lcg_hip_p2p_enable(1)
-        res["allreduce_path"] = "direct (peer mailboxes)" if p2p else "rccl"
-        res["ax_with_exchange_us_by_mode"] = exchange_probe
-        out["comm_probe"] = res
+                           "traffic": traffic, "traffic_source": source, "bytes_per_launch": shard_bytes, "avg_launch_us": ax_us,
+                           "launches": ax_calls}
+    if comm_probe is not None:
+        out["comm_probe"] = comm_probe
 
     if rank == 0 and world == 1 and "roofline" in out:
         # what THIS box's memory system sustains on a plain device copy (1 GiB read + 1 GiB written),
@@ -328,17 +276,233 @@ def main():
         out["roofline"]["frac_of_device_copy"] = out["roofline"]["achieved"] / copy_gbs
         del src, dst
 
+    if world == 1 and not sharded and not args.no_variants:
+        out["variants"] = variants(args, System, S, lib, api, n, spmv_bytes, iteration_bytes)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(A, b, n, args, np)
+        out["cpu_baseline"] = cpu_baseline(S.A, S.b, n, args, np)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
-        if p2p:
-            api.synchronize(); barrier()        # nobody unmaps a mailbox a peer may still write to
-            lib.lcg_hip_p2p_disconnect()
+        api.synchronize(); barrier()        # nobody unmaps a mailbox a peer may still write to
+        lib.lcg_hip_p2p_disconnect()
         lib.lcg_hip_comm_destroy()
         dist.destroy_process_group()
+
+
+def variants(args, System, S, lib, api, n, spmv_bytes, iteration_bytes):
+    """The same K-step CG on each column pattern of the family (three repetitions, median): it/s, A.x time and its
+    fraction of the 8 TB/s peak on ALGORITHMIC bytes, the kernel that ran, and the same solution check."""
+    res = {}
+    for pattern in ("constant_diagonals", "row_random_band", "scrambled"):
+        if pattern == S.pattern:
+            V, own = S, False
+        else:
+            V, own = System(pattern), True
+            V.rhs()
+            V.solve(min(args.warmup, 5) or 1)
+        check = V.guard() if own else None
+        times, ax_us, ax_calls = V.timed(args.steps, 3, 1)
+        med = sorted(times)[len(times) // 2]
+        byts = spmv_bytes(n, V.nnz)
+        entry = {"it_per_s": args.steps / med, "ax_us": ax_us, "frac": byts / (ax_us * 1e-6) / 1e9 / HBM_PEAK_GBS if ax_us > 0 else None,
+                 "algorithmic_GBs": byts / (ax_us * 1e-6) / 1e9 if ax_us > 0 else None, "nnz": V.nnz,
+                 "whole_iteration_algorithmic_GBs": iteration_bytes(V.nnz) / (med / args.steps) / 1e9,
+                 "kernel": lib.lcg_hip_csr_last_kernel(V.A.h).decode()}
+        model = lib.lcg_hip_csr_last_traffic_model(V.A.h)
+        if model:
+            entry["streamed_bytes_by_construction"] = model
+        if check:
+            entry["solution_check"] = check
+        res[pattern] = entry
+        if own:
+            V.A.destroy()
+            del V
+    return res
+
+
+def pmc_traffic(pattern, kernel):
+    """HBM bytes per A.x launch from the committed rocprofv3 --pmc runs (FETCH_SIZE x 2 + WRITE_SIZE as the guide
+    prescribes for gfx950), or (None, why).  Counters cannot be read from inside this process; the figure is tied to the
+    kernel it was collected on and dropped when another kernel ran."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        summ = json.load(open(path))
+    except (OSError, ValueError):
+        return None, "profiles/pmc_summary.json missing"
+    ent = summ.get("variants", {}).get(pattern)
+    if not ent:
+        return None, f"profiles/pmc_summary.json holds no entry for {pattern}"
+    family = kernel.split(" ")[0]
+    if family not in ent.get("kernel", ""):
+        return None, f"profiles/pmc_summary.json was collected on {ent.get('kernel', '?')[:60]}, this run used {family}"
+    return ent.get("hbm_bytes_per_launch"), f"profiles/pmc_summary.json ({summ.get('tag')}, {ent.get('collected', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes')})"
+
+
+def run_sharded(args, S, lib, api, partition, dist, torch, n, rank, barrier, allmax, allsum, out):
+    """N > 1 (or the one-rank rehearsal): baseline first, then every cheaper exchange that reproduces its product."""
+    world = dist.get_world_size()
+    A, xt, b = S.A, S.xt, S.b
+    labels = {0: "all-gather", 1: "neighbour ranges", 2: "direct peer writes"}
+    bad = torch.zeros(1, dtype=torch.float64, device="cuda")
+
+    def anybody(failed):
+        bad[0] = 1.0 if failed else 0.0
+        dist.all_reduce(bad)
+        return bad.item() != 0.0
+
+    def attempt(fn, what):
+        """Run fn on every rank; True only if it succeeded everywhere (exceptions become a vote, never a hang:
+        every collective the library makes has a time-out or is an RCCL call all ranks reach)."""
+        failed = False
+        try:
+            fn()
+        except Exception as exc:
+            print(f"[rank {rank}] {what}: {exc}", file=sys.stderr)
+            failed = True
+        return not anybody(failed)
+
+    # ---- 1. the north-star configuration: RCCL all-gather of x, RCCL all-reduce of the dots --------------------------
+    A.distribute(n, 0)
+    S.rhs()
+    x2 = 2.0 * xt + 1.0
+    b2 = torch.empty_like(b)
+    A.spmv(x2, b2); api.synchronize()
+    if args.warmup > 0:
+        S.solve(args.warmup)
+    check = S.guard()
+    base_times, base_ax_us, base_ax_calls = S.timed(args.steps, args.reps, 8)
+    base_med = sorted(base_times)[len(base_times) // 2]
+    out["value_rccl_allgather"] = args.steps / base_med
+    out["ms_per_step_rccl_allgather"] = 1e3 * base_med / args.steps
+    tried = {"all-gather + rccl all-reduce": args.steps / base_med}
+    best = (base_med, 0, False, base_times, base_ax_us, base_ax_calls)
+
+    # ---- 2. cheaper exchanges, each admitted only if it reproduces the all-gather product on this node ----------------
+    want = int(os.environ.get("LCG_HIP_DIST_MODE", "2"))
+    p2p, p2p_why = False, "disabled (LCG_HIP_P2P=0)"
+    if os.environ.get("LCG_HIP_P2P", "1") != "0" and want >= 0:
+        try:
+            p2p, p2p_why = partition.init_p2p_from_torch(lib)
+        except Exception as exc:
+            p2p, p2p_why = False, f"{type(exc).__name__}: {exc}"
+        p2p = not anybody(not p2p)
+        if p2p:
+            lib.lcg_hip_p2p_set_timeout_ms(2000)        # while the node's links are probed; 20 s afterwards
+        elif rank == 0:
+            print(f"[bench] direct paths not used: {p2p_why}", file=sys.stderr)
+        if not p2p:
+            lib.lcg_hip_p2p_disconnect()
+
+    def close(u, v):    # the direct path adds a row's remote part in another order: rounding only
+        return bool(((u - v).abs().max() <= 1e-12 * v.abs().max()).item())
+
+    def validate(mode):
+        t = [torch.empty_like(b) for _ in range(12)]
+        for i, ti in enumerate(t):          # alternating inputs expose stale buffers and parity slips
+            A.spmv(xt if i % 2 == 0 else x2, ti)
+        api.synchronize()
+        for i, ti in enumerate(t):
+            ref = b if i % 2 == 0 else b2
+            ok = torch.equal(ti, ref) if mode == 1 else close(ti, ref)
+            if not ok:
+                raise RuntimeError(f"product {i} of exchange mode {mode} differs from the all-gather product")
+
+    def teardown_p2p(why):
+        nonlocal p2p
+        p2p = False
+        lib.lcg_hip_p2p_enable(0)
+        A.distribute(n, 0)
+        lib.lcg_hip_p2p_disconnect()
+        if rank == 0:
+            print(f"[bench] direct paths switched off: {why}", file=sys.stderr)
+
+    forced = "LCG_HIP_DIST_MODE" in os.environ     # an explicit request: only that exchange is tried, and it wins when it validates
+    configs = []        # (exchange mode, all-reduce over the mailboxes?)
+    for mode in (0, 1, 2):
+        if mode > max(want, 0) or (mode == 2 and not p2p) or (forced and mode != want):
+            continue
+        for direct_sum in ((False, True) if p2p else (False,)):
+            if mode == 0 and not direct_sum:
+                continue        # the baseline, measured above
+            configs.append((mode, direct_sum))
+    for mode, direct_sum in configs:
+        if (mode == 2 or direct_sum) and not p2p:
+            continue
+        name = f"{labels[mode]} + {'direct' if direct_sum else 'rccl'} all-reduce"
+        if p2p:
+            lib.lcg_hip_p2p_enable(1 if (direct_sum or mode == 2) else 0)   # mode 2's plan is agreed over the mailboxes
+        if not attempt(lambda: A.distribute(n, mode), f"exchange mode {mode} unavailable"):
+            attempt(lambda: A.distribute(n, 0), "back to all-gather")
+            continue
+        if p2p and not direct_sum:
+            lib.lcg_hip_p2p_enable(0)
+        ok = attempt(lambda: validate(mode), f"{name} failed its check")
+        if ok:
+            res = {}
+
+            def time_it():
+                S.solve(max(1, min(args.warmup, 5)))
+                res["t"] = S.timed(args.steps, 1, 8)
+            ok = attempt(time_it, f"{name} failed while timed")
+            if ok:
+                def resid():
+                    mine, theirs, good = S.residual_ok()
+                    if not good:
+                        raise RuntimeError(f"recomputed {mine:.6e} vs monitored {theirs:.6e}")
+                ok = attempt(resid, f"{name}: monitored residual is not the true one")
+            if ok:
+                t1 = res["t"][0][0]
+                tried[name] = args.steps / t1
+                if t1 < best[0] or (forced and best[1] != want):
+                    best = (t1, mode, direct_sum, None, None, None)
+        if p2p and anybody(lib.lcg_hip_p2p_status() < 0):
+            teardown_p2p("an exchange timed out")
+        attempt(lambda: A.distribute(n, 0), "back to all-gather")
+    # ---- 3. the best validated configuration, measured like the baseline ------------------------------------------------
+    _, mode, direct_sum, times, ax_us, ax_calls = best
+    if p2p:
+        lib.lcg_hip_p2p_set_timeout_ms(20000)
+        lib.lcg_hip_p2p_enable(1 if (direct_sum or mode == 2) else 0)
+    if mode != 0 or direct_sum:
+        done = attempt(lambda: A.distribute(n, mode), "re-distribute under the chosen mode")
+        if done and p2p and not direct_sum:
+            lib.lcg_hip_p2p_enable(0)
+        res = {}
+
+        def final():
+            S.solve(max(1, min(args.warmup, 5)))
+            res["t"] = S.timed(args.steps, args.reps, 8)
+        if done and attempt(final, "chosen configuration failed while timed") and \
+                (forced or sorted(res["t"][0])[len(res["t"][0]) // 2] < base_med):
+            times, ax_us, ax_calls = res["t"]
+        else:       # never report less than the baseline that was measured
+            mode, direct_sum = 0, False
+            if p2p:
+                lib.lcg_hip_p2p_enable(0)
+            attempt(lambda: A.distribute(n, 0), "back to all-gather")
+            times, ax_us, ax_calls = base_times, base_ax_us, base_ax_calls
+    probe = {"configurations_it_per_s": {k: round(v, 1) for k, v in tried.items()},
+             "chosen": f"{labels[mode]} + {'direct' if direct_sum else 'rccl'} all-reduce",
+             "direct_paths": "connected and self-tested" if p2p else f"not used: {p2p_why}"}
+    # what the two collectives of an iteration cost on this node's links (dependent back-to-back calls)
+    try:
+        one = torch.ones(8, dtype=torch.float64, device="cuda")
+        ys = torch.empty_like(xt)
+        for name, call, reps in (("allreduce_4_doubles_us", lambda: lib.lcg_hip_allreduce_sum(one.data_ptr(), 4), 200),
+                                 ("ax_with_exchange_us", lambda: A.spmv(xt, ys), 50)):
+            for _ in range(5):
+                call()
+            api.synchronize(); barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                call()
+            api.synchronize()
+            probe[name] = allmax((time.perf_counter() - t0) / reps * 1e6)
+    except Exception as exc:
+        probe["probe_error"] = str(exc)
+    return times, ax_us, ax_calls, check, labels[mode], probe, (p2p and (direct_sum or mode == 2))
 
 
 def cpu_baseline(A, b, n, args, np):

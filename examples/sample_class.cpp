@@ -76,7 +76,9 @@ int main(int argc, char **argv)
         s.set_lcg_parameter(p);
         for (lcg_solver_enum id : {LCG_PG, LCG_SPG}) {
             std::fill(m.begin(), m.end(), 0.0);
-            s.MinimizeConstrained(m.data(), b.data(), low.data(), hig.data(), n, id, false);
+            // silent mode + a negative code (here: 40 iterations reached) throws, exactly as solver.cpp:174-178 does
+            try { s.MinimizeConstrained(m.data(), b.data(), low.data(), hig.data(), n, id, false); bad++; }
+            catch (const std::runtime_error &e) { if (std::string(e.what()) != "Reached the maximal iteration times.") bad++; }
             double mn = m[0], mx = m[0];
             for (double v : m) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
             std::printf("class %s: iterations=%d residual=%.10e min=%g max=%g\n", id == LCG_PG ? "PG" : "SPG", lcg_hip_last_iterations(),

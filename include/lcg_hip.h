@@ -199,10 +199,19 @@ int lcg_hip_csr_set_packed(lcg_hip_csr_t A, int mode);
  * 2048 rows, ds_add_f64) -- 28.5 streamed bytes per entry instead of 12 + a cache line per gather.  The plan
  * (re-ordered copy of the matrix: +26.5 B per entry) is built on the device at the first product.
  * mode: -1 automatic (real matrices of >= 4M entries and >= 1M columns whose 64-row blocks span on average
- * >= 2^21 columns; LCG_HIP_BINNED_SPAN changes that threshold), 0 never (frees the plan), 1 whenever eligible.
+ * >= 2^20 columns; LCG_HIP_BINNED_SPAN changes that threshold), 0 never (frees the plan), 1 whenever eligible.
  * LCG_HIP_BINNED=0/1 overrides for the whole process.  y differs from the row-block kernels' y in the last
  * bits (products are rounded before the add); it is bit-identical from call to call and from plan to plan. */
 int lcg_hip_csr_set_binned(lcg_hip_csr_t A, int mode);
+/* One-pass "tiled" A.x for matrices whose rows draw their columns at random from a band: the row-block kernels
+ * find x in the L2 there but move a 128-byte line per 8-byte gather.  A workgroup owns 4 x 1024 rows (sums in LDS),
+ * walks the column tiles they touch, copies each tile of x (4096 entries) into LDS and streams the rows' entries of
+ * that tile (val + a 32-bit (row, column) pair: 12 B per entry, as CSR).  mode: -1 automatic (real matrices of
+ * >= 4M entries whose columns do not run along diagonals and whose (workgroup, tile) pairs hold >= 700 entries on
+ * average: LCG_HIP_TILED_FILL), 0 never (frees the plan), 1 whenever eligible; LCG_HIP_TILED=0/1 overrides for the
+ * process.  Same determinism and the same last-bit deviation from the row-block kernels as the binned product. */
+int lcg_hip_csr_set_tiled(lcg_hip_csr_t A, int mode);
+const char *lcg_hip_csr_tiled_status(lcg_hip_csr_t A);
 /* Why A has (or has not) a binned plan: "ready", or the reason it is not used (static string). */
 const char *lcg_hip_csr_binned_status(lcg_hip_csr_t A);
 /* Name of the kernel family the latest product with A used (static string; "" before the first product). */
@@ -312,6 +321,9 @@ int lcg_hip_p2p_connect(int nranks, int rank, const void *handles);
 int lcg_hip_p2p_selftest(int rounds);
 int lcg_hip_p2p_enable(int on);
 int lcg_hip_p2p_status(void);
+/* Time-out of the waits on peer data (mailbox sums at once; a matrix's direct exchange from its next
+ * lcg_hip_csr_distribute(A, n, 2) on): short while a node's links are being probed, long in production. */
+int lcg_hip_p2p_set_timeout_ms(int ms);
 int lcg_hip_p2p_disconnect(void);
 /* Test hooks for the sharded product on ONE GPU: split a shard as rank `rank` of `nranks`
  * with no communicator; the caller fills the other ranks' slices of the gather buffer

@@ -70,6 +70,8 @@ SIGNATURES = {
     "lcg_hip_csr_set_kernel": (C.c_int, [vp, C.c_int]),
     "lcg_hip_csr_set_packed": (C.c_int, [vp, C.c_int]),
     "lcg_hip_csr_set_binned": (C.c_int, [vp, C.c_int]),
+    "lcg_hip_csr_set_tiled": (C.c_int, [vp, C.c_int]),
+    "lcg_hip_csr_tiled_status": (C.c_char_p, [vp]),
     "lcg_hip_csr_binned_status": (C.c_char_p, [vp]),
     "lcg_hip_csr_last_kernel": (C.c_char_p, [vp]),
     "lcg_hip_csr_last_traffic_model": (C.c_int64, [vp]),
@@ -107,6 +109,7 @@ SIGNATURES = {
     "lcg_hip_p2p_selftest": (C.c_int, [C.c_int]),
     "lcg_hip_p2p_enable": (C.c_int, [C.c_int]),
     "lcg_hip_p2p_status": (C.c_int, []),
+    "lcg_hip_p2p_set_timeout_ms": (C.c_int, [C.c_int]),
     "lcg_hip_p2p_disconnect": (C.c_int, []),
     "lcg_hip_csr_split_for_test": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int]),
     "lcg_hip_csr_xfull": (vp, [vp]),

@@ -1195,6 +1195,13 @@ int lcg_hip_p2p_enable(int on)
     return 0;
 }
 
+int lcg_hip_p2p_set_timeout_ms(int ms)
+{
+    if (ms < 1) return LCG_HIP_E_ARG;
+    g_xg.timeout_ticks = (long long)ms * 100000LL;      // picked up by the next exchange; direct plans copy it when they are made
+    return 0;
+}
+
 int lcg_hip_p2p_status(void)
 {
     if (!g_xg.connected) return 0;

@@ -496,7 +496,7 @@ __global__ __launch_bounds__(64) void k_span_sum(int n, const int *__restrict__ 
 
 static double span_threshold()
 {   // LCG_HIP_BINNED_SPAN: mean block span (columns) from which the automatic choice takes the binned product
-    static const double v = [] { const char *e = std::getenv("LCG_HIP_BINNED_SPAN"); return e ? atof(e) : (double)(1 << 19); }();
+    static const double v = [] { const char *e = std::getenv("LCG_HIP_BINNED_SPAN"); return e ? atof(e) : (double)(1 << 20); }();
     return v;
 }
 
@@ -529,6 +529,52 @@ static bool binned_chosen(const CsrPart &P, hipStream_t s)
     return true;
 }
 
+// ---- row-random bands: which matrices take the one-pass tiled product (csr_tiled.hip) ------------------------------
+// fraction of entries whose column is exactly one more than the entry in the same slot of the row above: ~1 for
+// diagonals / stencils (a wavefront's gather is then one contiguous run and the row-block kernels are at their best),
+// ~0 when every row draws its own columns
+__global__ __launch_bounds__(VB) void k_diag_like(int n, const int *__restrict__ rowptr, const int *__restrict__ col, unsigned long long *sum)
+{
+    const int i = blockIdx.x * VB + threadIdx.x;
+    unsigned cnt = 0;
+    if (i + 1 < n) {
+        const int a = rowptr[i], b = rowptr[i + 1], c = rowptr[i + 2];
+        const int m = min(b - a, c - b);
+        for (int s = 0; s < m; s++) cnt += col[a + s] + 1 == col[b + s];
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(sum, (unsigned long long)cnt);
+}
+
+static bool tiled_chosen(const CsrPart &P, hipStream_t s)
+{
+    if (P.tl_state != 0) return P.tl_state > 0;
+    static const int env = [] { const char *e = std::getenv("LCG_HIP_TILED"); return e ? atoi(e) : -1; }();
+    const int mode = env >= 0 ? env : P.tl_mode;
+    if (mode == 0 || P.n_cols <= 0 || P.nnz <= 0) { P.tl_state = -1; P.tl_why = mode == 0 ? "switched off" : "empty matrix or unknown column count"; return false; }
+    double min_fill = 0.0;
+    if (mode < 0) {
+        if (P.nnz < (1 << 22) || P.n_cols < (1 << 18)) { P.tl_state = -1; P.tl_why = "automatic mode: fewer than 4M entries or 256K columns"; return false; }
+        if (P.diag_like < 0.0) {
+            unsigned long long *d = nullptr, h = 0;
+            bool ok = hipMalloc(&d, sizeof h) == hipSuccess && hipMemsetAsync(d, 0, sizeof h, s) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(k_diag_like, dim3((P.n_rows + VB - 1) / VB), dim3(VB), 0, s, P.n_rows, P.rowptr, P.col, d);
+                ok = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+            }
+            if (d) hipFree(d);
+            if (!ok) { (void)hipGetLastError(); P.tl_state = -1; return false; }
+            P.diag_like = (double)h / (double)P.nnz;
+        }
+        if (P.diag_like > 0.5) { P.tl_state = -1; P.tl_why = "automatic mode: the columns run along diagonals (the row-block kernels gather contiguously)"; return false; }
+        static const double fill = [] { const char *e = std::getenv("LCG_HIP_TILED_FILL"); return e ? atof(e) : 700.0; }();
+        min_fill = fill;
+    }
+    const int rc = tiled_ready(P, s, min_fill);
+    if (rc <= 0) { P.tl_state = -1; return false; }
+    return true;
+}
+
 template <class V, bool ACC, bool PUSH = false>
 static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V *x, V *y, hipStream_t s,
                          const int *done, const PushPlan &pp = PushPlan())
@@ -539,6 +585,10 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
         if (n > 0 && (variant == 0 || variant == -1) && binned_chosen(P, s)) {
             P.last_kernel = "k_bin_expand + k_bin_reduce (two-pass binned product, x and row sums in LDS)";
             return binned_launch(P, reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), s, done);
+        }
+        if (n > 0 && (variant == 0 || variant == -1) && tiled_chosen(P, s)) {
+            P.last_kernel = "k_tile_spmv (one-pass tiled product: x tiles and row sums in LDS)";
+            return tiled_launch(P, reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), s, done);
         }
     }
     if (n == 0) {
@@ -1038,6 +1088,7 @@ static int alloc_part(CsrPart &P, int n_rows, long nnz, bool cplx)
 void free_part(CsrPart &P)
 {
     binned_free(P);
+    tiled_free(P);
     if (P.owned) { hipFree(P.rowptr); hipFree(P.col); hipFree(P.val); }
     if (P.pk_base) hipFree(P.pk_base);
     if (P.pk_ofs) hipFree(P.pk_ofs);
@@ -1319,6 +1370,23 @@ int lcg_hip_csr_set_binned(lcg_hip_csr_t A, int mode)
     return 0;
 }
 
+int lcg_hip_csr_set_tiled(lcg_hip_csr_t A, int mode)
+{
+    if (!A || mode < -1 || mode > 1) return LCG_HIP_E_ARG;
+    for (CsrPart *P : {&A->main, &A->loc}) {
+        P->tl_mode = mode;
+        if (mode == 0) tiled_free(*P);
+        else if (P->tl_state < 0) P->tl_state = 0;
+    }
+    return 0;
+}
+
+const char *lcg_hip_csr_tiled_status(lcg_hip_csr_t A)
+{
+    if (!A) return "";
+    return A->distributed ? A->loc.tl_why : A->main.tl_why;
+}
+
 const char *lcg_hip_csr_last_kernel(lcg_hip_csr_t A)
 {
     if (!A) return "";
@@ -1335,7 +1403,7 @@ int64_t lcg_hip_csr_last_traffic_model(lcg_hip_csr_t A)
 {
     if (!A) return 0;
     const CsrPart &P = A->distributed ? A->loc : A->main;
-    return P.bn_state > 0 ? binned_traffic_bytes(P) : 0;
+    return P.bn_state > 0 ? binned_traffic_bytes(P) : (P.tl_state > 0 ? tiled_traffic_bytes(P) : 0);
 }
 
 int lcg_hip_csr_build_jacobi(lcg_hip_csr_t A, double *diag_out)

@@ -150,6 +150,12 @@ struct CsrPart {
     mutable void *bn_plan = nullptr;
     mutable const char *bn_why = "not tried";   // why the plan is (not) there
     mutable double mean_span = -1.0;    // mean column span of a 64-row block (-1 = not measured)
+    mutable double diag_like = -1.0;    // fraction of entries whose column is one more than the entry above them (-1 = not measured)
+    // one-pass "tiled" product for row-random bands (csr_tiled.hip), plan built on first use
+    mutable int tl_mode = -1;      // -1 auto, 0 never, 1 whenever eligible
+    mutable int tl_state = 0;      // 0 not tried, 1 plan ready, -1 not eligible / not chosen
+    mutable void *tl_plan = nullptr;
+    mutable const char *tl_why = "not tried";
     mutable const char *last_kernel = "";   // name of the kernel family the latest product used
 };
 
@@ -195,6 +201,12 @@ int binned_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, c
 void binned_free(CsrPart &P);
 long binned_traffic_bytes(const CsrPart &P);
 size_t binned_plan_bytes(const CsrPart &P);
+// csr_tiled.hip
+int tiled_ready(const CsrPart &P, hipStream_t s, double min_fill);      // 1 plan ready, 0 not eligible, < 0 failure
+int tiled_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done_flag);
+void tiled_free(CsrPart &P);
+long tiled_traffic_bytes(const CsrPart &P);
+long tiled_tile_copy_bytes(const CsrPart &P);
 int op_part(lcg_hip_csr *A, int layout, int conjugate, const CsrPart **out);
 
 // comm.hip

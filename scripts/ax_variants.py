@@ -34,7 +34,8 @@ for pat in [int(p) for p in args.patterns.split(",")]:
     nnz = A.nnz
     byts = 12 * nnz + 4 * (n + 1) + 16 * n
     for mode in args.modes.split(","):
-        assert lib.lcg_hip_csr_set_binned(A.h, 1 if mode == "binned" else 0) == 0
+        assert lib.lcg_hip_csr_set_binned(A.h, {"binned": 1, "auto": -1}.get(mode, 0)) == 0
+        assert lib.lcg_hip_csr_set_tiled(A.h, {"tiled": 1, "auto": -1}.get(mode, 0)) == 0
         api.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         api.use_torch_stream()

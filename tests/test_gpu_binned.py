@@ -1,6 +1,6 @@
 """-m gpu: the two-pass binned A.x (liblcg_amd/csrc/csr_binned.hip) for scattered columns -- the arbitrary user CSR
-of the reference's cudaAx callback (sample8.cu:96-103) at its worst -- against the oracle's row-by-row product and
-against the row-block kernels on the same matrix.
+of the reference's cudaAx callback (sample8.cu:96-103) at its worst -- and the one-pass tiled A.x (csr_tiled.hip) for
+row-random bands, against the oracle's row-by-row product and against the row-block kernels on the same matrix.
 
 Band: the binned product rounds every a*x before adding it and sums a row in column order, the row-block kernels run
 four FMA chains per row and a tree: both are within a few ulp of |A||x| per row, so the test bounds
@@ -35,26 +35,29 @@ def _ragged(rng, n, ncols, max_len, long_rows=()):
     return rp, col
 
 
-def _check(api, lib, port, rp, col, val, x, ncols, expect_binned=True):
+def _check(api, lib, port, rp, col, val, x, ncols, expect_binned=True, fmt="binned"):
+    setter = lib.lcg_hip_csr_set_binned if fmt == "binned" else lib.lcg_hip_csr_set_tiled
+    status = lib.lcg_hip_csr_binned_status if fmt == "binned" else lib.lcg_hip_csr_tiled_status
+    name = b"k_bin_expand" if fmt == "binned" else b"k_tile_spmv"
     n = len(rp) - 1
     ref = port.csr_matvec(rp, col, val, x)
     bound = port.csr_matvec(rp, col, np.abs(val), np.abs(x))
     A = api.CsrMatrix.from_csr(rp, col, val, n_cols=ncols)
     xd = torch.from_numpy(x).cuda()
     y0 = torch.full((n,), 7.0, dtype=torch.float64, device="cuda"); y1 = y0.clone(); y2 = y0.clone()
-    assert lib.lcg_hip_csr_set_binned(A.h, 0) == 0
+    assert lib.lcg_hip_csr_set_binned(A.h, 0) == 0 and lib.lcg_hip_csr_set_tiled(A.h, 0) == 0
     A.spmv(xd, y0); api.synchronize()
-    assert b"bin" not in lib.lcg_hip_csr_last_kernel(A.h)
-    assert lib.lcg_hip_csr_set_binned(A.h, 1) == 0
+    assert b"k_spmv" in lib.lcg_hip_csr_last_kernel(A.h)
+    assert setter(A.h, 1) == 0
     A.spmv(xd, y1); A.spmv(xd, y2); api.synchronize()
-    assert (b"k_bin_expand" in lib.lcg_hip_csr_last_kernel(A.h)) == expect_binned, lib.lcg_hip_csr_binned_status(A.h)
-    assert (lib.lcg_hip_csr_binned_status(A.h) == b"ready") == expect_binned
+    assert (name in lib.lcg_hip_csr_last_kernel(A.h)) == expect_binned, status(A.h)
+    assert (status(A.h) == b"ready") == expect_binned
     assert torch.equal(y1, y2)                                      # call to call: same bits
     for y in (y0, y1):
         assert np.all(np.abs(y.cpu().numpy() - ref) <= 1e-13 * bound + 1e-300)
     if expect_binned:                                               # plan to plan: same bits
         B = api.CsrMatrix.from_csr(rp, col, val, n_cols=ncols)
-        assert lib.lcg_hip_csr_set_binned(B.h, 1) == 0
+        assert lib.lcg_hip_csr_set_binned(B.h, 0) == 0 and lib.lcg_hip_csr_set_tiled(B.h, 0) == 0 and setter(B.h, 1) == 0
         y3 = torch.empty_like(y1)
         B.spmv(xd, y3); api.synchronize()
         assert torch.equal(y1, y3)
@@ -78,6 +81,37 @@ def test_ragged_fuzz_against_the_oracle(api, lib, port):
         val = rng.standard_normal(rp[-1])
         x = rng.standard_normal(ncols)
         _check(api, lib, port, rp, col, val, x, ncols)
+        _check(api, lib, port, rp, col, val, x, ncols, fmt="tiled")
+
+
+def test_tiled_band_shapes(api, lib, port):
+    """The tiled product on what it is for: rows that draw their columns inside a band -- chunk (1024 rows), workgroup
+    (4096 rows) and tile (4096 columns) boundaries, groups longer than the six prefetched steps (768 entries) and
+    shorter than one, an unaligned x, odd group lengths (the padding pair), empty rows and an empty trailing chunk."""
+    rng = np.random.default_rng(77)
+    for n, band, per_row in ((4096, 300, 5), (4097, 9000, 33), (20000, 2000, 40), (9000, 70000, 3), (1023, 50, 7), (5000, 4096, 64)):
+        ncols = n
+        lens = rng.integers(0, per_row + 1, n); lens[rng.integers(0, n, n // 20)] = 0
+        rp = np.zeros(n + 1, np.int32); np.cumsum(lens, out=rp[1:])
+        rows = np.repeat(np.arange(n), lens)
+        col = np.clip(rows + rng.integers(-band, band + 1, rp[-1]), 0, ncols - 1).astype(np.int32)
+        val = rng.standard_normal(rp[-1])
+        x = rng.standard_normal(ncols + 1)[1:]                      # 8-byte aligned only once on the device? (copy is aligned) -- see below
+        _check(api, lib, port, rp, col, val, x, ncols, fmt="tiled")
+    # an x that is only 8-byte aligned on the device
+    n = 10000
+    rp = np.arange(0, 8 * n + 1, 8, dtype=np.int32)
+    col = np.clip(np.repeat(np.arange(n), 8) + rng.integers(-3000, 3001, 8 * n), 0, n - 1).astype(np.int32)
+    val = rng.standard_normal(8 * n); x = rng.standard_normal(n)
+    A = api.CsrMatrix.from_csr(rp, col, val)
+    assert lib.lcg_hip_csr_set_tiled(A.h, 1) == 0
+    buf = torch.zeros(n + 1, dtype=torch.float64, device="cuda"); buf[1:] = torch.from_numpy(x).cuda()
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    A.spmv(buf[1:], y); api.synchronize()
+    assert b"k_tile_spmv" in lib.lcg_hip_csr_last_kernel(A.h)
+    ref = port.csr_matvec(rp, col, val, x); bound = port.csr_matvec(rp, col, np.abs(val), np.abs(x))
+    assert np.all(np.abs(y.cpu().numpy() - ref) <= 1e-13 * bound + 1e-300)
+    A.destroy()
 
 
 def test_padding_never_touches_x_it_does_not_own(api, lib, port):
@@ -88,17 +122,19 @@ def test_padding_never_touches_x_it_does_not_own(api, lib, port):
     rp, col = _ragged(rng, n, ncols, 12)
     val = rng.standard_normal(rp[-1])
     x = rng.standard_normal(ncols)
-    for bad in (0, 8192, 16384, 39999):
-        x2 = x.copy(); x2[bad] = np.nan
-        A = api.CsrMatrix.from_csr(rp, col, val, n_cols=ncols)
-        assert lib.lcg_hip_csr_set_binned(A.h, 1) == 0
-        y = torch.empty(n, dtype=torch.float64, device="cuda")
-        A.spmv(torch.from_numpy(x2).cuda(), y); api.synchronize()
-        touched = np.zeros(n, bool)
-        rows = np.repeat(np.arange(n), np.diff(rp))
-        touched[rows[col == bad]] = True
-        assert np.array_equal(np.isnan(y.cpu().numpy()), touched), bad
-        A.destroy()
+    for bad in (0, 4096, 8192, 16384, 39999):
+        for setter in (lib.lcg_hip_csr_set_binned, lib.lcg_hip_csr_set_tiled):
+            x2 = x.copy(); x2[bad] = np.nan
+            A = api.CsrMatrix.from_csr(rp, col, val, n_cols=ncols)
+            assert lib.lcg_hip_csr_set_binned(A.h, 0) == 0 and lib.lcg_hip_csr_set_tiled(A.h, 0) == 0 and setter(A.h, 1) == 0
+            y = torch.empty(n, dtype=torch.float64, device="cuda")
+            A.spmv(torch.from_numpy(x2).cuda(), y); api.synchronize()
+            assert b"k_spmv" not in lib.lcg_hip_csr_last_kernel(A.h)
+            touched = np.zeros(n, bool)
+            rows = np.repeat(np.arange(n), np.diff(rp))
+            touched[rows[col == bad]] = True
+            assert np.array_equal(np.isnan(y.cpu().numpy()), touched), bad
+            A.destroy()
 
 
 def test_dense_groups_and_out_of_range_columns(api, lib, port):
@@ -124,16 +160,18 @@ def test_automatic_choice_and_solvers(api, lib, port):
     CGS and BiCGStab on a scattered system through the binned product meet the oracle's solutions."""
     from oracle import pyoracle as po
     n = 1_500_000
-    for pattern, band, want in ((api.GEN_SCRAMBLED, 0, True), (api.GEN_DIAGONALS, 4000, False), (api.GEN_ROW_RANDOM_BAND, 4000, False)):
+    for pattern, band, want in ((api.GEN_SCRAMBLED, 0, b"k_bin_expand"), (api.GEN_DIAGONALS, 40000, b"k_spmv_ldsp"),
+                                (api.GEN_ROW_RANDOM_BAND, 40000, b"k_tile_spmv")):
         A = api.CsrMatrix.generate(n, 16, band, True, 3, 0.01, pattern=pattern)
         x = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 3, 0, n, x)
         y = torch.empty_like(x); y2 = torch.empty_like(x)
         A.spmv(x, y); api.synchronize()
-        assert (b"k_bin_expand" in lib.lcg_hip_csr_last_kernel(A.h)) == want, (pattern, lib.lcg_hip_csr_last_kernel(A.h))
-        if want:
-            assert lib.lcg_hip_csr_last_traffic_model(A.h) > 20 * A.nnz
-            assert lib.lcg_hip_csr_set_binned(A.h, 0) == 0
+        assert want in lib.lcg_hip_csr_last_kernel(A.h), (pattern, lib.lcg_hip_csr_last_kernel(A.h), lib.lcg_hip_csr_binned_status(A.h), lib.lcg_hip_csr_tiled_status(A.h))
+        if want != b"k_spmv_ldsp":
+            assert lib.lcg_hip_csr_last_traffic_model(A.h) >= 12 * A.nnz
+            assert lib.lcg_hip_csr_set_binned(A.h, 0) == 0 and lib.lcg_hip_csr_set_tiled(A.h, 0) == 0
             A.spmv(x, y2); api.synchronize()
+            assert b"k_spmv" in lib.lcg_hip_csr_last_kernel(A.h)
             assert ((y - y2).abs().max() <= 1e-13 * y2.abs().max()).item()
         A.destroy()
     n = 50_000

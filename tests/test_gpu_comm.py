@@ -69,7 +69,11 @@ def test_one_rank_communicator_reproduces_unsharded_run(mode):
     assert forced["config"]["nnz"] == plain["config"]["nnz"]
     assert forced["steps"] == plain["steps"] == 30
     # same matrix, same arithmetic: the error after 30 iterations agrees to rounding
-    assert abs(forced["rel_err_vs_x_true"] - plain["rel_err_vs_x_true"]) <= 1e-6 * plain["rel_err_vs_x_true"] + 1e-15
+    fc, pc = forced["solution_check"], plain["solution_check"]
+    assert abs(fc["rel_err_vs_x_true_after_100_iterations"] - pc["rel_err_vs_x_true_after_100_iterations"]) <= 1e-4 * pc["rel_err_vs_x_true_after_100_iterations"]
+    # the monitored residual after 25 iterations (the classic schedule unsharded, one reduction sharded: same iterates)
+    assert abs(fc["residual_monitored_after_25"] - pc["residual_monitored_after_25"]) <= 1e-6 * pc["residual_monitored_after_25"]
+    assert forced["value_rccl_allgather"] > 0 and "all-gather + rccl all-reduce" in forced["comm_probe"]["configurations_it_per_s"]
 
 
 def _solve_cases(tmp_path, tag, extra_env):
