@@ -782,7 +782,10 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
         PushPlan pp, cp; WaitPlan wp;
         direct_plans(A, x, &pp, &wp, &cp);
         const double mean_l = A->n_rows ? (double)A->loc.nnz / A->n_rows : 0.0;
-        int rc = spmv_launch_push(A->loc, A->is_complex, A->variant, mean_l, x, y, c.stream, done, pp);
+        // test hook (tests/test_gpu_direct.py): this rank computes but never pushes -- what a dead link looks like to its neighbours
+        static const bool withhold = std::getenv("LCG_HIP_TEST_WITHHOLD_PUSH") != nullptr;
+        int rc = withhold ? spmv_launch(A->loc, A->is_complex, A->variant, mean_l, x, y, false, c.stream, done)
+                          : spmv_launch_push(A->loc, A->is_complex, A->variant, mean_l, x, y, c.stream, done, pp);
         if (rc) return rc;
         // One stream by default: product (+ pushing blocks) | k_recv | k_remote, no event at all.
         // LCG_HIP_DIRECT_STREAMS=2 puts the receiving kernels on the second stream -- enqueued AFTER the

@@ -18,6 +18,7 @@
 // builder measures that and refuses otherwise (scattered columns: the binned product; structured ones: csr.hip).
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "devcommon.hpp"
@@ -26,8 +27,7 @@ namespace lcgh {
 
 int device_exclusive_scan(int n, const int *counts, int *rowptr, hipStream_t s, long *total);   // csr.hip
 
-constexpr int TL_RW = 1024;         // rows per wavefront (sums: 8 KB of LDS)
-constexpr int TL_NW = 4;            // wavefronts (chunks) per workgroup
+constexpr int TL_MAXNW = 8;         // most wavefronts (chunks) per workgroup
 constexpr int TL_C = 4096;          // columns per tile (32 KB of LDS)
 constexpr int TL_C_LOG2 = 12;
 constexpr int TL_MAXSPAN = 2048;    // most tiles one workgroup's rows may span (LDS histogram of the builder: 4 x 8 KB)
@@ -37,6 +37,7 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 
 struct TiledPlan {
+    int rw = 1024, nw = 4;          // rows per wavefront (sums in LDS), wavefronts (chunks) per workgroup
     int n_rows = 0, nwg = 0;
     long n_cols = 0, entries = 0, pairs = 0;
     double *val2 = nullptr;
@@ -48,7 +49,7 @@ struct TiledPlan {
 };
 
 // ---------------------------------------------------------------------------------------------- the product
-template <int UN>
+template <int TL_RW, int TL_NW, int UN>
 __global__ __launch_bounds__(TL_NW * 64) void k_tile_spmv(int n, const int *__restrict__ tmin, const int *__restrict__ nspan,
                                                           const int *__restrict__ sofs, const int *__restrict__ gstart,
                                                           const int *__restrict__ binofs, const double *__restrict__ val2,
@@ -58,7 +59,10 @@ __global__ __launch_bounds__(TL_NW * 64) void k_tile_spmv(int n, const int *__re
     __shared__ __attribute__((aligned(16))) double sx[TL_C];
     __shared__ __attribute__((aligned(16))) double ys[TL_NW][TL_RW];
     if (done && *done) return;
-    const int g = blockIdx.x, tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    // the wavefront's index as a SCALAR: the group bounds below are then scalar loads (s_load), issued one tile
+    // ahead -- as vector loads they were a dependent L2 round trip in front of every tile's requests
+    const int g = blockIdx.x, tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = g * TL_NW + w;
     const long row0 = (long)chunk * TL_RW;
     double *my = ys[w];
@@ -71,12 +75,23 @@ __global__ __launch_bounds__(TL_NW * 64) void k_tile_spmv(int n, const int *__re
     const int *gs = gstart + (long)sofs[g] * TL_NW;
     const long bin = binofs[chunk];
     const bool x16 = (((uintptr_t)x) & 15) == 0;
+    // bounds of this wavefront's group of tile 0 and whether any wavefront has entries in it; refreshed one tile ahead
+    int a_nx = 0, b_nx = 0, any_nx = 0;
+    if (ns > 0) {
+        a_nx = gs[w]; b_nx = gs[TL_NW + w];
+        any_nx = 0;
+#pragma unroll
+        for (int q = 0; q < TL_NW; q++) any_nx += gs[TL_NW + q] - gs[q];
+    }
     for (int lt = 0; lt < ns; lt++) {
-        // this wavefront's group of the tile: [a, b) relative to its bin (the list carries one item more than tiles)
-        const int a = gs[lt * TL_NW + w], b = gs[(lt + 1) * TL_NW + w];
-        // a tile none of the four wavefronts has entries in is skipped by all of them (uniform decision)
-        const int any = gs[(lt + 1) * TL_NW + 0] - gs[lt * TL_NW + 0] + gs[(lt + 1) * TL_NW + 1] - gs[lt * TL_NW + 1] +
-                        gs[(lt + 1) * TL_NW + 2] - gs[lt * TL_NW + 2] + gs[(lt + 1) * TL_NW + 3] - gs[lt * TL_NW + 3];
+        const int a = a_nx, b = b_nx, any = any_nx;
+        if (lt + 1 < ns) {      // scalar loads for the NEXT tile: their latency runs beside this tile's work
+            a_nx = gs[(lt + 1) * TL_NW + w]; b_nx = gs[(lt + 2) * TL_NW + w];
+            any_nx = 0;
+#pragma unroll
+            for (int q = 0; q < TL_NW; q++) any_nx += gs[(lt + 2) * TL_NW + q] - gs[(lt + 1) * TL_NW + q];
+        }
+        // a tile none of the wavefronts has entries in is skipped by all of them (uniform decision)
         if (any == 0) continue;
         // the group's first UN steps are requested BEFORE the tile is copied: their HBM latency runs beside the copy
         v2d_t va[UN]; v2u_t ia[UN];
@@ -89,31 +104,36 @@ __global__ __launch_bounds__(TL_NW * 64) void k_tile_spmv(int n, const int *__re
             ia[u] = *reinterpret_cast<const v2u_t *>(idx2 + pc);
         }
         __syncthreads();                                // the previous tile's readers are done
+        // the slice of x (issuing these loads in front of the barrier as well was measured: no gain, 16 more registers)
         const long c0 = (long)(t0 + lt) << TL_C_LOG2;
         const int cn = (int)min((long)TL_C, n_cols - c0);
+        constexpr int NL = TL_C / 2 / (TL_NW * 64);
+        v2d_t xr[NL];
         if (x16 && cn == TL_C) {
-            constexpr int NL = TL_C / 2 / (TL_NW * 64);
-            v2d_t v[NL];
 #pragma unroll
-            for (int q = 0; q < NL; q++) v[q] = *reinterpret_cast<const v2d_t *>(x + c0 + 2 * (q * TL_NW * 64 + tid));
-#pragma unroll
-            for (int q = 0; q < NL; q++) reinterpret_cast<v2d_t *>(sx)[q * TL_NW * 64 + tid] = v[q];
+            for (int q = 0; q < NL; q++) xr[q] = *reinterpret_cast<const v2d_t *>(x + c0 + 2 * (q * TL_NW * 64 + tid));
         } else {
-            constexpr int NL = TL_C / (TL_NW * 64);
-            double v[NL];
 #pragma unroll
-            for (int q = 0; q < NL; q++) { const int i = q * TL_NW * 64 + tid; v[q] = x[c0 + (i < cn ? i : 0)]; }
-#pragma unroll
-            for (int q = 0; q < NL; q++) sx[q * TL_NW * 64 + tid] = v[q];
+            for (int q = 0; q < NL; q++) {
+                const int i = 2 * (q * TL_NW * 64 + tid);
+                xr[q].x = x[c0 + (i < cn ? i : 0)];
+                xr[q].y = x[c0 + (i + 1 < cn ? i + 1 : 0)];
+            }
         }
-        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < UN; u++) {
-            if (p0 + 128L * u < pe) {
-                const unsigned i0 = ia[u].x, i1 = ia[u].y;
-                __hip_atomic_fetch_add(my + (i0 >> 16), va[u].x * sx[i0 & 0xffffu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if ((i1 >> 16) != TL_PAD)
-                    __hip_atomic_fetch_add(my + (i1 >> 16), va[u].y * sx[i1 & 0xffffu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int q = 0; q < NL; q++) reinterpret_cast<v2d_t *>(sx)[q * TL_NW * 64 + tid] = xr[q];
+        __syncthreads();
+        {
+            double x0[UN], x1[UN];
+#pragma unroll
+            for (int u = 0; u < UN; u++) { x0[u] = sx[ia[u].x & (TL_C - 1)]; x1[u] = sx[ia[u].y & (TL_C - 1)]; }
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                if (p0 + 128L * u < pe) {
+                    __hip_atomic_fetch_add(my + (ia[u].x >> 16), va[u].x * x0[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((ia[u].y >> 16) != TL_PAD)
+                        __hip_atomic_fetch_add(my + (ia[u].y >> 16), va[u].y * x1[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
         // groups longer than UN steps (128 entries each): the rest, four steps in flight
@@ -144,13 +164,13 @@ __global__ __launch_bounds__(TL_NW * 64) void k_tile_spmv(int n, const int *__re
 
 // ---------------------------------------------------------------------------------------------- building the plan
 // per workgroup (4096 rows): smallest and largest tile its entries touch
-__global__ __launch_bounds__(256) void k_tl_span(int n, long n_cols, const int *__restrict__ rowptr, const int *__restrict__ col,
+__global__ __launch_bounds__(256) void k_tl_span(int n, int rows_per_wg, long n_cols, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                  int *tmin, int *nspan, int *flags)
 {
     __shared__ int slo[4], shi[4];
     const int g = blockIdx.x, tid = threadIdx.x;
-    const long r0 = (long)g * TL_RW * TL_NW;
-    const int r1 = (int)min((long)n, r0 + TL_RW * TL_NW);
+    const long r0 = (long)g * rows_per_wg;
+    const int r1 = (int)min((long)n, r0 + rows_per_wg);
     const int k0 = rowptr[r0], k1 = rowptr[r1];
     int lo = 0x7fffffff, hi = -1;
     bool bad = false;
@@ -172,14 +192,14 @@ __global__ __launch_bounds__(256) void k_tl_span(int n, long n_cols, const int *
 
 // per workgroup: entries per (wavefront, local tile), padded to even, scanned per wavefront into group starts;
 // gstart carries nspan + 1 items per workgroup (the last one = the bins' lengths)
-__global__ __launch_bounds__(256) void k_tl_count(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                  const int *__restrict__ tmin, const int *__restrict__ nspan,
-                                                  const int *__restrict__ sofs, int *gstart, int *binlen, unsigned long long *pairs)
+__global__ __launch_bounds__(64 * TL_MAXNW) void k_tl_count(int n, int TL_RW, int TL_NW, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                           const int *__restrict__ tmin, const int *__restrict__ nspan,
+                                                           const int *__restrict__ sofs, int *gstart, int *binlen, unsigned long long *pairs)
 {
-    extern __shared__ int hist[];       // [4][ns]
+    extern __shared__ int hist[];       // [nw][ns]
     const int g = blockIdx.x, tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int t0 = tmin[g], ns = nspan[g];
-    for (int i = tid; i < TL_NW * ns; i += 256) hist[i] = 0;
+    for (int i = tid; i < TL_NW * ns; i += 64 * TL_NW) hist[i] = 0;
     __syncthreads();
     const long r0 = (long)(g * TL_NW + w) * TL_RW;
     const int ra = (int)min((long)n, r0), rb = (int)min((long)n, r0 + TL_RW);
@@ -200,7 +220,7 @@ __global__ __launch_bounds__(256) void k_tl_count(int n, const int *__restrict__
     if (l == 0) { out[ns * TL_NW + w] = run; binlen[g * TL_NW + w] = run; }
     // (workgroup, tile) pairs that hold anything: what the tile copies will cost
     if (w == 0) {
-        for (int lt = l; lt < ns; lt += 64) used += (hist[lt] + hist[ns + lt] + hist[2 * ns + lt] + hist[3 * ns + lt]) > 0;
+        for (int lt = l; lt < ns; lt += 64) { int h = 0; for (int q = 0; q < TL_NW; q++) h += hist[q * ns + lt]; used += h > 0; }
         for (int off = 32; off > 0; off >>= 1) used += __shfl_down(used, off, 64);
         if (l == 0) atomicAdd(pairs, (unsigned long long)used);
     }
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(256) void k_tl_count(int n, const int *__restrict__
 
 // one wavefront per chunk walks its entries in CSR order, 64 at a time; rank inside the group = entries of that tile
 // placed so far + lower lanes of the batch with the same tile (one ballot per distinct tile): no atomics, no sort
-__global__ __launch_bounds__(64) void k_tl_place(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
+__global__ __launch_bounds__(64) void k_tl_place(int n, int TL_RW, int TL_NW, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                  const double *__restrict__ val, const int *__restrict__ tmin,
                                                  const int *__restrict__ nspan, const int *__restrict__ sofs,
                                                  const int *__restrict__ gstart, const int *__restrict__ binofs,
@@ -267,6 +287,17 @@ void tiled_free(CsrPart &P)
 }
 
 // min_fill: least mean number of entries per (workgroup, tile) pair for the plan to be worth building (0 = build anyway)
+struct TiledShape { int rw, nw, un; };
+static TiledShape tiled_shape()
+{   // LCG_HIP_TILED_SHAPE: 0 = 4 x 1024 rows (default), 1 = 8 x 512 rows, 2 = 8 x 1024 rows (one workgroup per CU)
+    static const int v = [] { const char *e = std::getenv("LCG_HIP_TILED_SHAPE"); return e ? atoi(e) : 0; }();
+    switch (v) {
+    case 1: return {512, 8, 3};
+    case 2: return {1024, 8, 6};
+    default: return {1024, 4, 6};
+    }
+}
+
 static int plan_build(const CsrPart &P, hipStream_t s, double min_fill, TiledPlan **out, const char **why)
 {
     *out = nullptr;
@@ -274,9 +305,11 @@ static int plan_build(const CsrPart &P, hipStream_t s, double min_fill, TiledPla
     const long n_cols = P.n_cols;
     *why = "empty matrix or unknown column count";
     if (n <= 0 || n_cols <= 0 || P.nnz <= 0) return 0;
+    const TiledShape shape = tiled_shape();
+    const int TL_RW = shape.rw, TL_NW = shape.nw;
     const int nwg = (n + TL_RW * TL_NW - 1) / (TL_RW * TL_NW);
     TiledPlan *T = new TiledPlan();
-    T->n_rows = n; T->nwg = nwg; T->n_cols = n_cols;
+    T->n_rows = n; T->nwg = nwg; T->n_cols = n_cols; T->rw = TL_RW; T->nw = TL_NW;
     int *flags = nullptr, *binlen = nullptr;
     unsigned long long *pairs = nullptr;
     auto cleanup = [&](int rc) {
@@ -291,11 +324,12 @@ static int plan_build(const CsrPart &P, hipStream_t s, double min_fill, TiledPla
     TCHK(hipMalloc(&T->sofs, sizeof(int) * ((size_t)nwg + 1)));
     TCHK(hipMalloc(&T->binofs, sizeof(int) * ((size_t)nwg * TL_NW + 1)));
     TCHK(hipMalloc(&binlen, sizeof(int) * (size_t)nwg * TL_NW));
+    static_assert(TL_MAXSPAN * TL_MAXNW * sizeof(int) <= 65536, "builder histogram must fit the default dynamic LDS");
     TCHK(hipMalloc(&flags, 2 * sizeof(int)));
     TCHK(hipMalloc(&pairs, sizeof(unsigned long long)));
     TCHK(hipMemsetAsync(flags, 0, 2 * sizeof(int), s));
     TCHK(hipMemsetAsync(pairs, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(k_tl_span, dim3(nwg), dim3(256), 0, s, n, n_cols, P.rowptr, P.col, T->tmin, T->nspan, flags);
+    hipLaunchKernelGGL(k_tl_span, dim3(nwg), dim3(256), 0, s, n, TL_RW * TL_NW, n_cols, P.rowptr, P.col, T->tmin, T->nspan, flags);
     TCHK(hipGetLastError());
     int hflags[2] = {0, 0};
     TCHK(hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, s));
@@ -319,8 +353,8 @@ static int plan_build(const CsrPart &P, hipStream_t s, double min_fill, TiledPla
     hipFree(span1);
     if (rc) return cleanup(rc);
     TCHK(hipMalloc(&T->gstart, sizeof(int) * (size_t)items * TL_NW));
-    hipLaunchKernelGGL(k_tl_count, dim3(nwg), dim3(256), sizeof(int) * TL_NW * (size_t)hflags[1], s, n, P.rowptr, P.col, T->tmin, T->nspan,
-                       T->sofs, T->gstart, binlen, pairs);
+    hipLaunchKernelGGL(k_tl_count, dim3(nwg), dim3(64 * TL_NW), sizeof(int) * TL_NW * (size_t)hflags[1], s, n, TL_RW, TL_NW, P.rowptr, P.col,
+                       T->tmin, T->nspan, T->sofs, T->gstart, binlen, pairs);
     TCHK(hipGetLastError());
     long total = 0;
     rc = device_exclusive_scan(nwg * TL_NW, binlen, T->binofs, s, &total);
@@ -336,8 +370,8 @@ static int plan_build(const CsrPart &P, hipStream_t s, double min_fill, TiledPla
     TCHK(hipMalloc(&T->idx2, sizeof(unsigned) * e2));
     TCHK(hipMemsetAsync(T->val2, 0, sizeof(double) * e2, s));
     TCHK(hipMemsetAsync(T->idx2, 0xff, sizeof(unsigned) * e2, s));
-    hipLaunchKernelGGL(k_tl_place, dim3(nwg * TL_NW), dim3(64), sizeof(int) * (size_t)hflags[1], s, n, P.rowptr, P.col, P.val, T->tmin, T->nspan,
-                       T->sofs, T->gstart, T->binofs, T->val2, T->idx2);
+    hipLaunchKernelGGL(k_tl_place, dim3(nwg * TL_NW), dim3(64), sizeof(int) * (size_t)hflags[1], s, n, TL_RW, TL_NW, P.rowptr, P.col, P.val,
+                       T->tmin, T->nspan, T->sofs, T->gstart, T->binofs, T->val2, T->idx2);
     TCHK(hipGetLastError());
     TCHK(hipStreamSynchronize(s));
     T->bytes = e2 * 12 + (size_t)items * TL_NW * 4 + (size_t)nwg * (12 + 4 * TL_NW);
@@ -366,8 +400,13 @@ int tiled_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, co
 {
     const TiledPlan *T = static_cast<const TiledPlan *>(P.tl_plan);
     if (!T) return fail(hipErrorInvalidValue, "tiled A.x without a plan", __FILE__, __LINE__);
-    hipLaunchKernelGGL((k_tile_spmv<6>), dim3(T->nwg), dim3(TL_NW * 64), 0, s, T->n_rows, T->tmin, T->nspan, T->sofs, T->gstart, T->binofs,
-                       T->val2, T->idx2, x, T->n_cols, y, done);
+#define TL_LAUNCH(RW, NW, UN)                                                                                                  \
+    hipLaunchKernelGGL((k_tile_spmv<RW, NW, UN>), dim3(T->nwg), dim3(NW * 64), 0, s, T->n_rows, T->tmin, T->nspan, T->sofs, T->gstart, \
+                       T->binofs, T->val2, T->idx2, x, T->n_cols, y, done)
+    if (T->rw == 512 && T->nw == 8) TL_LAUNCH(512, 8, 3);
+    else if (T->rw == 1024 && T->nw == 8) TL_LAUNCH(1024, 8, 6);
+    else TL_LAUNCH(1024, 4, 6);
+#undef TL_LAUNCH
     HIPCHK(hipGetLastError());
     return 0;
 }

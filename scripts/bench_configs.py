@@ -59,7 +59,7 @@ def fixed_iter_run(name, A, n, solver, iters, words, ax_per_it, jacobi=False):
     byts = ax_per_it * spmv_bytes(n, nnz) + 8 * words * n
     emit(config=name, rows=n, nnz=nnz, iterations=info.iterations, ret=info.ret, it_per_s=iters / dt, ms_per_it=1e3 * dt / iters,
          algorithmic_GBs=byts / (dt / iters) / 1e9, ax_mean_us=ax_us, ax_GBs=spmv_bytes(n, nnz) / (ax_us * 1e-6) / 1e9 if ax_us else None,
-         rel_err=((m - xt).norm() / xt.norm()).item())
+         rel_err=((m - xt).norm() / xt.norm()).item(), ax_kernel=lib.lcg_hip_csr_last_kernel(A.h).decode())
 
 
 def main():
@@ -88,10 +88,11 @@ def main():
         fixed_iter_run("2b: Laplace2D 1000x1000 CG 500 its", A, 1_000_000, api.LCG_CG, 500, 13, 1)
     if "c3" in what:
         n = 10_000_000
-        for band in (131072, 16384, 2048, 0):
-            A = api.CsrMatrix.generate(n, 16, band, True, 1, 0.01)
-            fixed_iter_run(f"3: 10M banded W={band} CG 100 its" if band else "3: 10M scrambled CG 20 its", A, n, api.LCG_CG,
-                           100 if band else 20, 13, 1)
+        for pattern, band, label in ((1, 131072, "33 constant diagonals W=131072"), (1, 2048, "33 constant diagonals W=2048"),
+                                     (2, 131072, "row-random band W=131072"), (2, 16384, "row-random band W=16384"),
+                                     (2, 1048576, "row-random band W=1048576"), (0, 0, "scrambled")):
+            A = api.CsrMatrix.generate(n, 16, band, True, 1, 0.01, pattern=pattern)
+            fixed_iter_run(f"3: 10M {label} CG 50 its", A, n, api.LCG_CG, 50, 13, 1)
             A.destroy()
     if "c5" in what:
         n = 10_000_000

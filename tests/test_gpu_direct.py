@@ -118,3 +118,39 @@ def test_three_ranks_on_one_gpu_direct_exchange(tmp_path, streams):
     for key in res[0]:
         if "/" in key and isinstance(res[0][key], list):
             assert len({tuple(r[key][:2]) for r in res}) == 1, key
+
+
+def _spawn(tmp_path, world, port, extra):
+    procs, outs = [], []
+    for r in range(world):
+        out = str(tmp_path / f"wh_{extra.get('PHASE', '1')}_{r}.json")
+        outs.append(out)
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **extra)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_withhold_worker.py"), out],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    logs = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(so[-1500:] + se[-3000:])
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    return [json.load(open(o)) for o in outs]
+
+
+def test_a_rank_that_withholds_its_pushes(tmp_path):
+    """The push path's failure mode (the mailboxes have theirs in tests/test_gpu_p2p.py): rank 1 of 3 multiplies but never
+    writes its boundary entries of x to its neighbours.  Nothing hangs: the neighbours' receive kernels give up after the
+    1.5 s time-out, their solves return LCG_HIP_E_COMM (-2002), they stop feeding the mailbox all-reduce, so the faulty
+    rank's solve ends the same way; every rank can see the verdict (lcg_hip_p2p_status() < 0 somewhere => the vote is
+    positive everywhere), tears the paths down, and a fresh connection without the fault runs the exchange again."""
+    res = _spawn(tmp_path, 3, 29581, {"WITHHOLD": "1"})
+    assert all(r["solve_rc"] == -2002 for r in res), res
+    assert all(r["votes"] >= 1 for r in res) and all(r["seconds"] < 60 for r in res), res
+    assert any(r["status_after"] == -1 for r in res)
+    res = _spawn(tmp_path, 3, 29582, {"WITHHOLD": "1", "PHASE": "2"})
+    assert all(r["product"] == [0, 0, 2] and r["votes"] == 0 for r in res), res
+    assert all(r["solve_rc"] in (0, -1019) for r in res), res
