@@ -1365,7 +1365,7 @@ int lcg_hip_csr_set_binned(lcg_hip_csr_t A, int mode)
     for (CsrPart *P : {&A->main, &A->loc}) {
         P->bn_mode = mode;
         if (mode == 0) binned_free(*P);     // gives the plan's memory back
-        else if (P->bn_state < 0) P->bn_state = 0;     // decide again at the next product
+        else P->bn_state = 0;               // decide again at the next product (a plan that exists is kept and reused)
     }
     return 0;
 }
@@ -1376,7 +1376,7 @@ int lcg_hip_csr_set_tiled(lcg_hip_csr_t A, int mode)
     for (CsrPart *P : {&A->main, &A->loc}) {
         P->tl_mode = mode;
         if (mode == 0) tiled_free(*P);
-        else if (P->tl_state < 0) P->tl_state = 0;
+        else P->tl_state = 0;               // decide again at the next product (a plan that exists is kept and reused)
     }
     return 0;
 }

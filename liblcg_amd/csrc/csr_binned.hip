@@ -396,6 +396,7 @@ static int plan_build(const CsrPart &P, hipStream_t s, BinnedPlan **out, const c
 int binned_ready(const CsrPart &P, hipStream_t s)
 {
     if (P.bn_state != 0) return P.bn_state > 0 ? 1 : 0;
+    if (P.bn_plan) { P.bn_state = 1; return 1; }       // built earlier (e.g. under a forced mode): reuse
     P.bn_state = -1;
     BinnedPlan *B = nullptr;
     int rc = plan_build(P, s, &B, &P.bn_why);

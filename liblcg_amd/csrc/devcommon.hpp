@@ -12,6 +12,8 @@
 // never waits for a scalar inside the loop.
 #pragma once
 
+#include <cstdlib>
+
 #include "internal.hpp"
 
 namespace lcgh {
@@ -65,9 +67,8 @@ __device__ __forceinline__ bool should_skip(const DevState *st, int mode)
 //               template<class T> void apply(long i, double *acc);   T = double2 (two reals /
 //               one complex) or double (scalar tail, real only)
 template <class Op, bool VEC2>
-__global__ __launch_bounds__(VB) void k_vec(Op op, long n, double *partials)
+__device__ __forceinline__ void vec_body(Op &op, long n, double *partials)
 {
-    if (should_skip(op.st, Op::SKIP)) return;
     constexpr int NRA = Op::NR > 0 ? Op::NR : 1;
     double acc[NRA];
 #pragma unroll
@@ -83,6 +84,13 @@ __global__ __launch_bounds__(VB) void k_vec(Op op, long n, double *partials)
         for (long i = tid; i < n; i += stride) op.template apply<double>(i, acc);
     }
     if (Op::NR > 0) block_reduce_store<NRA>(acc, partials);
+}
+
+template <class Op, bool VEC2>
+__global__ __launch_bounds__(VB) void k_vec(Op op, long n, double *partials)
+{
+    if (should_skip(op.st, Op::SKIP)) return;
+    vec_body<Op, VEC2>(op, n, partials);
 }
 
 template <class T> __device__ __forceinline__ T ld(const double *p, long i);
@@ -276,6 +284,7 @@ __device__ __forceinline__ bool wait_flags(const WaitPlan &wp)
 __device__ __forceinline__ void publish(DevState *st)
 {
     HostStatus *h = st->host;
+    if (!h) return;         // a block's private copy of the state (k_vecf): only block 0 mirrors to the host
     // the kernel cannot retire before these PCIe writes are acknowledged (a few us): between stops
     // the mirror is refreshed only every (pub_mask + 1)-th body -- enough for the host's pacing
     if (!st->done && (st->it & st->pub_mask)) return;
@@ -297,47 +306,54 @@ __device__ __forceinline__ void stop_rule(DevState *st, double g2, double m2)
     if (r <= st->eps) { st->done = 1; st->status = ST_CONVERGED; }
 }
 
+// Sum the G partials of each of NRA running sums (table row r = partials + r*MAXG) into sums[r] (LDS), every thread of the
+// block taking part.  All NRA * MAXG/VB loads of a lane are issued before the first add (a dependent load-add chain made
+// the one-block kernel take 16 us); fixed order => the same bits wherever and however often this runs.
+template <int NRA>
+__device__ __forceinline__ void reduce_partials(const double *partials, int G, double *sums)
+{
+    constexpr int PER = MAXG / VB;
+    double acc[NRA], v[NRA][PER];
+#pragma unroll
+    for (int r = 0; r < NRA; r++)
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int j = threadIdx.x + q * VB;
+            const double x = partials[r * MAXG + (j < G ? j : 0)];     // branch-free: select after the load
+            v[r][q] = j < G ? x : 0.0;
+        }
+#pragma unroll
+    for (int r = 0; r < NRA; r++) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < PER; q++) t += v[r][q];
+        acc[r] = t;
+    }
+    __shared__ double sh[NRA][VB / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < NRA; r++) {
+        double t = wave_sum(acc[r]);
+        if (lane == 0) sh[r][w] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NRA) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < VB / 64; k++) t += sh[threadIdx.x][k];
+        sums[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
 template <class Fin>
 __global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, int G, DevState *st, int mode, XgBox xb)
 {
     constexpr int NRA = Fin::NR > 0 ? Fin::NR : 1;
     __shared__ double sums[NRA];
     if (mode != SC_FIN && Fin::NR > 0) {
-        // all NRA * MAXG/VB loads of a lane are issued before the first add (a dependent
-        // load-add chain made this one-block kernel take 16 us); fixed order => reproducible
-        constexpr int PER = MAXG / VB;
-        double acc[NRA], v[NRA][PER];
-#pragma unroll
-        for (int r = 0; r < NRA; r++)
-#pragma unroll
-            for (int q = 0; q < PER; q++) {
-                const int j = threadIdx.x + q * VB;
-                const double x = partials[r * MAXG + (j < G ? j : 0)];     // branch-free: select after the load
-                v[r][q] = j < G ? x : 0.0;
-            }
-#pragma unroll
-        for (int r = 0; r < NRA; r++) {
-            double t = 0.0;
-#pragma unroll
-            for (int q = 0; q < PER; q++) t += v[r][q];
-            acc[r] = t;
-        }
-        __shared__ double sh[NRA][VB / 64];
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-        for (int r = 0; r < NRA; r++) {
-            double v = wave_sum(acc[r]);
-            if (lane == 0) sh[r][w] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < NRA) {
-            double v = 0.0;
-#pragma unroll
-            for (int k = 0; k < VB / 64; k++) v += sh[threadIdx.x][k];
-            sums[threadIdx.x] = v;
-            if (mode == SC_REDUCE) st->red[threadIdx.x] = v;
-        }
-        __syncthreads();
+        reduce_partials<NRA>(partials, G, sums);
+        if (mode == SC_REDUCE && threadIdx.x < NRA) st->red[threadIdx.x] = sums[threadIdx.x];
     } else if (Fin::NR > 0) {
         if (threadIdx.x < NRA) sums[threadIdx.x] = st->red[threadIdx.x];
         __syncthreads();
@@ -352,11 +368,49 @@ __global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, in
     if (mode != SC_REDUCE && threadIdx.x == 0) fin(st, sums);
 }
 
+// ---- scalar step fused into the pass that consumes it (single GPU) ------------------------------------------------
+// One CG iteration used to be six kernels, two of them one-block scalar steps on the critical path (5-8 us each plus a
+// kernel boundary).  Here EVERY block of the consuming pass sums the <= 512 partials of the previous pass itself -- in
+// reduce_partials' fixed order, so every block obtains the same bits -- and runs the scalar recurrence on a private copy
+// of DevState in LDS; the pass reads its coefficients (and the stop flag) from that copy.  Block 0 alone commits the copy,
+// to the OTHER buffer of a pair (`next`): no block ever reads a field another block is rewriting, and the kernels enqueued
+// afterwards are handed `next` as their state.  Partial sums ping-pong between two tables for the same reason.
+template <class Fin, class Op, bool VEC2>
+__global__ __launch_bounds__(VB) void k_vecf(Fin fin, Op op, long n, const double *pin, int G, double *pout, const DevState *cur, DevState *next)
+{
+    constexpr int NRF = Fin::NR > 0 ? Fin::NR : 1;
+    __shared__ DevState L;
+    __shared__ double sums[NRF];
+    static_assert(sizeof(DevState) % 8 == 0, "DevState is copied in 8-byte words");
+    {
+        const double *src = reinterpret_cast<const double *>(cur);
+        double *dst = reinterpret_cast<double *>(&L);
+        for (int i = threadIdx.x; i < (int)(sizeof(DevState) / 8); i += VB) dst[i] = src[i];
+    }
+    reduce_partials<NRF>(pin, G, sums);      // ends with a barrier: L and sums are complete
+    if (threadIdx.x == 0) {
+        if (blockIdx.x != 0) L.host = nullptr;
+        fin(&L, sums);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        const double *src = reinterpret_cast<const double *>(&L);
+        double *dst = reinterpret_cast<double *>(next);
+        for (int i = threadIdx.x; i < (int)(sizeof(DevState) / 8); i += VB) dst[i] = src[i];
+    }
+    op.st = &L;
+    if (should_skip(&L, Op::SKIP)) return;
+    vec_body<Op, VEC2>(op, n, pout);
+}
+
 inline int grid_for(long n_items)
 {
+    // 512 blocks (two per CU) keep the BLAS-1 passes at their bandwidth (measured on the 10M-row system: 2048 / 1024 / 512
+    // blocks = 171 / 172 / 166 us of BLAS-1 per CG iteration) and leave a quarter of the partials to re-reduce
+    static const long cap = [] { const char *e = std::getenv("LCG_HIP_MAXGRID"); long v = e ? atol(e) : 512; return v < 1 ? 1 : (v > MAXG ? (long)MAXG : v); }();
     long g = (n_items + VB - 1) / VB;
     if (g < 1) g = 1;
-    if (g > MAXG) g = MAXG;
+    if (g > cap) g = cap;
     return (int)g;
 }
 

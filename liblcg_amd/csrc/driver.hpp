@@ -42,6 +42,7 @@ struct Driver {
         const bool v2 = cplx || ((align_or & 15) == 0);
         const long items = cplx ? n : (v2 ? (n + 1) / 2 : n);
         const int g = grid_for(items);
+        op.st = c.state;        // the state of THIS launch (vecf below moves it between the buffers of a pair)
         if (cplx) {
             hipLaunchKernelGGL((k_vec<Op, false>), dim3(g), dim3(VB), 0, c.stream, op, n, c.partials);
         } else if (v2) {
@@ -51,6 +52,27 @@ struct Driver {
         }
         last_g = g;
         HIPCHK(hipGetLastError());
+        return dbg(typeid(Op).name());
+    }
+    // Scalar step `fin` (on the sums of the latest reducing pass) fused into the pass `op` that consumes its result:
+    // one launch instead of k_scal + k_vec (devcommon.hpp: k_vecf).  Real vectors, one GPU; when the rows are sharded the
+    // sums have to meet the other ranks' first, so the step stays its own kernel(s) around the all-reduce.
+    template <class Fin, class Op> int vecf(Fin fin, Op op, uintptr_t align_or = 0)
+    {
+        static const bool off = std::getenv("LCG_HIP_NO_FUSED_SCALAR") != nullptr;      // A/B runs
+        if (cplx || comm_active() || off) {
+            int rc = scal(fin);
+            return rc ? rc : vec(op, align_or);
+        }
+        const bool v2 = (align_or & 15) == 0;
+        const int g = grid_for(v2 ? (n + 1) / 2 : n);
+        DevState *cur = c.state, *next = c.state == c.state_pair[0] ? c.state_pair[1] : c.state_pair[0];
+        double *pin = c.partials, *pout = c.partials == c.partials_pair[0] ? c.partials_pair[1] : c.partials_pair[0];
+        if (v2) hipLaunchKernelGGL((k_vecf<Fin, Op, true>), dim3(g), dim3(VB), 0, c.stream, fin, op, n, pin, last_g, pout, cur, next);
+        else hipLaunchKernelGGL((k_vecf<Fin, Op, false>), dim3(g), dim3(VB), 0, c.stream, fin, op, n, pin, last_g, pout, cur, next);
+        HIPCHK(hipGetLastError());
+        c.state = next;
+        if (Op::NR > 0) { c.partials = pout; last_g = g; }
         return dbg(typeid(Op).name());
     }
     int last_g = 1;

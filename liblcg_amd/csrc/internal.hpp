@@ -90,8 +90,10 @@ struct Ctx {
     hipStream_t own_stream = nullptr;  // created by the library
     hipStream_t comm_stream = nullptr; // second stream for gather/compute overlap
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    double *partials = nullptr;        // [MAXR][MAXG]
-    DevState *state = nullptr;
+    double *partials = nullptr;        // [MAXR][MAXG]: the table the latest reducing pass wrote (one of partials_pair)
+    DevState *state = nullptr;         // the state the next kernel is handed (one of state_pair: driver.hpp, vecf)
+    double *partials_pair[2] = {nullptr, nullptr};
+    DevState *state_pair[2] = {nullptr, nullptr};
     HostStatus *hstat = nullptr;       // pinned, mapped
     HostStatus *hstat_dev = nullptr;   // device alias of hstat
     double *scratch_host = nullptr;    // pinned, 64 doubles

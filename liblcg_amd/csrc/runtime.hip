@@ -46,9 +46,13 @@ int ensure_init()
     // (with it each hand-off cost ~11 us of cache write-back on the critical path)
     HIPCHK(hipEventCreateWithFlags(&c.ev_a, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK(hipEventCreateWithFlags(&c.ev_b, hipEventDisableTiming | hipEventDisableSystemFence));
-    HIPCHK(hipMalloc(&c.partials, sizeof(double) * MAXR * MAXG));
-    HIPCHK(hipMalloc(&c.state, sizeof(DevState)));
-    HIPCHK(hipMemset(c.state, 0, sizeof(DevState)));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipMalloc(&c.partials_pair[i], sizeof(double) * MAXR * MAXG));
+        HIPCHK(hipMalloc(&c.state_pair[i], sizeof(DevState)));
+        HIPCHK(hipMemset(c.state_pair[i], 0, sizeof(DevState)));
+    }
+    c.partials = c.partials_pair[0];
+    c.state = c.state_pair[0];
     HIPCHK(hipHostMalloc((void **)&c.hstat, sizeof(HostStatus), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void **)&c.hstat_dev, c.hstat, 0));
     HIPCHK(hipHostMalloc((void **)&c.scratch_host, sizeof(double) * 64, hipHostMallocDefault));

@@ -421,10 +421,8 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
     int rc = k.run_loop([&]() -> int {
         TRY(k.ax(d, Ad));                                                        // :232
         TRY(k.drv.vec(OpDot1{st, d, Ad}, al(d) | al(Ad)));                       // :234
-        TRY(k.drv.scal(FinAlpha{}));                                             // :235
-        TRY(k.drv.vec(OpCgUpdate{st, m, g, d, Ad, 0.0}, a_upd));                 // :237-255
-        TRY(k.drv.scal(FinClose<false>{}));                                      // :244-257
-        TRY(k.drv.vec(OpCgDir{st, d, g, 0.0}, al(d) | al(g)));                   // :259-263
+        TRY(k.drv.vecf(FinAlpha{}, OpCgUpdate{st, m, g, d, Ad, 0.0}, a_upd));    // :235, :237-255
+        TRY(k.drv.vecf(FinClose<false>{}, OpCgDir{st, d, g, 0.0}, al(d) | al(g)));   // :244-257, :259-263
         return 0;
     });
     int rc2 = hb.close(c.stream);
@@ -462,16 +460,14 @@ static int solve_pcg(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pf
     int rc = k.run_loop([&]() -> int {
         TRY(k.ax(d, Ad));                                                        // :387
         TRY(k.drv.vec(OpDot1{st, d, Ad}, al(d) | al(Ad)));                       // :389
-        TRY(k.drv.scal(FinAlpha{}));                                             // :390
         if (invdiag) {
-            TRY(k.drv.vec(OpPcgUpdateJacobi{st, m, r, z, d, Ad, invdiag, 0.0}, a_all));   // :392-414
+            TRY(k.drv.vecf(FinAlpha{}, OpPcgUpdateJacobi{st, m, r, z, d, Ad, invdiag, 0.0}, a_all));   // :390, :392-414
         } else {
-            TRY(k.drv.vec(OpPcgUpdate{st, m, r, d, Ad, 0.0}, a_all));            // :392-397
+            TRY(k.drv.vecf(FinAlpha{}, OpPcgUpdate{st, m, r, d, Ad, 0.0}, a_all));   // :390, :392-397
             TRY(k.drv.checked_mx([&] { Mfp(inst, r, z, n); }));                  // :399
             TRY(k.drv.vec(OpPcgDots{st, m, r, z}, a_all));                       // :401-414
         }
-        TRY(k.drv.scal(FinClose<false>{}));                                      // :415-416
-        TRY(k.drv.vec(OpPcgDir{st, d, z, 0.0}, al(d) | al(z)));                  // :418-422
+        TRY(k.drv.vecf(FinClose<false>{}, OpPcgDir{st, d, z, 0.0}, al(d) | al(z)));  // :415-416, :418-422
         return 0;
     });
     int rc2 = hb.close(c.stream);
@@ -502,12 +498,10 @@ static int solve_cgs(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const 
     int rc = k.run_loop([&]() -> int {
         TRY(k.ax(pk, Ax));                                                       // :546
         TRY(k.drv.vec(OpDot1{st, Ax, r0}, a_all));                               // :548-552
-        TRY(k.drv.scal(FinAlpha{}));                                             // :553
-        TRY(k.drv.vec(OpCgsQW{st, u, Ax, q, w, 0.0}, a_all));                    // :556-560
+        TRY(k.drv.vecf(FinAlpha{}, OpCgsQW{st, u, Ax, q, w, 0.0}, a_all));       // :553, :556-560
         TRY(k.ax(w, Ax));                                                        // :562
         TRY(k.drv.vec(OpCgsUpdate{st, m, r, w, Ax, r0, 0.0}, a_all));            // :565-588
-        TRY(k.drv.scal(FinClose<false>{}));                                      // :589-590
-        TRY(k.drv.vec(OpCgsDir{st, u, pk, r, q, 0.0}, a_all));                   // :593-597
+        TRY(k.drv.vecf(FinClose<false>{}, OpCgsDir{st, u, pk, r, q, 0.0}, a_all));   // :589-590, :593-597
         return 0;
     });
     int rc2 = hb.close(c.stream);
@@ -537,14 +531,11 @@ static int solve_bicgstab(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, c
     int rc = k.run_loop([&]() -> int {
         TRY(k.ax(pk, Ap));                                                       // :718
         TRY(k.drv.vec(OpDot1{st, Ap, r0}, a_all));                               // :720-724
-        TRY(k.drv.scal(FinAlpha{}));                                             // :725
-        TRY(k.drv.vec(OpBicgS{st, r, Ap, s, 0.0}, a_all));                       // :727-731
+        TRY(k.drv.vecf(FinAlpha{}, OpBicgS{st, r, Ap, s, 0.0}, a_all));          // :725, :727-731
         TRY(k.ax(s, Ax));                                                        // :733
         TRY(k.drv.vec(OpDot2{st, Ax, s}, a_all));                                // :735-740
-        TRY(k.drv.scal(FinOmega{}));                                             // :741
-        TRY(k.drv.vec(OpBicgUpdate{st, m, r, pk, s, Ax, r0, 0.0, 0.0}, a_all));  // :743-772
-        TRY(k.drv.scal(FinClose<true>{}));                                       // :773-774
-        TRY(k.drv.vec(OpBicgDir{st, pk, r, Ap, 0.0, 0.0}, a_all));               // :776-780
+        TRY(k.drv.vecf(FinOmega{}, OpBicgUpdate{st, m, r, pk, s, Ax, r0, 0.0, 0.0}, a_all));   // :741, :743-772
+        TRY(k.drv.vecf(FinClose<true>{}, OpBicgDir{st, pk, r, Ap, 0.0, 0.0}, a_all));          // :773-774, :776-780
         return 0;
     });
     int rc2 = hb.close(c.stream);
