@@ -314,7 +314,7 @@ template <bool PUSH, int NS, int BITS>
 __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__ rowptr, const v4i *__restrict__ packed,
                                                   const int *__restrict__ pofs, const int *__restrict__ pbase,
                                                   const double *__restrict__ val, const double *__restrict__ x,
-                                                  double *__restrict__ y, const int *done, PushPlan pp, int xmode)
+                                                  double *__restrict__ y, const int *done, PushPlan pp)
 {
     if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
     const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
@@ -391,16 +391,10 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
             c[q] = ok ? cc : 0;         // an empty block never wrote scol[0]: column 0 is always a valid address
             a[q] = sval[ok ? kk - bv : 0];
         }
-        if (xmode == 0) {
+        // (non-temporal gathers: 3.86 instead of 1.44 ms on the row-random band, 0.97 instead of 0.75 on constant diagonals;
+        //  L1-bypassing sc1 gathers: no difference -- measured in round 2 and removed)
 #pragma unroll
-            for (int q = 0; q < UNR; q++) xv[q] = x[c[q]];
-        } else if (xmode == 1) {        // LAB: non-temporal gathers
-#pragma unroll
-            for (int q = 0; q < UNR; q++) xv[q] = __builtin_nontemporal_load(x + c[q]);
-        } else {                        // LAB: L1-bypassing (sc1) gathers
-#pragma unroll
-            for (int q = 0; q < UNR; q++) xv[q] = __hip_atomic_load(const_cast<double *>(x) + c[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        for (int q = 0; q < UNR; q++) xv[q] = x[c[q]];
 #pragma unroll
         for (int q = 0; q < UNR; q++) acc = (k + q * T < re) ? fma(a[q], xv[q], acc) : acc;   // select, not a zero product: same bits as the plain loop
         k += UNR * T;
@@ -631,11 +625,10 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
                 // gathers per lane in the first batch: enough for the longest row when that is 9..12 per lane
                 const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);
                 const int ns = per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
-                static const int xmode = [] { const char *e = std::getenv("LCG_HIP_X_LOAD"); return e ? atoi(e) : 0; }();   // LAB
 #define PK_LAUNCH(NSS, BB)                                                                                          \
         hipLaunchKernelGGL((k_spmv_ldsp<PUSH, NSS, BB>), dim3((n + PK_R - 1) / PK_R + xb), dim3(VB), 0, s, n, P.rowptr, \
                            static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, reinterpret_cast<const double *>(val), \
-                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, pp, xmode)
+                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, pp)
 #define PK_CASE(NSS)                                                                                                \
     case NSS:                                                                                                       \
         if (P.pk_bits == 18) PK_LAUNCH(NSS, 18); else PK_LAUNCH(NSS, 21);                                          \
