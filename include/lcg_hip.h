@@ -207,7 +207,7 @@ int lcg_hip_csr_set_binned(lcg_hip_csr_t A, int mode);
  * find x in the L2 there but move a 128-byte line per 8-byte gather.  A workgroup owns 4 x 1024 rows (sums in LDS),
  * walks the column tiles they touch, copies each tile of x (4096 entries) into LDS and streams the rows' entries of
  * that tile (val + a 32-bit (row, column) pair: 12 B per entry, as CSR).  mode: -1 automatic (real matrices of
- * >= 4M entries whose columns do not run along diagonals and whose (workgroup, tile) pairs hold >= 700 entries on
+ * >= 4M entries whose columns do not run along diagonals and whose (workgroup, tile) pairs hold >= 500 entries on
  * average: LCG_HIP_TILED_FILL), 0 never (frees the plan), 1 whenever eligible; LCG_HIP_TILED=0/1 overrides for the
  * process.  Same determinism and the same last-bit deviation from the row-block kernels as the binned product. */
 int lcg_hip_csr_set_tiled(lcg_hip_csr_t A, int mode);

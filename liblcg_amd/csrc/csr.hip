@@ -561,7 +561,7 @@ static bool tiled_chosen(const CsrPart &P, hipStream_t s)
             P.diag_like = (double)h / (double)P.nnz;
         }
         if (P.diag_like > 0.5) { P.tl_state = -1; P.tl_why = "automatic mode: the columns run along diagonals (the row-block kernels gather contiguously)"; return false; }
-        static const double fill = [] { const char *e = std::getenv("LCG_HIP_TILED_FILL"); return e ? atof(e) : 700.0; }();
+        static const double fill = [] { const char *e = std::getenv("LCG_HIP_TILED_FILL"); return e ? atof(e) : 500.0; }();
         min_fill = fill;
     }
     const int rc = tiled_ready(P, s, min_fill);

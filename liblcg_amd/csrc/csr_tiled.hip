@@ -14,7 +14,7 @@
 // Order of the stream: [chunk of 1024 rows][tile][entries in CSR order]; a group is padded to an even length (padding:
 // row 0xFFFF).  A row is summed by one wavefront in stream order: same bits from call to call and from plan to plan
 // (k_tl_place ranks entries without atomics).  As in csr_binned.hip products are rounded before they are added.
-// Worth it while a (workgroup, tile) pair holds >~ 700 entries (tile copies are L2 traffic: pairs x 32 KB); the plan
+// Worth it while a (workgroup, tile) pair holds >~ 500 entries (tile copies are L2 traffic: pairs x 32 KB); the plan
 // builder measures that and refuses otherwise (scattered columns: the binned product; structured ones: csr.hip).
 #include <algorithm>
 #include <cstring>
