@@ -121,7 +121,8 @@ int    lcg_hip_last_ax_calls(void);
  * Chronopoulos-Gear rearrangement of the same recurrence -- w = A.g is applied to the gradient,
  * A.d follows from Ad = beta Ad - w, and g.g, g.w, m.m share ONE reduction (one RCCL all-reduce
  * per iteration instead of two); same iterates in exact arithmetic, same stop rule and counts.
- * LCG_HIP_CG_AUTO (default): classic on one GPU, one-reduction when the rows are sharded. */
+ * LCG_HIP_CG_AUTO (default): one-reduction when the rows are sharded and, on one GPU, for systems of fewer than 2^17 rows
+ * (an iteration is then a chain of kernel latencies: three launches instead of four); classic otherwise. */
 enum { LCG_HIP_CG_AUTO = 0, LCG_HIP_CG_CLASSIC = 1, LCG_HIP_CG_ONE_REDUCTION = 2 };
 int    lcg_hip_set_cg_schedule(int schedule);
 

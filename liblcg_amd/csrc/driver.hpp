@@ -11,6 +11,7 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <functional>
 #include <cstring>
 #include <thread>
 #include <typeinfo>
@@ -76,6 +77,10 @@ struct Driver {
         return dbg(typeid(Op).name());
     }
     int last_g = 1;
+    // A body whose closing scalar step rides in the NEXT body's first pass (vecf) leaves the last one open: `tail`
+    // closes it, once, after the last body and before the state is read.
+    std::function<int()> tail;
+    int run_tail() { if (!tail) return 0; auto t = std::move(tail); tail = nullptr; return t(); }
     // LCG_HIP_DEBUG_SYNC=1: synchronise after every launch and name it on stderr (fault isolation)
     bool debug_sync = std::getenv("LCG_HIP_DEBUG_SYNC") != nullptr;
     int dbg(const char *what)
@@ -202,6 +207,7 @@ struct Driver {
                 if (h.done) break;
             }
         }
+        rc = run_tail(); if (rc) return rc;
         rc = read_state(h); if (rc) return rc;
         if (h.status == ST_COMM) return comm_lost(h);
         finish(h);

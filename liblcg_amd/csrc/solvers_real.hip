@@ -401,20 +401,39 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
     TRY(k.drv.vec(OpCgInit{st, Ad, B, m, g, d}, al(Ad) | al(B) | al(m) | al(g) | al(d)));
     TRY(k.drv.scal(FinInit{}));
     const uintptr_t a_upd = al(m) | al(g) | al(d) | al(Ad);
+    // AUTO: the one-reduction schedule when the rows are sharded (one all-reduce per iteration) and on one GPU for systems so
+    // small that an iteration is a chain of kernel latencies (< 2^17 rows): three launches per iteration instead of four
     const bool one_reduction = c.cg_schedule == LCG_HIP_CG_ONE_REDUCTION ||
-                               (c.cg_schedule == LCG_HIP_CG_AUTO && comm_active());
+                               (c.cg_schedule == LCG_HIP_CG_AUTO && (comm_active() || n < (1 << 17)));
     if (one_reduction) {
         double *w; TRY(ws.get(w, nullptr, sizeof(double) * n));
         TRY(k.ax(g, w));
         TRY(k.drv.vec(OpDot1{st, g, w}, al(g) | al(w)));
-        TRY(k.drv.scal(FinCg1Start{}));
-        int rc = k.run_loop([&]() -> int {
-            TRY(k.drv.vec(OpCg1Update{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
-            TRY(k.ax(g, w));
-            TRY(k.drv.vec(OpCg1Dots{st, m, g, w}, al(m) | al(g) | al(w)));
-            TRY(k.drv.scal(FinCg1Close{}));
-            return 0;
-        });
+        int rc;
+        if (Pfp == nullptr && !comm_active()) {
+            // One GPU, no progress callback: the scalar step that closes body k rides in the first pass of body k+1
+            // (FinCg1Start in front of the first one), so a body is three launches: update | A.g | dots.  The last body is
+            // closed by the tail.  Same arithmetic in the same order as the four-launch form below.
+            bool first = true;
+            k.drv.tail = [&]() -> int { return first ? k.drv.scal(FinCg1Start{}) : k.drv.scal(FinCg1Close{}); };
+            rc = k.run_loop([&]() -> int {
+                if (first) { TRY(k.drv.vecf(FinCg1Start{}, OpCg1Update{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w))); first = false; }
+                else TRY(k.drv.vecf(FinCg1Close{}, OpCg1Update{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
+                TRY(k.ax(g, w));
+                TRY(k.drv.vec(OpCg1Dots{st, m, g, w}, al(m) | al(g) | al(w)));
+                return 0;
+            });
+            k.drv.tail = nullptr;
+        } else {
+            TRY(k.drv.scal(FinCg1Start{}));
+            rc = k.run_loop([&]() -> int {
+                TRY(k.drv.vec(OpCg1Update{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
+                TRY(k.ax(g, w));
+                TRY(k.drv.vec(OpCg1Dots{st, m, g, w}, al(m) | al(g) | al(w)));
+                TRY(k.drv.scal(FinCg1Close{}));
+                return 0;
+            });
+        }
         int rc2 = hb.close(c.stream);
         return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
     }

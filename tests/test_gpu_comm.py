@@ -74,6 +74,24 @@ def test_one_rank_communicator_reproduces_unsharded_run(mode):
     # the monitored residual after 25 iterations (the classic schedule unsharded, one reduction sharded: same iterates)
     assert abs(fc["residual_monitored_after_25"] - pc["residual_monitored_after_25"]) <= 1e-6 * pc["residual_monitored_after_25"]
     assert forced["value_rccl_allgather"] > 0 and "all-gather + rccl all-reduce" in forced["comm_probe"]["configurations_it_per_s"]
+    assert forced["value"] > 0 and forced["timed_repetitions"] == 5 and forced["value_min"] <= forced["value"] <= forced["value_max"]
+    # the unsharded line names its workload for what it is and carries the three column patterns
+    assert "constant diagonals" in plain["config"]["workload"] and plain["roofline"]["traffic_source"]
+    assert set(plain["variants"]) == {"constant_diagonals", "row_random_band", "scrambled"}
+    assert all(v["it_per_s"] > 0 and 0 < v["frac"] < 1 for v in plain["variants"].values())
+
+
+def test_sharded_products_use_the_tiled_kernel_too():
+    """A row-random band shard under the all-gather exchange: the local-column part (all of it with one rank) is large
+    enough for the automatic choice to take the tiled product; the bench's guard (residual recomputed with a second A.x,
+    100 iterations towards x_true) passes on it."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-variants", "--rows", "1500000", "--band", "40000",
+                        "--pattern", "row_random_band", "--steps", "20", "--warmup", "3", "--reps", "2"], capture_output=True, text=True,
+                       env=dict(os.environ, LCG_HIP_FORCE_COMM="1", LCG_HIP_DIST_MODE="0", MASTER_PORT="29543"), timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert "k_tile_spmv" in out["roofline"]["kernel"], out["roofline"]["kernel"]
+    assert out["solution_check"]["rel_err_vs_x_true_after_100_iterations"] < 1e-3 and "row-random band" in out["config"]["workload"]
 
 
 def _solve_cases(tmp_path, tag, extra_env):
