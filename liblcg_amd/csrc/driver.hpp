@@ -56,16 +56,16 @@ struct Driver {
         return dbg(typeid(Op).name());
     }
     // Scalar step `fin` (on the sums of the latest reducing pass) fused into the pass `op` that consumes its result:
-    // one launch instead of k_scal + k_vec (devcommon.hpp: k_vecf).  Real vectors, one GPU; when the rows are sharded the
+    // one launch instead of k_scal + k_vec (devcommon.hpp: k_vecf).  One GPU; when the rows are sharded the
     // sums have to meet the other ranks' first, so the step stays its own kernel(s) around the all-reduce.
     template <class Fin, class Op> int vecf(Fin fin, Op op, uintptr_t align_or = 0)
     {
         static const bool off = std::getenv("LCG_HIP_NO_FUSED_SCALAR") != nullptr;      // A/B runs
-        if (cplx || comm_active() || off) {
+        if (comm_active() || off) {
             int rc = scal(fin);
             return rc ? rc : vec(op, align_or);
         }
-        const bool v2 = (align_or & 15) == 0;
+        const bool v2 = !cplx && (align_or & 15) == 0;      // complex passes take one 16-byte element per lane (vec_n)
         const int g = grid_for(v2 ? (n + 1) / 2 : n);
         DevState *cur = c.state, *next = c.state == c.state_pair[0] ? c.state_pair[1] : c.state_pair[0];
         double *pin = c.partials, *pout = c.partials == c.partials_pair[0] ? c.partials_pair[1] : c.partials_pair[0];

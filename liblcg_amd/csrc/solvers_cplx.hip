@@ -523,12 +523,10 @@ static int solve_cbicg(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, doubl
     int rc = k.run_loop([&]() -> int {
         TRY(k.ax(d1, Ax));                                              // :169
         TRY(k.drv.vec(OpZDot<true>{st, d2, Ax}));                       // :170
-        TRY(k.drv.scal(FinZAlpha{C_RHO}));                              // :171
-        TRY(k.drv.vec(OpZBicgUpd1{st, m, r1, d1, Ax, {}}));              // :173-178
+        TRY(k.drv.vecf(FinZAlpha{C_RHO}, OpZBicgUpd1{st, m, r1, d1, Ax, {}}));   // :171 | :173-178
         TRY(k.axop(d2, Ax, 1, 1));                                      // :187  A^H.d2
         TRY(k.drv.vec(OpZBicgUpd2{st, r2, Ax, m, r1, {}}));              // :180-203
-        TRY(k.drv.scal(FinZClose<0>{}));                                // :204-205
-        TRY(k.drv.vec(OpZBicgDirPair{st, d1, d2, r1, r2, {}}));             // :207-212
+        TRY(k.drv.vecf(FinZClose<0>{}, OpZBicgDirPair{st, d1, d2, r1, r2, {}}));   // :204-205 | :207-212
         return 0;
     });
     int rc2 = hb.close(c.stream);
@@ -564,16 +562,14 @@ static int solve_cpcg(clcg_hip_axfunc_ptr Afp, clcg_hip_axfunc_ptr Mfp, clcg_hip
     int rc = k.run_loop([&]() -> int {
         TRY(k.ax(d, Ax));                                               // :500
         TRY(k.drv.vec(OpZDot<false>{st, d, Ax}));                       // :501
-        TRY(k.drv.scal(FinZAlpha{C_RHO}));                              // :502
         if (inv) {
-            TRY(k.drv.vec(OpZPcgUpdJacobi{st, m, r, s, d, Ax, inv, {}}));   // :504-516
+            TRY(k.drv.vecf(FinZAlpha{C_RHO}, OpZPcgUpdJacobi{st, m, r, s, d, Ax, inv, {}}));   // :502 | :504-516
         } else {
-            TRY(k.drv.vec(OpZPcgUpd{st, m, r, d, Ax, {}}));             // :504-505
+            TRY(k.drv.vecf(FinZAlpha{C_RHO}, OpZPcgUpd{st, m, r, d, Ax, {}}));             // :502 | :504-505
             TRY(k.drv.checked_mx([&] { Mfp(inst, r, s, n, 0, 0); }));   // :513
             TRY(k.drv.vec(OpZPcgDots{st, m, r, s}));                    // :507-516
         }
-        TRY(k.drv.scal(FinZPcg<false>{}));                              // :517
-        TRY(k.drv.vec(OpZXpay{st, d, s, {}}));                          // :519-520  d = s + b d
+        TRY(k.drv.vecf(FinZPcg<false>{}, OpZXpay{st, d, s, {}}));   // :517 | :519-520  d = s + b d
         return 0;
     });
     int rc2 = hb.close(c.stream);
@@ -601,10 +597,8 @@ static int solve_bicg_sym(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, do
     int rc = k.run_loop([&]() -> int {
         TRY(k.ax(d, Ax));                                               // :319
         TRY(k.drv.vec(OpZDot<false>{st, d, Ax}));                       // :320
-        TRY(k.drv.scal(FinZAlpha{C_RR}));                               // :321
-        TRY(k.drv.vec(OpSymUpdate{st, m, r, d, Ax, {}}));               // :323-345
-        TRY(k.drv.scal(FinZClose<1>{}));                                // :346-347
-        TRY(k.drv.vec(OpZXpay{st, d, r, {}}));                          // :349-353
+        TRY(k.drv.vecf(FinZAlpha{C_RR}, OpSymUpdate{st, m, r, d, Ax, {}}));   // :321 | :323-345
+        TRY(k.drv.vecf(FinZClose<1>{}, OpZXpay{st, d, r, {}}));   // :346-347 | :349-353
         return 0;
     });
     int rc2 = hb.close(c.stream);
@@ -634,12 +628,10 @@ static int solve_ccgs(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, double
     int rc = k.run_loop([&]() -> int {
         TRY(k.ax(pk, Ax));                                              // :463
         TRY(k.drv.vec(OpZDot<true>{st, rb, Ax}));                       // :464
-        TRY(k.drv.scal(FinZAlpha{C_RHO}));                              // :465
-        TRY(k.drv.vec(OpZQW{st, u, Ax, q, w, {}}));                     // :467-472
+        TRY(k.drv.vecf(FinZAlpha{C_RHO}, OpZQW{st, u, Ax, q, w, {}}));   // :465 | :467-472
         TRY(k.ax(w, Ax));                                               // :474
         TRY(k.drv.vec(OpZCgsUpdate{st, m, r, w, Ax, rb, {}}));          // :476-498
-        TRY(k.drv.scal(FinZClose<0>{}));                                // :499-500
-        TRY(k.drv.vec(OpZUP{st, u, pk, r, q, {}}));                     // :502-507
+        TRY(k.drv.vecf(FinZClose<0>{}, OpZUP{st, u, pk, r, q, {}}));   // :499-500 | :502-507
         return 0;
     });
     int rc2 = hb.close(c.stream);
@@ -669,14 +661,11 @@ static int solve_cbicgstab(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, d
     int rc = k.run_loop([&]() -> int {
         TRY(k.ax(pk, Ap));                                              // :620
         TRY(k.drv.vec(OpZDot<true>{st, rb, Ap}));                       // :621
-        TRY(k.drv.scal(FinZAlpha{C_RHO}));                              // :622
-        TRY(k.drv.vec(OpZS{st, r, Ap, s, {}}));                         // :624-628
+        TRY(k.drv.vecf(FinZAlpha{C_RHO}, OpZS{st, r, Ap, s, {}}));   // :622 | :624-628
         TRY(k.ax(s, As));                                               // :630
         TRY(k.drv.vec(OpZOmegaDots{st, As, s}));                        // :631-632
-        TRY(k.drv.scal(FinZOmega{}));                                   // :633
-        TRY(k.drv.vec(OpZBicgUpdate{st, m, r, pk, s, As, rb, {}, {}})); // :635-657
-        TRY(k.drv.scal(FinZClose<2>{}));                                // :658-659
-        TRY(k.drv.vec(OpZBicgDir{st, pk, r, Ap, {}, {}}));              // :661-665
+        TRY(k.drv.vecf(FinZOmega{}, OpZBicgUpdate{st, m, r, pk, s, As, rb, {}, {}}));   // :633 | :635-657
+        TRY(k.drv.vecf(FinZClose<2>{}, OpZBicgDir{st, pk, r, Ap, {}, {}}));   // :658-659 | :661-665
         return 0;
     });
     int rc2 = hb.close(c.stream);
@@ -710,20 +699,15 @@ static int solve_tfqmr(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, doubl
         if (step & 1) {
             TRY(k.ax(pk, v));                                           // :759
             TRY(k.drv.vec(OpZDot<true>{st, rb, v}));                    // :761
-            TRY(k.drv.scal(FinZAlpha{C_RHO}));                          // :762
-            TRY(k.drv.vec(OpZQW{st, u, v, q, uq, {}}));                 // :764-769
+            TRY(k.drv.vecf(FinZAlpha{C_RHO}, OpZQW{st, u, v, q, uq, {}}));   // :762 | :764-769
             TRY(k.ax(uq, Ax));                                          // :771
             TRY(k.drv.vec(OpTfR{st, r, Ax, {}}));                       // :773-779
-            TRY(k.drv.scal(FinTfHead<1>{}));                            // :806-834 (j = 1)
-            TRY(k.drv.vec(OpTfDM{st, d, m, u, {}, {}}));                // :815-840
+            TRY(k.drv.vecf(FinTfHead<1>{}, OpTfDM{st, d, m, u, {}, {}}));   // :806-834 (j = 1) | :815-840
             TRY(k.drv.scal(FinTfStepClose<1>{}));                       // :842-852
         } else {
-            TRY(k.drv.scal(FinTfHead<2>{}));                            // :806-834 (j = 2)
-            TRY(k.drv.vec(OpTfDM{st, d, m, q, {}, {}}));                // :825-840
-            TRY(k.drv.scal(FinTfStepClose<2>{}));                       // :842-852
-            TRY(k.drv.vec(OpZDot<true>{st, rb, r}));                    // :856
-            TRY(k.drv.scal(FinTfTail{}));                               // :853-858
-            TRY(k.drv.vec(OpZUP{st, u, pk, r, q, {}}));                 // :860-865
+            TRY(k.drv.vecf(FinTfHead<2>{}, OpTfDM{st, d, m, q, {}, {}}));   // :806-834 (j = 2) | :825-840
+            TRY(k.drv.vecf(FinTfStepClose<2>{}, OpZDot<true>{st, rb, r}));   // :842-852 | :856
+            TRY(k.drv.vecf(FinTfTail{}, OpZUP{st, u, pk, r, q, {}}));   // :853-858 | :860-865
         }
         return 0;
     });
