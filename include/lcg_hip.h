@@ -202,7 +202,10 @@ int lcg_hip_csr_set_packed(lcg_hip_csr_t A, int mode);
  * mode: -1 automatic (real matrices of >= 4M entries and >= 1M columns whose 64-row blocks span on average
  * >= 2^20 columns; LCG_HIP_BINNED_SPAN changes that threshold), 0 never (frees the plan), 1 whenever eligible.
  * LCG_HIP_BINNED=0/1 overrides for the whole process.  y differs from the row-block kernels' y in the last
- * bits (products are rounded before the add); it is bit-identical from call to call and from plan to plan. */
+ * bits (products are rounded before the add); it is bit-identical from call to call and from plan to plan.
+ * The packed, tiled and binned forms are COPIES of the matrix made at the first product: a caller who rewrites the
+ * arrays of an adopted matrix (lcg_hip_csr_create with adopt != 0) afterwards drops them with set_*(A, 0) and
+ * re-arms the automatic choice with set_*(A, -1). */
 int lcg_hip_csr_set_binned(lcg_hip_csr_t A, int mode);
 /* One-pass "tiled" A.x for matrices whose rows draw their columns at random from a band: the row-block kernels
  * find x in the L2 there but move a 128-byte line per 8-byte gather.  A workgroup owns 4 x 1024 rows (sums in LDS),
