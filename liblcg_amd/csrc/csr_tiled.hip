@@ -295,7 +295,10 @@ void tiled_free(CsrPart &P)
 // min_fill: least mean number of entries per (workgroup, tile) pair for the plan to be worth building (0 = build anyway)
 struct TiledShape { int rw, nw, un; };
 static TiledShape tiled_shape()
-{   // LCG_HIP_TILED_SHAPE: 0 = 4 x 1024 rows (default), 1 = 8 x 512 rows, 2 = 8 x 1024 rows (one workgroup per CU)
+{   // LCG_HIP_TILED_SHAPE (A/B runs): 0 = 4 x 1024 rows (default: 0.82-0.85 ms on the 10M-row row-random band), 1 = 8 x 512 rows
+    // (0.92-0.94), 2 = 8 x 1024 rows, one workgroup per CU (0.93-0.95).  Also measured and removed: a pipeline across tiles with the
+    // next tile's requests in flight during this tile's adds (1.05 ms), and double-buffered tiles with requests two tiles ahead in a
+    // one-workgroup-per-CU shape (1.18 ms) -- two independent workgroups per CU overlap their phases better than either.
     static const int v = [] { const char *e = std::getenv("LCG_HIP_TILED_SHAPE"); return e ? atoi(e) : 0; }();
     switch (v) {
     case 1: return {512, 8, 3};
