@@ -49,7 +49,21 @@ def workload_name(pattern, band, npairs, solver):
     return f"synthetic SPD CSR, {what}, plain {solver.upper()} via lcg_hip_lcg (BASELINE configs[2]/[3])"
 
 
+def emit(line):
+    """The ONE line this program writes to its standard output (file descriptor saved in main())."""
+    os.write(_REAL_STDOUT, (line + "\n").encode())
+
+
+_REAL_STDOUT = 1
+
+
 def main():
+    # Libraries (RCCL prints a version banner) write to descriptor 1 as they please: from here on descriptor 1 IS the
+    # standard error, and the JSON line goes to a private copy of the original standard output.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -227,7 +241,7 @@ def main():
         out.update({"value": 0.0, "ms_per_step": None, "error": f"{type(exc).__name__}: {exc}",
                     "config": {"workload": workload_name(args.pattern, args.band, args.npairs, args.solver)}})
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            emit(json.dumps(out))
         raise
 
     med = statistics.median(times)
@@ -251,7 +265,7 @@ def main():
         shard_bytes = spmv_bytes(nloc, S.nnz_local) if world == 1 else 12 * S.nnz_local + 4 * (nloc + 1) + 8 * n + 8 * nloc
         achieved = shard_bytes / (ax_us * 1e-6) / 1e9
         kernel = lib.lcg_hip_csr_last_kernel(S.A.h).decode()
-        traffic, source = pmc_traffic(args.pattern, kernel) if world == 1 else (None, "not collected for sharded runs")
+        traffic, source = pmc_traffic(args.pattern, kernel, S.nnz_local) if world == 1 and not sharded else (None, "not collected for sharded runs")
         out["roofline"] = {"bound": "hbm", "kernel": kernel if world == 1 else "A.x (local product + x exchange + remote columns): " + kernel,
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": source, "bytes_per_launch": shard_bytes, "avg_launch_us": ax_us,
@@ -283,7 +297,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(S.A, S.b, n, args, np)
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if dist is not None:
         api.synchronize(); barrier()        # nobody unmaps a mailbox a peer may still write to
         lib.lcg_hip_p2p_disconnect()
@@ -322,7 +336,7 @@ def variants(args, System, S, lib, api, n, spmv_bytes, iteration_bytes):
     return res
 
 
-def pmc_traffic(pattern, kernel):
+def pmc_traffic(pattern, kernel, nnz=None):
     """HBM bytes per A.x launch from the committed rocprofv3 --pmc runs (FETCH_SIZE x 2 + WRITE_SIZE as the guide
     prescribes for gfx950), or (None, why).  Counters cannot be read from inside this process; the figure is tied to the
     kernel it was collected on and dropped when another kernel ran."""
@@ -334,6 +348,8 @@ def pmc_traffic(pattern, kernel):
     ent = summ.get("variants", {}).get(pattern)
     if not ent:
         return None, f"profiles/pmc_summary.json holds no entry for {pattern}"
+    if nnz is not None and ent.get("nnz") not in (None, nnz):
+        return None, f"profiles/pmc_summary.json was collected on a matrix of {ent.get('nnz')} entries, this run has {nnz}"
     family = kernel.split(" ")[0]
     if family not in ent.get("kernel", ""):
         return None, f"profiles/pmc_summary.json was collected on {ent.get('kernel', '?')[:60]}, this run used {family}"

@@ -65,6 +65,14 @@ def main():
                        "(calibrated on the BLAS-1 kernels below, whose byte counts are known exactly), so streaming kernels are "
                        "corrected x2; for the row-block kernels' 8-byte x gathers the doubled figure is an upper bound",
                "variants": {}}
+    sizes = {}      # pattern -> (rows, nnz) of the matrices the counters were collected on
+    for f in glob.glob(os.path.join(src, "pmc_FETCH_SIZE.jsonl")):
+        for line in open(f):
+            try:
+                e = json.loads(line)
+                sizes[e["pattern"]] = (e["rows"], e["nnz"])
+            except (ValueError, KeyError):
+                pass
     for pattern, fams in FAMILY.items():
         ks = [k for k in agg if any(f in k for f in fams) and "FETCH_SIZE" in agg[k]]
         if not ks:
@@ -74,6 +82,8 @@ def main():
         ent = {"kernel": " + ".join(k.split("(")[0].replace("void ", "") for k in ks), "fetch_size_raw_bytes": fetch, "write_size_bytes": write,
                "hbm_bytes_per_launch": 2 * fetch + write,
                "collected": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on scripts/ax_variants.py, {summary['collected']}"}
+        if pattern in sizes:
+            ent["rows"], ent["nnz"] = sizes[pattern]
         hit = sum((mean(k, "TCC_HIT_sum") or 0.0) for k in ks); miss = sum((mean(k, "TCC_MISS_sum") or 0.0) for k in ks)
         if hit + miss > 0:
             ent["l2_hit_rate"] = hit / (hit + miss)
