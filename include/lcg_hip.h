@@ -116,6 +116,9 @@ double lcg_hip_last_residual(void);
 int    lcg_hip_set_profiling(int on);
 double lcg_hip_last_ax_mean_us(void);
 int    lcg_hip_last_ax_calls(void);
+/* The solvers keep their temporaries (the reference allocates and frees them per call, lcg.cpp:158-166,266-271) for the
+ * next solve; this gives the idle ones back to the device. */
+int    lcg_hip_trim(void);
 /* How plain CG (LCG_CG, lcg.cpp:143-274) is scheduled.  LCG_HIP_CG_CLASSIC: the reference's own
  * recurrence, two reductions per iteration (d.Ad, then m.m/g.g).  LCG_HIP_CG_ONE_REDUCTION: the
  * Chronopoulos-Gear rearrangement of the same recurrence -- w = A.g is applied to the gradient,

@@ -124,8 +124,15 @@ struct Driver {
         h.pub_mask = comm_active() ? 0x3fffffff : ((cplx ? 2 * n : n) >= (1 << 20) ? 0 : 3);
         if (const char *e = std::getenv("LCG_HIP_PUBLISH_EVERY")) h.pub_mask = std::max(1, atoi(e)) - 1;
         c.hstat->it = 0; c.hstat->done = 0; c.hstat->status = 0; c.hstat->t = 0; c.hstat->residual = 0.0;
-        HIPCHK(hipMemcpyAsync(c.state, &h, sizeof h, hipMemcpyHostToDevice, c.stream));
-        HIPCHK(hipStreamSynchronize(c.stream));
+        (void)lcg_hip_last_ax_mean_us();        // a previous solve's events, if nobody asked yet: they are about to be reused
+        // from a pinned staging slot, in stream order in front of the solve's first kernel: no synchronisation here (the
+        // previous solve ended with one, so the slot is free)
+        *c.state_stage = h;
+        HIPCHK(hipMemcpyAsync(c.state, c.state_stage, sizeof h, hipMemcpyHostToDevice, c.stream));
+        // kernels that a sharded A.x puts on the second stream read the stop flag too, and the direct exchange starts them
+        // without a fork event: they must not see the previous solve's flag
+        HIPCHK(hipEventRecord(c.ev_a, c.stream));
+        HIPCHK(hipStreamWaitEvent(c.comm_stream, c.ev_a, 0));
         return 0;
     }
     int read_state(DevState &h)
@@ -160,13 +167,18 @@ struct Driver {
     int run(Body &&body, bool has_pfp, Pfp &&pfp, int code_max_it, int code_nan)
     {
         DevState h;
-        int rc = read_state(h);
-        if (rc) return rc;
-        if (h.status == ST_ALREADY) {                       // lcg.cpp:186-203
-            if (has_pfp) pfp(h.residual, 0);
-            finish(h);
-            return LCG_ALREADY_OPTIMIZIED;
+        int rc = 0;
+        if (has_pfp) {
+            rc = read_state(h);
+            if (rc) return rc;
+            if (h.status == ST_ALREADY) {                   // lcg.cpp:186-203
+                pfp(h.residual, 0);
+                finish(h);
+                return LCG_ALREADY_OPTIMIZIED;
+            }
         }
+        // (without a progress callback nobody needs the setup's verdict yet: "already optimised" has set the stop flag, the
+        //  bodies enqueued below fall through, and the verdict is read with the final state -- one stream drain less per solve)
         if (has_pfp) {
             for (;;) {                                      // lcg.cpp:206-230, one sync per iteration
                 if (pfp(h.residual, h.t)) { finish(h); return LCG_STOP; }
@@ -211,6 +223,7 @@ struct Driver {
         rc = read_state(h); if (rc) return rc;
         if (h.status == ST_COMM) return comm_lost(h);
         finish(h);
+        if (h.status == ST_ALREADY) return LCG_ALREADY_OPTIMIZIED;
         if (h.status == ST_NAN) return code_nan;
         if (h.done && h.status == ST_CONVERGED) return LCG_CONVERGENCE;
         return code_max_it;
@@ -248,6 +261,7 @@ struct Driver {
         rc = read_state(h); if (rc) return rc;
         if (h.status == ST_COMM) return comm_lost(h);
         finish(h);
+        if (h.status == ST_ALREADY) return LCG_ALREADY_OPTIMIZIED;
         if (h.status == ST_NAN) return code_nan;
         if (h.done && h.status == ST_CONVERGED) return LCG_CONVERGENCE;
         return code_max_it;
@@ -267,16 +281,7 @@ struct Driver {
         c.last_residual = h.residual;
         c.last_ax_calls = c.prof_used / 2;
         c.last_ax_mean_us = 0.0;
-        if (c.profile && c.prof_used >= 2) {
-            hipStreamSynchronize(c.stream);
-            double tot = 0.0;
-            for (int i = 0; i + 1 < c.prof_used; i += 2) {
-                float ms = 0.f;
-                hipEventElapsedTime(&ms, c.prof_ev[i], c.prof_ev[i + 1]);
-                tot += ms;
-            }
-            c.last_ax_mean_us = 1e3 * tot / (c.prof_used / 2);
-        }
+        c.prof_pending = c.profile ? c.prof_used : 0;   // turned into a mean when somebody asks (lcg_hip_last_ax_mean_us)
         c.prof_used = 0;
     }
 };
@@ -313,17 +318,36 @@ struct HostBridge {
 
 // device scratch vectors of one solve (freed on scope exit); caller-provided pointers win
 struct Workspace {
-    std::vector<double *> mine;
     int get(double *&out, double *given, size_t bytes)
     {
         if (given) { out = given; return 0; }
-        double *p = nullptr;
-        HIPCHK(hipMalloc(&p, bytes));
-        mine.push_back(p);
-        out = p;
+        Ctx &c = ctx();
+        int best = -1;
+        for (size_t i = 0; i < c.scratch.size(); i++)
+            if (!c.scratch[i].busy && c.scratch[i].bytes >= bytes && (best < 0 || c.scratch[i].bytes < c.scratch[best].bytes)) best = (int)i;
+        if (best < 0) {
+            // nothing fits: give one idle smaller vector back and allocate
+            for (size_t i = 0; i < c.scratch.size(); i++)
+                if (!c.scratch[i].busy) { (void)hipFree(c.scratch[i].p); c.scratch.erase(c.scratch.begin() + i); break; }
+            double *p = nullptr;
+            HIPCHK(hipMalloc(&p, bytes));
+            c.scratch.push_back({p, bytes, false});
+            best = (int)c.scratch.size() - 1;
+            // indices held by this workspace may have shifted by the erase above: they are re-resolved by pointer below
+        }
+        c.scratch[best].busy = true;
+        held.push_back(c.scratch[best].p);
+        out = c.scratch[best].p;
         return 0;
     }
-    ~Workspace() { for (double *p : mine) hipFree(p); }
+    std::vector<double *> held;
+    ~Workspace()
+    {
+        Ctx &c = ctx();
+        for (double *p : held)
+            for (auto &s : c.scratch)
+                if (s.p == p) s.busy = false;
+    }
 };
 
 } // namespace lcgh

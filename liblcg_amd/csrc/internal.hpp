@@ -112,6 +112,12 @@ struct Ctx {
     int prof_used = 0;
     double last_ax_mean_us = 0.0;
     int last_ax_calls = 0;
+    int prof_pending = 0;              // events of the finished solve not yet turned into last_ax_mean_us (done on demand)
+    DevState *state_stage = nullptr;   // pinned: the initial state of a solve on its way to the device (no stream sync)
+    // scratch vectors of past solves, kept for the next one (hipMalloc + hipFree cost ~0.2 ms per solve, as much as ten
+    // iterations of a small system; lcg_hip_trim() gives them back)
+    struct Scratch { double *p; size_t bytes; bool busy; };
+    std::vector<Scratch> scratch;
     unsigned shadow_seed = 1;
     std::vector<double> shadow_vec;    // explicit rbar0 for the next complex solve
     std::string err;

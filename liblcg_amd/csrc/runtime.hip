@@ -56,6 +56,7 @@ int ensure_init()
     HIPCHK(hipHostMalloc((void **)&c.hstat, sizeof(HostStatus), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void **)&c.hstat_dev, c.hstat, 0));
     HIPCHK(hipHostMalloc((void **)&c.scratch_host, sizeof(double) * 64, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&c.state_stage, sizeof(DevState), hipHostMallocDefault));
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipHostMalloc((void **)&c.snap[i], sizeof(DevState), hipHostMallocDefault));
         HIPCHK(hipEventCreateWithFlags(&c.snap_ev[i], hipEventDisableTiming));
@@ -206,7 +207,32 @@ clcg_para clcg_hip_default_parameters(void)
 
 int lcg_hip_last_iterations(void) { return ctx().last_iters; }
 double lcg_hip_last_residual(void) { return ctx().last_residual; }
-double lcg_hip_last_ax_mean_us(void) { return ctx().last_ax_mean_us; }
+double lcg_hip_last_ax_mean_us(void)
+{
+    Ctx &c = ctx();
+    if (c.prof_pending >= 2) {      // read the events of the last solve now, not inside its timed region
+        hipStreamSynchronize(c.stream);
+        double tot = 0.0;
+        for (int i = 0; i + 1 < c.prof_pending; i += 2) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, c.prof_ev[i], c.prof_ev[i + 1]);
+            tot += ms;
+        }
+        c.last_ax_mean_us = 1e3 * tot / (c.prof_pending / 2);
+        c.prof_pending = 0;
+    }
+    return c.last_ax_mean_us;
+}
+
+int lcg_hip_trim(void)
+{
+    Ctx &c = ctx();
+    if (!c.inited) return 0;
+    (void)hipDeviceSynchronize();
+    for (auto it = c.scratch.begin(); it != c.scratch.end();)
+        if (!it->busy) { (void)hipFree(it->p); it = c.scratch.erase(it); } else ++it;
+    return 0;
+}
 int lcg_hip_last_ax_calls(void) { return ctx().last_ax_calls; }
 
 int lcg_hip_set_cg_schedule(int schedule)
@@ -230,7 +256,7 @@ int lcg_hip_set_profiling(int on)
         // 35 us long -- the direction update before it -- against rocprofv3's kernel trace)
         for (auto &ev : c.prof_ev) HIPCHK(hipEventCreate(&ev));
     }
-    c.prof_used = 0;
+    c.prof_used = 0; c.prof_pending = 0;
     return 0;
 }
 

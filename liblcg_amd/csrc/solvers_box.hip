@@ -134,6 +134,7 @@ template <int SLOT> struct FinStore1 {   // park one reduced sum in DevState::s[
 
 static inline uintptr_t al(const void *p) { return (uintptr_t)p; }
 double global_rows(Ctx &c, int n);
+double global_rows_of(Ctx &c, int n, const void *afp, const void *inst);   // comm.hip
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
 static int solve_pg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const double *B, const double *low,
@@ -158,7 +159,7 @@ static int solve_pg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
         low = dlow; hig = dhig;
     }
     Driver drv(c, n, false, p.max_iterations, p.epsilon, p.abs_diff);
-    TRY(drv.init_state(global_rows(c, n)));
+    TRY(drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
     const uintptr_t a_all = al(m) | al(B) | al(g) | al(Ad) | al(mn) | al(low) | al(hig);
     lcg_para para = p;
@@ -205,7 +206,7 @@ static int solve_spg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const 
         low = dlow; hig = dhig;
     }
     Driver drv(c, n, false, p.max_iterations, p.epsilon, p.abs_diff);
-    TRY(drv.init_state(global_rows(c, n)));
+    TRY(drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
     const uintptr_t a_all = al(m) | al(B) | al(g) | al(Ad) | al(mn) | al(d) | al(low) | al(hig);
     lcg_para para = p;

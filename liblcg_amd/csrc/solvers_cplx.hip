@@ -466,6 +466,7 @@ static int ccheck_args(const clcg_para &p, int n, const double *m, const double 
 }
 
 double global_rows(Ctx &c, int n);
+double global_rows_of(Ctx &c, int n, const void *afp, const void *inst);   // comm.hip
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
@@ -514,7 +515,7 @@ static int solve_cbicg(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, doubl
     TRY(ws.get(r1, nullptr, nb)); TRY(ws.get(r2, nullptr, nb)); TRY(ws.get(d1, nullptr, nb));
     TRY(ws.get(d2, nullptr, nb)); TRY(ws.get(Ax, nullptr, nb));
     CplxCommon k(c, n, p, inst, Afp, Pfp, m);
-    TRY(k.drv.init_state(global_rows(c, n)));
+    TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
 
     TRY(k.ax(m, Ax));                                                   // clcg.cpp:99
@@ -546,7 +547,7 @@ static int solve_cpcg(clcg_hip_axfunc_ptr Afp, clcg_hip_axfunc_ptr Mfp, clcg_hip
     Workspace ws; double *r, *d, *s, *Ax;
     TRY(ws.get(r, nullptr, nb)); TRY(ws.get(d, nullptr, nb)); TRY(ws.get(s, nullptr, nb)); TRY(ws.get(Ax, nullptr, nb));
     CplxCommon k(c, n, p, inst, Afp, Pfp, m);
-    TRY(k.drv.init_state(global_rows(c, n)));
+    TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
     const double *inv = nullptr;        // built-in Jacobi on a complex handle: fold M^-1 into the update
     if (Mfp == clcg_hip_jacobi_mx && inst) {
@@ -588,7 +589,7 @@ static int solve_bicg_sym(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, do
     Workspace ws; double *r, *d, *Ax;
     TRY(ws.get(r, nullptr, nb)); TRY(ws.get(d, nullptr, nb)); TRY(ws.get(Ax, nullptr, nb));
     CplxCommon k(c, n, p, inst, Afp, Pfp, m);
-    TRY(k.drv.init_state(global_rows(c, n)));
+    TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
 
     TRY(k.ax(m, Ax));                                                   // clcg.cpp:250
@@ -618,7 +619,7 @@ static int solve_ccgs(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, double
     TRY(ws.get(r, nullptr, nb)); TRY(ws.get(rb, nullptr, nb)); TRY(ws.get(pk, nullptr, nb)); TRY(ws.get(Ax, nullptr, nb));
     TRY(ws.get(u, nullptr, nb)); TRY(ws.get(q, nullptr, nb)); TRY(ws.get(w, nullptr, nb));
     CplxCommon k(c, n, p, inst, Afp, Pfp, m);
-    TRY(k.drv.init_state(global_rows(c, n)));
+    TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
     TRY(make_shadow(c, n, rb));                                         // clcg.cpp:399-404
 
@@ -651,7 +652,7 @@ static int solve_cbicgstab(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, d
     TRY(ws.get(r, nullptr, nb)); TRY(ws.get(rb, nullptr, nb)); TRY(ws.get(pk, nullptr, nb));
     TRY(ws.get(s, nullptr, nb)); TRY(ws.get(Ap, nullptr, nb)); TRY(ws.get(As, nullptr, nb));
     CplxCommon k(c, n, p, inst, Afp, Pfp, m);
-    TRY(k.drv.init_state(global_rows(c, n)));
+    TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
     TRY(make_shadow(c, n, rb));                                         // clcg.cpp:556-561
 
@@ -686,7 +687,7 @@ static int solve_tfqmr(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, doubl
     TRY(ws.get(rb, nullptr, nb)); TRY(ws.get(r, nullptr, nb)); TRY(ws.get(Ax, nullptr, nb)); TRY(ws.get(q, nullptr, nb));
     TRY(ws.get(uq, nullptr, nb));
     CplxCommon k(c, n, p, inst, Afp, Pfp, m);
-    TRY(k.drv.init_state(global_rows(c, n)));
+    TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
     TRY(make_shadow(c, n, rb));                                         // clcg.cpp:721-725
 

@@ -379,7 +379,8 @@ static int check_args(const lcg_para &p, int n, const double *m, const double *B
     return 0;
 }
 
-double global_rows(Ctx &c, int n);   // comm.hip: n summed over ranks (n itself when single)
+double global_rows(Ctx &c, int n);
+double global_rows_of(Ctx &c, int n, const void *afp, const void *inst);   // comm.hip   // comm.hip: n summed over ranks (n itself when single)
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
@@ -394,7 +395,7 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
     Workspace ws; double *g, *d, *Ad;
     TRY(ws.get(g, Gk, sizeof(double) * n)); TRY(ws.get(d, Dk, sizeof(double) * n)); TRY(ws.get(Ad, ADk, sizeof(double) * n));
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
-    TRY(k.drv.init_state(global_rows(c, n)));
+    TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
 
     TRY(k.ax(m, Ad));                                                            // lcg.cpp:168
@@ -461,7 +462,7 @@ static int solve_pcg(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pf
     TRY(ws.get(r, nullptr, sizeof(double) * n)); TRY(ws.get(z, nullptr, sizeof(double) * n));
     TRY(ws.get(d, nullptr, sizeof(double) * n)); TRY(ws.get(Ad, nullptr, sizeof(double) * n));
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
-    TRY(k.drv.init_state(global_rows(c, n)));
+    TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
     // built-in Jacobi on a handle that owns its reciprocal diagonal: fold M^-1 into the update
     const double *invdiag = nullptr;
@@ -507,7 +508,7 @@ static int solve_cgs(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const 
     TRY(ws.get(r, RK, nb)); TRY(ws.get(r0, R0T, nb)); TRY(ws.get(pk, PK, nb)); TRY(ws.get(Ax, AX, nb));
     TRY(ws.get(u, UK, nb)); TRY(ws.get(q, QK, nb)); TRY(ws.get(w, WK, nb));
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
-    TRY(k.drv.init_state(global_rows(c, n)));
+    TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
     const uintptr_t a_all = al(m) | al(B) | al(r) | al(r0) | al(pk) | al(Ax) | al(u) | al(q) | al(w);
 
@@ -540,7 +541,7 @@ static int solve_bicgstab(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, c
     TRY(ws.get(r, nullptr, nb)); TRY(ws.get(r0, nullptr, nb)); TRY(ws.get(pk, nullptr, nb));
     TRY(ws.get(Ax, nullptr, nb)); TRY(ws.get(s, nullptr, nb)); TRY(ws.get(Ap, nullptr, nb));
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
-    TRY(k.drv.init_state(global_rows(c, n)));
+    TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
     const uintptr_t a_all = al(m) | al(B) | al(r) | al(r0) | al(pk) | al(Ax) | al(s) | al(Ap);
 
@@ -681,7 +682,7 @@ static int solve_bicgstab2(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, 
     TRY(ws.get(r, nullptr, nb)); TRY(ws.get(r0, nullptr, nb)); TRY(ws.get(pk, nullptr, nb));
     TRY(ws.get(Ax, nullptr, nb)); TRY(ws.get(s, nullptr, nb)); TRY(ws.get(Ap, nullptr, nb));
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
-    TRY(k.drv.init_state(global_rows(c, n)));
+    TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
     const uintptr_t a_all = al(m) | al(B) | al(r) | al(r0) | al(pk) | al(Ax) | al(s) | al(Ap);
     const int halves = p.abs_diff ? 1 : 0;
