@@ -275,3 +275,26 @@ def test_complex_bicgstab_and_cap(api, port, goldens, case1kc):
         assert info.ret == ref["ret"] == -1019 and info.iterations == ref["iters"] == 12
         assert np.linalg.norm(x - ref["x"]) <= tol * np.linalg.norm(ref["x"])
         assert abs(info.residual - ref["residual"]) <= 100 * tol * abs(ref["residual"])
+
+
+def test_temporaries_are_kept_between_solves_and_can_be_given_back(api, case10k, A10k):
+    """The reference allocates and frees its temporaries per call (lcg.cpp:158-166,266-271); here they stay for the next solve
+    (no hipMalloc / hipFree inside the timed region of a repeated solve) until lcg_hip_trim(): same answers either way, and the
+    device memory comes back."""
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    n, rp, ci, v, b, xs = case10k
+    p = api.lcg_default_parameters(epsilon=1e-12, abs_diff=1)
+    assert lib.lcg_hip_trim() == 0
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    i1, x1 = _solve_real(api, A10k, api.LCG_CGS, b, n, p)            # seven work vectors
+    i2, x2 = _solve_real(api, A10k, api.LCG_CGS, b, n, p)            # ... reused
+    i3, x3 = _solve_real(api, A10k, api.LCG_CG, b, n, p)             # a smaller set from the same pool
+    assert i1.ret == i2.ret == i3.ret == 0 and np.array_equal(x1, x2) and i1.iterations == i2.iterations
+    assert np.linalg.norm(x3 - xs) <= 1e-7
+    assert lib.lcg_hip_trim() == 0
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 21)        # nothing of the solves' scratch is still held
+    i4, x4 = _solve_real(api, A10k, api.LCG_CGS, b, n, p)
+    assert np.array_equal(x1, x4)
