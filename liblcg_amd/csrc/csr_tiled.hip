@@ -296,7 +296,8 @@ void tiled_free(CsrPart &P)
 struct TiledShape { int rw, nw, un; };
 static TiledShape tiled_shape()
 {   // LCG_HIP_TILED_SHAPE (A/B runs): 0 = 4 x 1024 rows (default: 0.82-0.85 ms on the 10M-row row-random band), 1 = 8 x 512 rows
-    // (0.92-0.94), 2 = 8 x 1024 rows, one workgroup per CU (0.93-0.95).  Also measured and removed: a pipeline across tiles with the
+    // (0.92-0.94), 2 = 8 x 1024 rows, one workgroup per CU (0.93-0.95).  Also measured and removed: 4 x 640 and 4 x 512 rows (three
+    // workgroups per CU: 0.95-1.01), 4 x 1280 and 4 x 1536 rows (fewer tile copies per row: 0.90 / 0.94); a pipeline across tiles with the
     // next tile's requests in flight during this tile's adds (1.05 ms), and double-buffered tiles with requests two tiles ahead in a
     // one-workgroup-per-CU shape (1.18 ms) -- two independent workgroups per CU overlap their phases better than either.
     static const int v = [] { const char *e = std::getenv("LCG_HIP_TILED_SHAPE"); return e ? atoi(e) : 0; }();
