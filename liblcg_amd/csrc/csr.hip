@@ -585,6 +585,12 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
             return tiled_launch(P, reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), s, done);
         }
     }
+    if constexpr (sizeof(V) == 8 && !ACC && PUSH) {     // sharded rows, direct exchange: the tiled product carries the pushing blocks too
+        if (n > 0 && (variant == 0 || variant == -1) && tiled_chosen(P, s)) {
+            P.last_kernel = "k_tile_spmv (one-pass tiled product: x tiles and row sums in LDS) + pushing blocks";
+            return tiled_launch(P, reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), s, done, &pp);
+        }
+    }
     if (n == 0) {
         if (PUSH && xb > 0) {       // nothing to multiply, but the neighbours still wait for x and the flags
             hipLaunchKernelGGL((k_spmv_wave<V, 1, ACC, PUSH>), dim3(xb), dim3(VB), 0, s, 0, P.rowptr, P.col,

@@ -49,13 +49,18 @@ struct TiledPlan {
 };
 
 // ---------------------------------------------------------------------------------------------- the product
-template <int TL_RW, int TL_NW, int UN>
+// PUSH (sharded rows, direct exchange): the first pp.nblocks blocks of the grid carry this rank's boundary entries of x to the
+// neighbours (devcommon.hpp: push_block) while the rest multiply -- as in the row-block kernels of csr.hip.
+template <int TL_RW, int TL_NW, int UN, bool PUSH = false>
 __global__ __launch_bounds__(TL_NW * 64) void k_tile_spmv(int n, int nwg, const int *__restrict__ tmin, const int *__restrict__ nspan,
                                                           const int *__restrict__ sofs, const int *__restrict__ gstart,
                                                           const int *__restrict__ binofs, const double *__restrict__ val2,
                                                           const unsigned *__restrict__ idx2, const double *__restrict__ x,
-                                                          long n_cols, double *__restrict__ y, const int *done)
+                                                          long n_cols, double *__restrict__ y, const int *done, PushPlan pp)
 {
+    static_assert(!PUSH || TL_NW * 64 == VB, "push_block moves PUSH_CHUNK entries with VB threads");
+    if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
+    const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
     __shared__ __attribute__((aligned(16))) double sx[TL_C];
     __shared__ __attribute__((aligned(16))) double ys[TL_NW][TL_RW];
     if (done && *done) return;
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(TL_NW * 64) void k_tile_spmv(int n, int nwg, const 
     // but a few of their tiles, so each XCD is given a CONTIGUOUS eighth of the row blocks: its L2 then fetches an eighth
     // of x (plus the band) instead of all of it.  Speed only: any placement gives the same result.
     const int per_xcd = (nwg + 7) >> 3;
-    const int g = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int g = (bid & 7) * per_xcd + (bid >> 3);
     if (g >= nwg) return;
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -407,13 +412,20 @@ int tiled_ready(const CsrPart &P, hipStream_t s, double min_fill)
     return 1;
 }
 
-int tiled_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done)
+int tiled_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done, const PushPlan *push)
 {
     const TiledPlan *T = static_cast<const TiledPlan *>(P.tl_plan);
     if (!T) return fail(hipErrorInvalidValue, "tiled A.x without a plan", __FILE__, __LINE__);
+    if (push) {
+        if (T->rw != 1024 || T->nw != 4) return fail(hipErrorInvalidValue, "pushing blocks need the 4 x 1024 shape", __FILE__, __LINE__);
+        hipLaunchKernelGGL((k_tile_spmv<1024, 4, 6, true>), dim3(8 * ((T->nwg + 7) / 8) + push->nblocks), dim3(VB), 0, s, T->n_rows, T->nwg, T->tmin,
+                           T->nspan, T->sofs, T->gstart, T->binofs, T->val2, T->idx2, x, T->n_cols, y, done, *push);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
 #define TL_LAUNCH(RW, NW, UN)                                                                                                  \
     hipLaunchKernelGGL((k_tile_spmv<RW, NW, UN>), dim3(8 * ((T->nwg + 7) / 8)), dim3(NW * 64), 0, s, T->n_rows, T->nwg, T->tmin, T->nspan, T->sofs, T->gstart, \
-                       T->binofs, T->val2, T->idx2, x, T->n_cols, y, done)
+                       T->binofs, T->val2, T->idx2, x, T->n_cols, y, done, PushPlan())
     if (T->rw == 512 && T->nw == 8) TL_LAUNCH(512, 8, 3);
     else if (T->rw == 1024 && T->nw == 8) TL_LAUNCH(1024, 8, 6);
     else TL_LAUNCH(1024, 4, 6);

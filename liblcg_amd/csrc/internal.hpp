@@ -211,7 +211,7 @@ long binned_traffic_bytes(const CsrPart &P);
 size_t binned_plan_bytes(const CsrPart &P);
 // csr_tiled.hip
 int tiled_ready(const CsrPart &P, hipStream_t s, double min_fill);      // 1 plan ready, 0 not eligible, < 0 failure
-int tiled_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done_flag);
+int tiled_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done_flag, const PushPlan *push = nullptr);
 void tiled_free(CsrPart &P);
 long tiled_traffic_bytes(const CsrPart &P);
 long tiled_tile_copy_bytes(const CsrPart &P);

@@ -39,14 +39,16 @@ def main(ref_path, out_path):
         if verbose:
             print(f"[rank {rank}]", *a, file=sys.stderr, flush=True)
 
-    for tag in ("band", "scr", "nsym"):
+    for tag in ("band", "scr", "nsym", "rrb"):
         if f"{tag}/n" not in ref.files:
             continue
         n = int(ref[f"{tag}/n"]); band = int(ref[f"{tag}/band"]); sym = bool(ref[f"{tag}/sym"])
         r0, r1 = partition.shard_range(n, world, rank)
-        A = api.CsrMatrix.generate(n, 16, band, sym, 3, 0.01, r0, r1)
+        A = api.CsrMatrix.generate(n, 16, band, sym, 3, 0.01, r0, r1, pattern=api.GEN_ROW_RANDOM_BAND if tag == "rrb" else None)
         A.distribute(n, 2)
-        if tag != "scr":        # also drive the packed-column product with pushing blocks (auto only from 4M entries up)
+        if tag == "rrb":        # rows that draw their own columns: the tiled product with pushing blocks (auto only from 4M entries up)
+            assert lib.lcg_hip_csr_set_tiled(A.h, 1) == 0
+        elif tag != "scr":      # also drive the packed-column product with pushing blocks (auto only from 4M entries up)
             assert lib.lcg_hip_csr_set_packed(A.h, 1) == 0
         res[f"{tag}/recv"] = int(lib.lcg_hip_csr_exchange_volume(A.h))
         x1 = torch.from_numpy(ref[f"{tag}/x1"][r0:r1]).cuda()
@@ -65,6 +67,7 @@ def main(ref_path, out_path):
             w = want[r0:r1]
             errs.append(float(np.abs(y.cpu().numpy() - w).max() / np.abs(w).max()))
         res[f"{tag}/spmv_err"] = max(errs)
+        res[f"{tag}/kernel"] = lib.lcg_hip_csr_last_kernel(A.h).decode()
         say(tag, "products: max err", max(errs), "per call", ["%.1e" % e for e in errs], "p2p status", lib.lcg_hip_p2p_status())
         b = torch.from_numpy(ref[f"{tag}/b"][r0:r1]).cuda()
         para = api.lcg_default_parameters(epsilon=1e-10, abs_diff=1)

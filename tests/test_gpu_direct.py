@@ -21,14 +21,16 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-CASES = (("band", 60000, 700, True), ("scr", 30011, 0, True), ("nsym", 45000, 1200, False))
+CASES = (("band", 60000, 700, True), ("scr", 30011, 0, True), ("nsym", 45000, 1200, False), ("rrb", 52000, 900, True))
 
 
 def _reference(path, cases=CASES):
     from liblcg_amd import api
     out = {}
     for tag, n, band, sym in cases:
-        A = api.CsrMatrix.generate(n, 16, band, sym, 3, 0.01)
+        A = api.CsrMatrix.generate(n, 16, band, sym, 3, 0.01, pattern=api.GEN_ROW_RANDOM_BAND if tag == "rrb" else None)
+        if tag == "rrb":
+            assert api.L.load().lcg_hip_csr_set_tiled(A.h, 0) == 0      # reference product: the row-block kernel
         x1 = torch.empty(n, dtype=torch.float64, device="cuda")
         api.gen_xtrue(n, 1, 0, n, x1)
         x2 = 2.0 * x1 + 1.0
@@ -96,7 +98,8 @@ def test_three_ranks_on_one_gpu_direct_exchange(tmp_path, streams):
     for r in res:
         # banded: only the neighbours' band-wide ranges travel; scrambled: everything does
         assert 0 < r["band/recv"] <= 2 * 700 and r["scr/recv"] > 15000, r
-        for tag in ("band", "scr", "nsym"):
+        assert "k_tile_spmv" in r["rrb/kernel"] and "pushing blocks" in r["rrb/kernel"], r["rrb/kernel"]
+        for tag in ("band", "scr", "nsym", "rrb"):
             assert r[f"{tag}/spmv_err"] < 1e-13, (tag, r)
             for name in ("cg", "pcg", "bicgstab", "cgs"):
                 key = f"{tag}/{name}"
