@@ -247,6 +247,11 @@ int lcg_hip_spmv(lcg_hip_csr_t A, const double *x, double *y);                  
  * MatTranspose / Conjugate products the reference's callbacks are asked for (clcg.h:40-41,
  * clcg.cpp:187; cusparseSpMV with CUSPARSE_OPERATION_*TRANSPOSE in sample9.cu:97). */
 int lcg_hip_spmv_op(lcg_hip_csr_t A, const double *x, double *y, int layout, int conjugate);
+/* y = A.x together with the sums the Krylov loops take right after it (lcg.cpp:234 d.Ad, :548-552 Ap.r0, :735-740 As.s and
+ * As.As): result2[0] = y.u, result2[1] = y.y (host, after a stream synchronise; NULL = enqueue only).  Where the kernel family
+ * allows, the sums ride in the product's epilogue (what the built-in solvers use on one GPU: lcg_hip_csr_last_kernel says
+ * "carrying the dot"); otherwise product and reduction run as two launches.  Real matrices. */
+int lcg_hip_spmv_dot(lcg_hip_csr_t A, const double *x, double *y, const double *u, double *result2);
 int lcg_hip_dot(int n, const double *a, const double *b, double *result);      /* lcg_dot, algebra.cpp:154-163; cublasDdot lcg_cuda.cu:187 */
 int lcg_hip_nrm2(int n, const double *a, double *result);                      /* cublasDznrm2-style 2-norm */
 int lcg_hip_axpy(int n, double alpha, const double *x, double *y);             /* y += alpha*x, cublasDaxpy lcg_cuda.cu:190 */

@@ -82,6 +82,7 @@ SIGNATURES = {
     "clcg_hip_csr_ax": (None, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "lcg_hip_spmv": (C.c_int, [vp, vp, vp]),
     "lcg_hip_spmv_op": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+    "lcg_hip_spmv_dot": (C.c_int, [vp, vp, vp, vp, c_double_p]),
     "lcg_hip_dot": (C.c_int, [C.c_int, vp, vp, c_double_p]),
     "lcg_hip_nrm2": (C.c_int, [C.c_int, vp, c_double_p]),
     "lcg_hip_axpy": (C.c_int, [C.c_int, C.c_double, vp, vp]),

@@ -80,24 +80,20 @@ __global__ void k_max_slice(int n, int R, const int *rowptr, int *out)
 // ---- one-window kernel: the host has verified (k_max_slice) that every block's slice fits one
 // LDS window.  ALL of the block's HBM loads are issued before the first LDS store, 16 B per
 // lane per access (~25 KB in flight per block); then every lane keeps UNR gathers of x in flight.
-template <class V, int R, bool ACC, bool PUSH = false>
-__global__ __launch_bounds__(VB) void k_spmv_lds1(int n, long nnz, const int *__restrict__ rowptr,
-                                                  const int *__restrict__ col, const V *__restrict__ val,
-                                                  const V *__restrict__ x, V *__restrict__ y,
-                                                  const int *done, PushPlan pp)
+// The work of one row block, shared by the plain kernel and the one that carries a dot (below).  Returns the finished y
+// of row row0 + tid % R on the lanes that wrote it (`mine`).
+template <class V, int R, bool ACC>
+__device__ __forceinline__ V lds1_block(int bid, int n, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                        const V *__restrict__ val, const V *__restrict__ x, V *__restrict__ y, V *sval, int *scol,
+                                        bool &mine)
 {
-    if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
-    const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
     constexpr int T = VB / R;
     constexpr int CH = LdsCfg<V>::CH;                       // entries per LDS window (multiple of 4)
     constexpr int NRND = (CH + VB * 4 - 1) / (VB * 4);      // 4-entry units per lane
     constexpr int VU = sizeof(V) / 4;                       // 16-byte pieces of val per 4 entries
     constexpr int UNR = 4;                                  // x gathers in flight per lane
     static_assert(T * R <= CH, "row-sum exchange must fit the staging buffer");
-    __shared__ __attribute__((aligned(16))) V sval[CH];
-    __shared__ __attribute__((aligned(16))) int scol[CH];
     V(*sred)[R] = reinterpret_cast<V(*)[R]>(sval);
-    if (done && *done) return;
 
     const int tid = threadIdx.x;
     const int row0 = bid * R;
@@ -148,17 +144,75 @@ __global__ __launch_bounds__(VB) void k_spmv_lds1(int n, long nnz, const int *__
     for (; k < re; k += T) acc = mac(sval[k - base], x[scol[k - base]], acc);
     __syncthreads();
     // the T partial sums of a row meet in LDS (staging buffer reused); y written coalesced
+    mine = j0 == 0 && rl < nrows;
     if (T > 1) {
         sred[j0][rl] = acc;
         __syncthreads();
-        if (j0 == 0 && rl < nrows) {
+        if (mine) {
             V v = sred[0][rl];
 #pragma unroll
             for (int j = 1; j < T; j++) v = vadd(v, sred[j][rl]);
-            y[row0 + rl] = ACC ? vadd(y[row0 + rl], v) : v;
+            acc = ACC ? vadd(y[row0 + rl], v) : v;
+            y[row0 + rl] = acc;
         }
-    } else if (rl < nrows) {
-        y[row0 + rl] = ACC ? vadd(y[row0 + rl], acc) : acc;
+    } else if (mine) {
+        if (ACC) acc = vadd(y[row0 + rl], acc);
+        y[row0 + rl] = acc;
+    }
+    return acc;
+}
+
+template <class V, int R, bool ACC, bool PUSH = false>
+__global__ __launch_bounds__(VB) void k_spmv_lds1(int n, long nnz, const int *__restrict__ rowptr,
+                                                  const int *__restrict__ col, const V *__restrict__ val,
+                                                  const V *__restrict__ x, V *__restrict__ y,
+                                                  const int *done, PushPlan pp)
+{
+    if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
+    const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
+    constexpr int CH = LdsCfg<V>::CH;
+    __shared__ __attribute__((aligned(16))) V sval[CH];
+    __shared__ __attribute__((aligned(16))) int scol[CH];
+    if (done && *done) return;
+    bool mine;
+    (void)lds1_block<V, R, ACC>(bid, n, rowptr, col, val, x, y, sval, scol, mine);
+}
+
+// ---- the same product carrying a dot: the Krylov loops follow every A.x with y.u (CG / PCG: d.Ad, CGS / BiCGStab: Ap.r0,
+// As.s and As.As; lcg.cpp:234, 389, 548-552, 720-724, 735-740) -- a pass of its own over two vectors and, on small systems, a
+// launch of its own on the critical path.  Here the lanes that write y multiply it with u on the way out (u is requested
+// before the block's stream, so the load hides behind it) and the workgroup leaves ONE partial sum per running sum in its
+// slot of Ctx::ax_partials, which the consuming scalar step adds up in index order (devcommon.hpp: reduce_partials,
+// PartCount) -- no atomics, the same bits from call to call.  y itself is bit-identical to the plain kernel's.
+template <int R>
+__global__ __launch_bounds__(VB) void k_spmv_lds1d(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                   const double *__restrict__ val, const double *__restrict__ x,
+                                                   double *__restrict__ y, const int *done, DotPlan dp)
+{
+    constexpr int CH = LdsCfg<double>::CH;
+    __shared__ __attribute__((aligned(16))) double sval[CH];
+    __shared__ __attribute__((aligned(16))) int scol[CH];
+    __shared__ double wsum[2][VB / 64];
+    if (done && *done) return;
+    const int rl = threadIdx.x % R, j0 = threadIdx.x / R;
+    const long row = (long)blockIdx.x * R + rl;
+    const double uv = (dp.dbg & 1) ? 1.0 : dp.u[(j0 == 0 && row < n) ? row : 0];
+    bool mine;
+    const double v = lds1_block<double, R, false>(blockIdx.x, n, rowptr, col, val, x, y, sval, scol, mine);
+    double a0 = mine ? v * uv : 0.0, a1 = mine ? v * v : 0.0;
+    if (dp.dbg & 2) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int NW = R >= 64 ? R / 64 : 1;        // wavefronts that hold finished rows
+    if (w < NW) {
+        a0 = wave_sum(a0); a1 = wave_sum(a1);
+        if (lane == WSUM_LANE) { wsum[0][w] = a0; wsum[1][w] = a1; }
+    }
+    if (NW > 1) __syncthreads();
+    if (threadIdx.x < 2 && (threadIdx.x == 0 || dp.yy)) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; q++) t += wsum[threadIdx.x][q];
+        dp.part[threadIdx.x * AXP_CAP + blockIdx.x] = t;
     }
 }
 
@@ -569,6 +623,33 @@ static bool tiled_chosen(const CsrPart &P, hipStream_t s)
     return true;
 }
 
+// rows per block of the LDS-staged kernels so that R*mean_row entries fit one LDS window, and whether EVERY block's slice
+// does (blocks whose slice exceeds the window take the window-by-window kernel); scanned once per (matrix, R)
+template <class V>
+static int lds_shape(const CsrPart &P, int variant, double mean_row, hipStream_t s, int *R_out, bool *onewin)
+{
+    const int n = P.n_rows;
+    const double cap = LdsCfg<V>::CH - 64;
+    const int R = variant < -1 ? -variant
+                               : (256 * mean_row <= cap ? 256 : 128 * mean_row <= cap ? 128 : 64 * mean_row <= cap ? 64
+                                  : 32 * mean_row <= cap ? 32 : 16);
+    if (P.slice_R != R) {
+        int *d = nullptr, h = 0;
+        HIPCHK(hipMalloc(&d, sizeof(int)));
+        HIPCHK(hipMemsetAsync(d, 0, sizeof(int), s));
+        const int nb = (n + R - 1) / R;
+        hipLaunchKernelGGL(k_max_slice, dim3((nb + VB - 1) / VB), dim3(VB), 0, s, n, R, P.rowptr, d);
+        hipError_t e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        hipFree(d);
+        if (e != hipSuccess) return fail(e, "slice scan", __FILE__, __LINE__);
+        P.slice_R = R; P.max_slice = h;
+    }
+    *R_out = R;
+    *onewin = P.padded && P.max_slice <= LdsCfg<V>::CH;
+    return 0;
+}
+
 template <class V, bool ACC, bool PUSH = false>
 static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V *x, V *y, hipStream_t s,
                          const int *done, const PushPlan &pp = PushPlan())
@@ -607,25 +688,8 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
     }
     if (variant < 0) {
         if (!al16) return fail(hipErrorInvalidValue, "LDS-staged A.x needs 16-byte aligned col/val", __FILE__, __LINE__);
-        // rows per block so that R*mean_row entries fit one LDS window
-        // (blocks whose slice exceeds the window take the kernel's window-by-window path)
-        const double cap = LdsCfg<V>::CH - 64;
-        int R = variant < -1 ? -variant
-                             : (256 * mean_row <= cap ? 256 : 128 * mean_row <= cap ? 128 : 64 * mean_row <= cap ? 64
-                                : 32 * mean_row <= cap ? 32 : 16);
-        if (P.slice_R != R) {       // once per (matrix, R): does every block fit one window?
-            int *d = nullptr, h = 0;
-            HIPCHK(hipMalloc(&d, sizeof(int)));
-            HIPCHK(hipMemsetAsync(d, 0, sizeof(int), s));
-            const int nb = (n + R - 1) / R;
-            hipLaunchKernelGGL(k_max_slice, dim3((nb + VB - 1) / VB), dim3(VB), 0, s, n, R, P.rowptr, d);
-            hipError_t e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
-            hipFree(d);
-            if (e != hipSuccess) return fail(e, "slice scan", __FILE__, __LINE__);
-            P.slice_R = R; P.max_slice = h;
-        }
-        const bool onewin = P.padded && P.max_slice <= LdsCfg<V>::CH;
+        int R = 0; bool onewin = false;
+        { int rc = lds_shape<V>(P, variant, mean_row, s, &R, &onewin); if (rc) return rc; }
         if constexpr (sizeof(V) == 8 && !ACC) {
             if (R == PK_R && onewin && packed_ready(P, s)) {
                 // gathers per lane in the first batch: enough for the longest row when that is 9..12 per lane
@@ -700,6 +764,45 @@ int spmv_launch_push(const CsrPart &P, bool is_complex, int variant, double mean
         return spmv_dispatch<double2, false, true>(P, variant, mean_row, reinterpret_cast<const double2 *>(x),
                                                    reinterpret_cast<double2 *>(y), s, done, pp);
     return spmv_dispatch<double, false, true>(P, variant, mean_row, x, y, s, done, pp);
+}
+
+// A.x with the dot(s) that follow it in the Krylov loops carried in the product (k_spmv_lds1d): one GPU, real, the LDS-staged
+// one-window family.  Everything else answers 0 and the caller multiplies and reduces in two launches as before.
+int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots, hipStream_t s,
+               const int *done)
+{
+    static const bool off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT"); return e && atoi(e) == 0; }();
+    if (off || !A || A->is_complex || A->distributed || A->n_rows <= 0) return 0;
+    const CsrPart &P = A->main;
+    const int n = P.n_rows;
+    if (A->variant != 0 && A->variant != -1) return 0;
+    if (A->mean_row > 160.0 || ((((uintptr_t)P.val | (uintptr_t)P.col) & 15) != 0)) return 0;
+    if (binned_chosen(P, s) || tiled_chosen(P, s)) return 0;
+    int R = 0; bool onewin = false;
+    { int rc = lds_shape<double>(P, -1, A->mean_row, s, &R, &onewin); if (rc) return rc; }
+    if (!onewin) return 0;
+    if (R == PK_R && packed_ready(P, s)) return 0;
+    const int nblk = (n + R - 1) / R;
+    // Where it pays (measured, scripts/ax_dot_lab.py + scripts/ab_small.py): systems whose iteration is a chain of kernel
+    // latencies -- the product grows by ~0.6 us, a ~3 us pass and its launch go.  At 1M rows (3907 row blocks) the product grew by
+    // 3.2 us and every block of the consuming pass re-added 3907 partials: 39.2 vs 38.5 us per PCG iteration, so from
+    // LCG_HIP_AX_DOT_MAXBLK (default 2048) row blocks on the separate pass stays.
+    static const int maxblk = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_MAXBLK"); const int v = e ? atoi(e) : 2048; return v < 1 ? 1 : (v > AXP_CAP ? AXP_CAP : v); }();
+    if (nblk > maxblk) return 0;
+    DotPlan dp; dp.u = u; dp.part = part; dp.yy = yy;
+    static const int dbg = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_DBG"); return e ? atoi(e) : 0; }();
+    dp.dbg = dbg;
+    const int g = nblk;
+#define LDSD_CASE(RR) case RR: hipLaunchKernelGGL((k_spmv_lds1d<RR>), dim3(g), dim3(VB), 0, s, n, P.rowptr, P.col, P.val, x, y, done, dp); break;
+    switch (R) {
+        LDSD_CASE(256) LDSD_CASE(128) LDSD_CASE(64) LDSD_CASE(32) LDSD_CASE(16)
+    default: return 0;
+    }
+#undef LDSD_CASE
+    HIPCHK(hipGetLastError());
+    P.last_kernel = "k_spmv_lds1d (LDS-staged CSR carrying the dot that follows the product)";
+    *slots = g;
+    return 1;
 }
 
 // ------------------------------------------------------------------------- Jacobi / diagonal

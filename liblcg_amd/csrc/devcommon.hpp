@@ -18,10 +18,26 @@
 
 namespace lcgh {
 
+// Sum over the 64 lanes of a wavefront with DPP moves (row shifts inside the rows of 16, then the two row broadcasts): six
+// steps of two v_mov_dpp + one v_add_f64.  __shfl_down goes through the LDS crossbar (ds_bpermute, two per double and step):
+// ~1 us per reducing kernel with four running sums -- a fifth of a kernel on the launch-bound systems.  The total is valid in
+// the LAST lane (WSUM_LANE); lanes a step has no source for add +0.0.  Fixed order: the same bits every time.
+constexpr int WSUM_LANE = 63;
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_get(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    v += dpp_get<0x111, 0xf>(v);    // row_shr:1
+    v += dpp_get<0x112, 0xf>(v);    // row_shr:2
+    v += dpp_get<0x114, 0xf>(v);    // row_shr:4
+    v += dpp_get<0x118, 0xf>(v);    // row_shr:8: lane 15 of every row holds the row's sum
+    v += dpp_get<0x142, 0xa>(v);    // row_bcast:15 into rows 1 and 3
+    v += dpp_get<0x143, 0xc>(v);    // row_bcast:31 into rows 2 and 3: lane 63 holds the total
     return v;
 }
 
@@ -35,7 +51,7 @@ __device__ __forceinline__ void block_reduce_store(double *acc, double *partials
 #pragma unroll
     for (int r = 0; r < NR; r++) {
         double v = wave_sum(acc[r]);
-        if (lane == 0) sh[r][w] = v;
+        if (lane == WSUM_LANE) sh[r][w] = v;
     }
     __syncthreads();
     if (threadIdx.x < NR) {
@@ -310,7 +326,7 @@ __device__ __forceinline__ void stop_rule(DevState *st, double g2, double m2)
 // block taking part.  All NRA * MAXG/VB loads of a lane are issued before the first add (a dependent load-add chain made
 // the one-block kernel take 16 us); fixed order => the same bits wherever and however often this runs.
 template <int NRA>
-__device__ __forceinline__ void reduce_partials(const double *partials, int G, double *sums)
+__device__ __forceinline__ void reduce_partials(const double *partials, const PartCount &pc, double *sums)
 {
     constexpr int PER = MAXG / VB;
     double acc[NRA], v[NRA][PER];
@@ -319,6 +335,7 @@ __device__ __forceinline__ void reduce_partials(const double *partials, int G, d
 #pragma unroll
         for (int q = 0; q < PER; q++) {
             const int j = threadIdx.x + q * VB;
+            const int G = pc.g[r];
             const double x = partials[r * MAXG + (j < G ? j : 0)];     // branch-free: select after the load
             v[r][q] = j < G ? x : 0.0;
         }
@@ -329,12 +346,30 @@ __device__ __forceinline__ void reduce_partials(const double *partials, int G, d
         for (int q = 0; q < PER; q++) t += v[r][q];
         acc[r] = t;
     }
+    if (pc.ax_row >= 0) {       // sums carried by an A.x kernel: one partial per workgroup of that kernel, batches of 8 loads in flight
+        double t0 = 0.0, t1 = 0.0;
+        for (int j0 = 0; j0 < pc.ax_n; j0 += 8 * VB) {
+            double a[8], b[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int j = j0 + threadIdx.x + q * VB;
+                const int jj = j < pc.ax_n ? j : 0;
+                a[q] = pc.axp[jj];
+                b[q] = pc.ax_yy ? pc.axp[AXP_CAP + jj] : 0.0;
+                if (j >= pc.ax_n) { a[q] = 0.0; b[q] = 0.0; }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) { t0 += a[q]; t1 += b[q]; }
+        }
+#pragma unroll
+        for (int r = 0; r < NRA; r++) acc[r] += r == pc.ax_row ? t0 : (r == pc.ax_row + 1 && pc.ax_yy ? t1 : 0.0);
+    }
     __shared__ double sh[NRA][VB / 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int r = 0; r < NRA; r++) {
         double t = wave_sum(acc[r]);
-        if (lane == 0) sh[r][w] = t;
+        if (lane == WSUM_LANE) sh[r][w] = t;
     }
     __syncthreads();
     if (threadIdx.x < NRA) {
@@ -347,7 +382,7 @@ __device__ __forceinline__ void reduce_partials(const double *partials, int G, d
 }
 
 template <class Fin>
-__global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, int G, DevState *st, int mode, XgBox xb)
+__global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, PartCount G, DevState *st, int mode, XgBox xb)
 {
     constexpr int NRA = Fin::NR > 0 ? Fin::NR : 1;
     __shared__ double sums[NRA];
@@ -376,7 +411,7 @@ __global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, in
 // to the OTHER buffer of a pair (`next`): no block ever reads a field another block is rewriting, and the kernels enqueued
 // afterwards are handed `next` as their state.  Partial sums ping-pong between two tables for the same reason.
 template <class Fin, class Op, bool VEC2>
-__global__ __launch_bounds__(VB) void k_vecf(Fin fin, Op op, long n, const double *pin, int G, double *pout, const DevState *cur, DevState *next)
+__global__ __launch_bounds__(VB) void k_vecf(Fin fin, Op op, long n, const double *pin, PartCount G, double *pout, const DevState *cur, DevState *next)
 {
     constexpr int NRF = Fin::NR > 0 ? Fin::NR : 1;
     __shared__ DevState L;

@@ -51,7 +51,7 @@ struct Driver {
         } else {
             hipLaunchKernelGGL((k_vec<Op, false>), dim3(g), dim3(VB), 0, c.stream, op, n, c.partials);
         }
-        last_g = g;
+        if (Op::NR > 0) pcnt.all(g);
         HIPCHK(hipGetLastError());
         return dbg(typeid(Op).name());
     }
@@ -69,14 +69,16 @@ struct Driver {
         const int g = grid_for(v2 ? (n + 1) / 2 : n);
         DevState *cur = c.state, *next = c.state == c.state_pair[0] ? c.state_pair[1] : c.state_pair[0];
         double *pin = c.partials, *pout = c.partials == c.partials_pair[0] ? c.partials_pair[1] : c.partials_pair[0];
-        if (v2) hipLaunchKernelGGL((k_vecf<Fin, Op, true>), dim3(g), dim3(VB), 0, c.stream, fin, op, n, pin, last_g, pout, cur, next);
-        else hipLaunchKernelGGL((k_vecf<Fin, Op, false>), dim3(g), dim3(VB), 0, c.stream, fin, op, n, pin, last_g, pout, cur, next);
+        if (v2) hipLaunchKernelGGL((k_vecf<Fin, Op, true>), dim3(g), dim3(VB), 0, c.stream, fin, op, n, pin, pcnt, pout, cur, next);
+        else hipLaunchKernelGGL((k_vecf<Fin, Op, false>), dim3(g), dim3(VB), 0, c.stream, fin, op, n, pin, pcnt, pout, cur, next);
         HIPCHK(hipGetLastError());
         c.state = next;
-        if (Op::NR > 0) { c.partials = pout; last_g = g; }
+        if (Op::NR > 0) { c.partials = pout; pcnt.all(g); }
         return dbg(typeid(Op).name());
     }
-    int last_g = 1;
+    // partial sums waiting in c.partials, per running sum: the latest reducing pass sets all rows to its grid; an A.x that
+    // carried a dot in its epilogue (csr_ax_dot) sets the rows it wrote
+    PartCount pcnt = [] { PartCount p; p.all(1); return p; }();
     // A body whose closing scalar step rides in the NEXT body's first pass (vecf) leaves the last one open: `tail`
     // closes it, once, after the last body and before the state is read.
     std::function<int()> tail;
@@ -93,9 +95,9 @@ struct Driver {
     }
 
     // scalar step after the most recent reducing vec()
-    template <class Fin> int scal(Fin fin) { return scal_g(fin, last_g); }
-    template <class Fin> int scal_g(Fin fin, int g)
+    template <class Fin> int scal(Fin fin)
     {
+        const PartCount g = pcnt;
         XgBox xb;
         if (comm_active() && Fin::NR > 0 && xg_box(&xb)) {
             // reduce + exchange over the peer mailboxes + scalar step in one launch

@@ -54,6 +54,27 @@ struct WaitPlan {
     const unsigned long long *flag[XG_MAXSEG];  // the neighbours' flag words in MY flag array
 };
 
+// Partial sums per running sum: slots 0 .. g[r]-1 of table row r hold the r-th sum's partials (one per block of the reducing
+// pass).  One running sum (two with yy) may instead come from the epilogue of an A.x kernel that leaves one partial per
+// workgroup -- up to AXP_CAP of them -- in a buffer of its own: ax_n entries at axp feed sum ax_row, those at axp + AXP_CAP feed
+// sum ax_row + 1.  Everything is added in a fixed order: the same bits wherever and however often the reduction runs.
+constexpr int AXP_CAP = 16384;
+struct PartCount {
+    int g[MAXR];
+    const double *axp = nullptr;
+    int ax_n = 0, ax_row = -1, ax_yy = 0;
+    void all(int v) { for (int r = 0; r < MAXR; r++) g[r] = v; ax_row = -1; ax_n = 0; ax_yy = 0; }
+};
+
+// Sums an A.x kernel leaves beside y (one GPU, solver loops): workgroup w adds its rows' y_i * u_i into part[w] and, when yy is
+// set, y_i * y_i into part[AXP_CAP + w] -- the dot that follows every A.x of the Krylov loops without its own pass over y.
+struct DotPlan {
+    const double *u = nullptr;
+    double *part = nullptr;
+    int yy = 0;
+    int dbg = 0;        // lab switches (LCG_HIP_AX_DOT_DBG): 1 no u load, 2 no reduction / store
+};
+
 // Mirror of the stop state in host-mapped pinned memory; written by the scalar kernels,
 // polled by the host without touching the stream.
 struct HostStatus {
@@ -93,6 +114,7 @@ struct Ctx {
     double *partials = nullptr;        // [MAXR][MAXG]: the table the latest reducing pass wrote (one of partials_pair)
     DevState *state = nullptr;         // the state the next kernel is handed (one of state_pair: driver.hpp, vecf)
     double *partials_pair[2] = {nullptr, nullptr};
+    double *ax_partials = nullptr;     // [2][AXP_CAP]: the sums an A.x kernel carried (csr.hip: k_spmv_lds1d), see PartCount
     DevState *state_pair[2] = {nullptr, nullptr};
     HostStatus *hstat = nullptr;       // pinned, mapped
     HostStatus *hstat_dev = nullptr;   // device alias of hstat
@@ -203,6 +225,10 @@ int spmv_launch(const CsrPart &P, bool is_complex, int variant, double mean_row,
 int spmv_launch_push(const CsrPart &P, bool is_complex, int variant, double mean_row, const double *x, double *y,
                      hipStream_t s, const int *done_flag, const PushPlan &pp);
 int jacobi_launch(const lcg_hip_csr *A, const double *x, double *z, int n, hipStream_t s);
+// y = A.x with the sums y.u (and y.y) riding in the product: 1 = done, *slots partial sums wait in part[0 .. *slots) (and
+// part[AXP_CAP ..)); 0 = this matrix / kernel family cannot (nothing was launched: the caller multiplies and reduces as before); < 0 failure
+int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots, hipStream_t s,
+               const int *done_flag);
 // csr_binned.hip
 int binned_ready(const CsrPart &P, hipStream_t s);      // 1 plan ready, 0 not eligible, < 0 failure
 int binned_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done_flag);

@@ -52,6 +52,7 @@ int ensure_init()
         HIPCHK(hipMemset(c.state_pair[i], 0, sizeof(DevState)));
     }
     c.partials = c.partials_pair[0];
+    HIPCHK(hipMalloc(&c.ax_partials, sizeof(double) * 2 * AXP_CAP));
     c.state = c.state_pair[0];
     HIPCHK(hipHostMalloc((void **)&c.hstat, sizeof(HostStatus), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void **)&c.hstat_dev, c.hstat, 0));
@@ -71,6 +72,16 @@ struct OpDotPlain {
     DevState *st; const double *a, *b;
     __device__ void prep() {}
     template <class T> __device__ void apply(long i, double *acc) { acc[0] += dotp(ld<T>(a, i), ld<T>(b, i)); }
+};
+struct OpDot2Plain {    // acc0 = a.b, acc1 = a.a
+    static constexpr int NR = 2, SKIP = SKIP_NEVER;
+    DevState *st; const double *a, *b;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const T x = ld<T>(a, i);
+        acc[0] += dotp(x, ld<T>(b, i)); acc[1] += dotp(x, x);
+    }
 };
 template <bool CONJ>
 struct OpCDot {      // complex: sum a_i b_i (CONJ = false) or sum conj(a_i) b_i
@@ -123,7 +134,8 @@ static int reduce_to_host(Op op, long n, bool cplx, uintptr_t align_or, double *
     double *dst = nullptr;
     HIPCHK(hipMalloc(&dst, sizeof(double) * NRR));
     FinCopy<NRR> fin{dst};
-    hipLaunchKernelGGL((k_scal<FinCopy<NRR>>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FUSED, XgBox());
+    PartCount pc; pc.all(g);
+    hipLaunchKernelGGL((k_scal<FinCopy<NRR>>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, pc, c.state, SC_FUSED, XgBox());
     if (comm_active()) { rc = comm_allreduce(dst, NRR, c.stream); if (rc) { hipFree(dst); return rc; } }
     hipError_t e = hipMemcpyAsync(c.scratch_host, dst, sizeof(double) * NRR, hipMemcpyDeviceToHost, c.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
@@ -272,6 +284,32 @@ int lcg_hip_dot(int n, const double *a, const double *b, double *result)
 {
     if (n <= 0 || !a || !b || !result) return LCG_HIP_E_ARG;
     return reduce_to_host<OpDotPlain, 1>(OpDotPlain{nullptr, a, b}, n, false, (uintptr_t)a | (uintptr_t)b, result);
+}
+int lcg_hip_spmv_dot(lcg_hip_csr_t A, const double *x, double *y, const double *u, double *result2)
+{
+    if (!A || !x || !y || !u || A->is_complex) return LCG_HIP_E_ARG;
+    int rc = ensure_init(); if (rc) return rc;
+    Ctx &c = ctx();
+    int slots = 0;
+    const int f = csr_ax_dot(A, x, y, u, 1, c.ax_partials, &slots, c.stream, nullptr);
+    if (f < 0) return f;
+    if (f == 0) {       // this matrix / kernel family keeps product and reduction apart
+        rc = lcg_hip_spmv(A, x, y); if (rc) return rc;
+        if (!result2) return 0;
+        return reduce_to_host<OpDot2Plain, 2>(OpDot2Plain{nullptr, y, u}, A->n_rows, false, (uintptr_t)y | (uintptr_t)u, result2);
+    }
+    if (!result2) return 0;
+    PartCount pc; pc.all(0); pc.axp = c.ax_partials; pc.ax_n = slots; pc.ax_row = 0; pc.ax_yy = 1;
+    double *dst = nullptr;
+    HIPCHK(hipMalloc(&dst, sizeof(double) * 2));
+    FinCopy<2> fin{dst};
+    hipLaunchKernelGGL((k_scal<FinCopy<2>>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, pc, c.state, SC_FUSED, XgBox());
+    hipError_t e = hipMemcpyAsync(c.scratch_host, dst, sizeof(double) * 2, hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    hipFree(dst);
+    if (e != hipSuccess) return fail(e, "spmv_dot", __FILE__, __LINE__);
+    result2[0] = c.scratch_host[0]; result2[1] = c.scratch_host[1];
+    return 0;
 }
 int lcg_hip_nrm2(int n, const double *a, double *result)
 {

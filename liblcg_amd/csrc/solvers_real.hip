@@ -167,6 +167,24 @@ struct OpCg1Update {    // d = b d - g; Ad = b Ad - w; m += a d; g += a Ad      
         st_(g, i, vadd(gv, ak * sv));
     }
 };
+struct OpCg1UpdateSums { // the same update leaving m.m, g.g and the NaN count behind (rows 0, 1, 3; g.w comes with the product: row 2)
+    static constexpr int NR = 4, SKIP = SKIP_DONE;
+    DevState *st; double *m, *g, *d, *Ad; const double *w; double ak, bk;
+    __device__ void prep() { ak = st->s[S_AK]; bk = st->s[S_BK]; }
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const T g0 = ld<T>(g, i);
+        const T dv = vsub(bk * ld<T>(d, i), g0);
+        const T sv = vsub(bk * ld<T>(Ad, i), ld<T>(w, i));
+        st_(d, i, dv); st_(Ad, i, sv);
+        const T mv = vadd(ld<T>(m, i), ak * dv);
+        const T gv = vadd(g0, ak * sv);
+        st_(m, i, mv); st_(g, i, gv);
+        acc[0] += dotp(mv, mv);
+        acc[1] += dotp(gv, gv);
+        acc[3] += nanflag(mv);
+    }
+};
 struct OpCg1Dots {      // m.m, g.g, g.w, NaN                                   lcg.cpp:244-255, 234
     static constexpr int NR = 4, SKIP = SKIP_DONE;
     DevState *st; const double *m, *g, *w;
@@ -363,6 +381,26 @@ struct RealCommon {
         : c(c_), drv(c_, n_, false, p.max_iterations, p.epsilon, p.abs_diff), para(p), inst(inst_),
           Afp(A), Pfp(P), m(m_), n(n_) {}
     int ax(const double *x, double *y) { return drv.timed_ax([&] { Afp(inst, x, y, n); }); }
+    // y = A.x followed by the sums y.u (and y.y): with the built-in product on a handle this process holds whole, the sums ride
+    // in the product's epilogue (csr.hip: k_spmv_lds1d) and reach the next scalar step as its sum `row` (y.y: row + 1) -- *fused
+    // says so; otherwise the product is made as always and the caller runs its own reducing pass
+    int ax_dot(const double *x, double *y, const double *u, bool yy, int row, bool *fused)
+    {
+        int f = 0, slots = 0;
+        const bool builtin = Afp == lcg_hip_csr_ax && inst != nullptr && !comm_active();
+        int rc = drv.timed_ax([&] {
+            if (builtin) f = csr_ax_dot(static_cast<lcg_hip_csr *>(inst), x, y, u, yy ? 1 : 0, c.ax_partials, &slots, c.stream, &c.state->done);
+            if (f == 0) Afp(inst, x, y, n);
+            else if (f < 0 && !c.ax_rc) c.ax_rc = f;
+        });
+        *fused = f == 1;
+        if (f == 1) {
+            PartCount &pc = drv.pcnt;
+            pc.axp = c.ax_partials; pc.ax_n = slots; pc.ax_row = row; pc.ax_yy = yy ? 1 : 0;
+            pc.g[row] = 0; if (yy) pc.g[row + 1] = 0;
+        }
+        return rc;
+    }
     int run_loop(const std::function<int()> &body)
     {
         auto pfp = [&](double resid, int t) -> int { return Pfp(inst, m, resid, &para, n, t); };
@@ -408,10 +446,34 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
                                (c.cg_schedule == LCG_HIP_CG_AUTO && (comm_active() || n < (1 << 17)));
     if (one_reduction) {
         double *w; TRY(ws.get(w, nullptr, sizeof(double) * n));
-        TRY(k.ax(g, w));
-        TRY(k.drv.vec(OpDot1{st, g, w}, al(g) | al(w)));
+        bool fused; TRY(k.ax_dot(g, w, g, false, 0, &fused));
+        if (!fused) TRY(k.drv.vec(OpDot1{st, g, w}, al(g) | al(w)));
         int rc;
-        if (Pfp == nullptr && !comm_active()) {
+        if (fused && Pfp == nullptr) {
+            // The product carries g.w, the update pass the other sums of the body: a body is TWO launches, `[step] update + sums |
+            // A.g + g.w`; the scalar step that closes body k rides in the update of body k+1, the last one is closed by the tail.
+            bool first = true;
+            k.drv.tail = [&]() -> int { return first ? k.drv.scal(FinCg1Start{}) : k.drv.scal(FinCg1Close{}); };
+            rc = k.run_loop([&]() -> int {
+                if (first) { TRY(k.drv.vecf(FinCg1Start{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w))); first = false; }
+                else TRY(k.drv.vecf(FinCg1Close{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
+                bool f; TRY(k.ax_dot(g, w, g, false, 2, &f));
+                if (!f) { c.err = "A.x stopped carrying its dot in the middle of a solve"; return LCG_HIP_E_ARG; }
+                return 0;
+            });
+            k.drv.tail = nullptr;
+        } else if (fused) {
+            // with a progress callback the state is read after every body: the same passes with the scalar step as its own
+            // kernel at the end of the body (the same arithmetic: bit-identical iterates)
+            TRY(k.drv.scal(FinCg1Start{}));
+            rc = k.run_loop([&]() -> int {
+                TRY(k.drv.vec(OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
+                bool f; TRY(k.ax_dot(g, w, g, false, 2, &f));
+                if (!f) { c.err = "A.x stopped carrying its dot in the middle of a solve"; return LCG_HIP_E_ARG; }
+                TRY(k.drv.scal(FinCg1Close{}));
+                return 0;
+            });
+        } else if (Pfp == nullptr && !comm_active()) {
             // One GPU, no progress callback: the scalar step that closes body k rides in the first pass of body k+1
             // (FinCg1Start in front of the first one), so a body is three launches: update | A.g | dots.  The last body is
             // closed by the tail.  Same arithmetic in the same order as the four-launch form below.
@@ -439,8 +501,8 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
         return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
     }
     int rc = k.run_loop([&]() -> int {
-        TRY(k.ax(d, Ad));                                                        // :232
-        TRY(k.drv.vec(OpDot1{st, d, Ad}, al(d) | al(Ad)));                       // :234
+        bool f; TRY(k.ax_dot(d, Ad, d, false, 0, &f));                          // :232
+        if (!f) TRY(k.drv.vec(OpDot1{st, d, Ad}, al(d) | al(Ad)));               // :234
         TRY(k.drv.vecf(FinAlpha{}, OpCgUpdate{st, m, g, d, Ad, 0.0}, a_upd));    // :235, :237-255
         TRY(k.drv.vecf(FinClose<false>{}, OpCgDir{st, d, g, 0.0}, al(d) | al(g)));   // :244-257, :259-263
         return 0;
@@ -478,8 +540,8 @@ static int solve_pcg(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pf
     TRY(k.drv.scal(FinInit{}));
     const uintptr_t a_all = al(m) | al(r) | al(z) | al(d) | al(Ad) | al(invdiag);
     int rc = k.run_loop([&]() -> int {
-        TRY(k.ax(d, Ad));                                                        // :387
-        TRY(k.drv.vec(OpDot1{st, d, Ad}, al(d) | al(Ad)));                       // :389
+        bool f; TRY(k.ax_dot(d, Ad, d, false, 0, &f));                          // :387
+        if (!f) TRY(k.drv.vec(OpDot1{st, d, Ad}, al(d) | al(Ad)));               // :389
         if (invdiag) {
             TRY(k.drv.vecf(FinAlpha{}, OpPcgUpdateJacobi{st, m, r, z, d, Ad, invdiag, 0.0}, a_all));   // :390, :392-414
         } else {
@@ -516,8 +578,8 @@ static int solve_cgs(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const 
     TRY(k.drv.vec(OpShadowInit<true>{st, Ax, B, m, r, r0, pk, u}, a_all));       // :480-497
     TRY(k.drv.scal(FinInit{}));
     int rc = k.run_loop([&]() -> int {
-        TRY(k.ax(pk, Ax));                                                       // :546
-        TRY(k.drv.vec(OpDot1{st, Ax, r0}, a_all));                               // :548-552
+        bool f; TRY(k.ax_dot(pk, Ax, r0, false, 0, &f));                        // :546
+        if (!f) TRY(k.drv.vec(OpDot1{st, Ax, r0}, a_all));                       // :548-552
         TRY(k.drv.vecf(FinAlpha{}, OpCgsQW{st, u, Ax, q, w, 0.0}, a_all));       // :553, :556-560
         TRY(k.ax(w, Ax));                                                        // :562
         TRY(k.drv.vec(OpCgsUpdate{st, m, r, w, Ax, r0, 0.0}, a_all));            // :565-588
@@ -549,11 +611,11 @@ static int solve_bicgstab(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, c
     TRY(k.drv.vec(OpShadowInit<false>{st, Ax, B, m, r, r0, pk, nullptr}, a_all)); // :650-667
     TRY(k.drv.scal(FinInit{}));
     int rc = k.run_loop([&]() -> int {
-        TRY(k.ax(pk, Ap));                                                       // :718
-        TRY(k.drv.vec(OpDot1{st, Ap, r0}, a_all));                               // :720-724
+        bool f; TRY(k.ax_dot(pk, Ap, r0, false, 0, &f));                        // :718
+        if (!f) TRY(k.drv.vec(OpDot1{st, Ap, r0}, a_all));                       // :720-724
         TRY(k.drv.vecf(FinAlpha{}, OpBicgS{st, r, Ap, s, 0.0}, a_all));          // :725, :727-731
-        TRY(k.ax(s, Ax));                                                        // :733
-        TRY(k.drv.vec(OpDot2{st, Ax, s}, a_all));                                // :735-740
+        TRY(k.ax_dot(s, Ax, s, true, 0, &f));                                    // :733
+        if (!f) TRY(k.drv.vec(OpDot2{st, Ax, s}, a_all));                        // :735-740
         TRY(k.drv.vecf(FinOmega{}, OpBicgUpdate{st, m, r, pk, s, Ax, r0, 0.0, 0.0}, a_all));   // :741, :743-772
         TRY(k.drv.vecf(FinClose<true>{}, OpBicgDir{st, pk, r, Ap, 0.0, 0.0}, a_all));          // :773-774, :776-780
         return 0;

@@ -76,14 +76,17 @@ def test_config4_nonsymmetric_bicgstab_full_size(api):
     m = torch.zeros_like(x)
     info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=1e-10, abs_diff=1), A, api.LCG_BICGSTAB)
     assert info.ret == 0 and info.residual <= 1e-10 and 5 <= info.iterations <= 200
-    assert ((m - xt).norm() / xt.norm()).item() <= 1e-5
+    # how close to x_true the stop leaves the answer: |e| <= |A^-1| |r| with |r| = residual * N <= 1e-3 and |A^-1| <= 1 / 0.01
+    # (rows are diagonally dominant by the generator's 0.01 margin) => |e| / |x_true| <= 0.1 / 1826 = 5.5e-5; which iteration
+    # happens to cross the threshold decides where below that the run lands (seen: 0.7e-5 .. 1.2e-5)
+    assert ((m - xt).norm() / xt.norm()).item() <= 5.5e-5
     A.spmv(m, Ax); api.synchronize()
     true_res = (Ax - b).norm().item() / n
     assert true_res <= 1.05e-10 and abs(true_res - info.residual) <= 0.05 * info.residual
     # CGS, the reference's default solver (lcg.h:72), on the same system
     m.zero_()
     info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=1e-10, abs_diff=1), A, api.LCG_CGS)
-    assert info.ret == 0 and ((m - xt).norm() / xt.norm()).item() <= 1e-5
+    assert info.ret == 0 and ((m - xt).norm() / xt.norm()).item() <= 5.5e-5
 
 
 @pytest.mark.parametrize("pattern,n,band,seed", NONSYM_SYSTEMS)

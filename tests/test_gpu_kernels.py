@@ -123,6 +123,52 @@ def test_spmv_transpose_and_conjugate(api, port, cplx):
     assert torch.equal(yd, y2)
 
 
+def test_product_carrying_its_dot(api, port):
+    """lcg_hip_spmv_dot: y = A.x with y.u and y.y riding in the product's epilogue (k_spmv_lds1d, what the one-GPU solver loops
+    use for the dot that follows every A.x: lcg.cpp:234, 548-552, 735-740).  y must be BIT-identical to the plain product's;
+    the sums agree with the oracle's product summed in numpy to rounding; the same bits on a second call.  Row lengths choose
+    every rows-per-block shape (256 .. 16); ragged rows, empty rows, sizes around the block edges; systems the fused form does
+    not take (rows longer than a window, more row blocks than the threshold) answer through product + reduction."""
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    res = (C.c_double * 2)()
+    cases = [(n, ml) for ml in (3, 12, 30, 60, 130) for n in (1, 63, 64, 65, 257, 5000)] + [(40000, 6), (3001, 40)]
+    for n, max_len in cases:
+        long_rows = [(5, 5000)] if (n, max_len) == (3001, 40) else ()
+        rp, col = _ragged(rng, n, n, max_len, long_rows=long_rows)
+        if rp[-1] == 0:
+            continue
+        val = rng.standard_normal(rp[-1]); x = rng.standard_normal(n); u = rng.standard_normal(n)
+        A = api.CsrMatrix.from_csr(rp, col, val)
+        xd = torch.from_numpy(x).cuda(); ud = torch.from_numpy(u).cuda()
+        y0 = torch.empty_like(xd); y1 = torch.full_like(xd, 3.0)
+        A.spmv(xd, y0); api.synchronize()
+        assert lib.lcg_hip_spmv_dot(A.h, xd.data_ptr(), y1.data_ptr(), ud.data_ptr(), res) == 0
+        kern = lib.lcg_hip_csr_last_kernel(A.h).decode()
+        fused = "carrying the dot" in kern
+        if long_rows:
+            assert not fused, kern          # a row longer than an LDS window: the windowed kernel, two launches
+        elif max_len <= 30:
+            assert fused, (n, max_len, kern)    # (longer rows: some block's slice may exceed one window, then as above)
+        assert torch.equal(y0, y1), (n, max_len, kern)
+        yr = port.csr_matvec(rp, col, val, x)
+        bound = float(np.abs(yr) @ np.abs(u)) + 1e-300, float(yr @ yr) + 1e-300
+        assert abs(res[0] - float(yr @ u)) <= 1e-12 * bound[0] and abs(res[1] - float(yr @ yr)) <= 1e-12 * bound[1], (n, max_len)
+        first = (res[0], res[1])
+        assert lib.lcg_hip_spmv_dot(A.h, xd.data_ptr(), y1.data_ptr(), ud.data_ptr(), res) == 0
+        assert (res[0], res[1]) == first
+        A.destroy()
+    # more row blocks than the threshold: two launches, same answers
+    A = api.CsrMatrix.laplace2d(800, 800); n = 640000
+    xd = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 3, 0, n, xd)
+    y0 = torch.empty_like(xd); y1 = torch.empty_like(xd)
+    A.spmv(xd, y0)
+    assert lib.lcg_hip_spmv_dot(A.h, xd.data_ptr(), y1.data_ptr(), xd.data_ptr(), res) == 0
+    assert "carrying the dot" not in lib.lcg_hip_csr_last_kernel(A.h).decode() and torch.equal(y0, y1)
+    assert abs(res[0] - float(y0 @ xd)) <= 1e-12 * float(y0.abs() @ xd.abs()) and abs(res[1] - float(y0 @ y0)) <= 1e-12 * float(y0 @ y0)
+
+
 def test_spmv_edge_shapes(api, port):
     rng = np.random.default_rng(3)
     for n in (1, 2, 63, 64, 65, 255, 256, 257):

@@ -235,6 +235,9 @@ def test_complex_bicg_with_adjoint_product(api, port, goldens, case1kc, case10kc
     assert np.linalg.norm(x12 - ref["x"]) <= 1e-9 * np.linalg.norm(ref["x"])
 
 
+XS_BAND = 1e-2     # |x - x_known| of a converged complex CGS / TFQMR run on the bundled systems (see the sensitivity test)
+
+
 @pytest.mark.parametrize("sid,name", [(2, "cgs"), (4, "tfqmr")])
 @pytest.mark.parametrize("case", ["1K", "10K"])
 def test_complex_shadow_solvers(api, port, goldens, case1kc, case10kc, sid, name, case):
@@ -247,12 +250,14 @@ def test_complex_shadow_solvers(api, port, goldens, case1kc, case10kc, sid, name
     assert info.ret == ret == 0
     assert info.residual <= 1e-10
     assert abs(info.iterations - iters) <= 0.12 * iters                 # rounding-order sensitive recurrences
-    assert np.linalg.norm(x - xs) <= 2e-3
+    # distance to the bundled answer at the stop (sqrt(r.r)/N <= 1e-10): the reference's own runs end 0.6e-3 .. 4.1e-3 away on
+    # the 10K system depending on 1-ulp changes of b (tests/test_oracle_sensitivity.py::test_complex_10k_distance_to_the_known_answer)
+    assert np.linalg.norm(x - xs) <= XS_BAND
     gold = goldens[f"cplx/{name}_{case}/x"]
     assert np.linalg.norm(x - gold) / np.linalg.norm(gold) <= 5e-5
     # default (seeded) shadow vector: still converges to the known answer
     info2, x2 = _solve_cplx(api, A, sid, b, n, api.clcg_default_parameters(epsilon=1e-10, abs_diff=1))
-    assert info2.ret == 0 and np.linalg.norm(x2 - xs) <= 2e-3
+    assert info2.ret == 0 and np.linalg.norm(x2 - xs) <= XS_BAND
 
 
 def test_complex_bicgstab_and_cap(api, port, goldens, case1kc):

@@ -61,6 +61,22 @@ def test_complex_converged_runs(port, case1kc, sid):
     assert _rel(a["x"], c["x"]) <= 1e-9 / 10
 
 
+@pytest.mark.parametrize("name,sid", [("cgs", po.CLCG_CGS), ("tfqmr", po.CLCG_TFQMR)])
+def test_complex_10k_distance_to_the_known_answer(port, goldens, case10kc, name, sid):
+    """How far from the bundled answer a CONVERGED complex CGS / TFQMR run of the reference ends (stop: sqrt(r.r)/N <= 1e-10)
+    moves with rounding: 0.6e-3 .. 4.1e-3 over 1-ulp changes of b with the golden run's own shadow vector -- the golden run
+    itself sits at 3.1e-3 (CGS) / 4.1e-3 (TFQMR).  The GPU test's band (XS_BAND = 1e-2) is twice the largest."""
+    n, rp, ci, v, b, xs = case10kc
+    rb = port.vecrnd(n, int(goldens[f"cplx/{name}_10K/meta"][5]))
+    para = po.default_cpara(epsilon=1e-10, abs_diff=1)
+    dist = []
+    for s in range(3):
+        r = port.csolve(sid, rp, ci, v, b if s == 0 else _perturbed(b, s), para=para, rbar0=rb)
+        assert r["ret"] == 0
+        dist.append(np.linalg.norm(r["x"] - xs))
+    assert max(dist) <= 1e-2 / 2 and max(dist) >= 2e-3 / 2     # the old 2e-3 band was inside the reference's own spread
+
+
 def test_complex_bicgstab_is_chaotic_on_the_bundled_systems(port, case1kc, case10kc):
     for (n, rp, ci, v, b, _), lo, hi in ((case1kc, 1e-9, 1e-4 / 10), (case10kc, 1e-5, 1.0)):
         rb = port.vecrnd(n, 42)
