@@ -197,6 +197,13 @@ int lcg_hip_csr_set_kernel(lcg_hip_csr_t A, int variant);
  * span < 2^21 columns), 0 never (frees the packed copy), 1 whenever eligible.  LCG_HIP_PACKED=0/1
  * overrides for the whole process. */
 int lcg_hip_csr_set_packed(lcg_hip_csr_t A, int mode);
+/* Blocks of the packed form stored as RUNS: every row of the block has the same number of entries and every entry's column is
+ * one more than the entry in the same slot of the row above (constant diagonals, stencils away from the edges).  Such a
+ * block carries row 0's columns only -- 8.06 instead of 10.3 bytes of stream per entry -- and its x gathers leave together
+ * with the value stream (-22 % on the headline A.x, bit-identical y).  Returns the number of run blocks of the packed copy
+ * (0 before the first product built it, or when there are none); *blocks_out (may be NULL) = all blocks of 64 rows.
+ * LCG_HIP_PACKED_RUNS=0 stores every block with its own columns. */
+int64_t lcg_hip_csr_packed_runs(lcg_hip_csr_t A, int64_t *blocks_out);
 /* Two-pass "binned" A.x for matrices whose columns are scattered over more of x than any cache holds (the
  * arbitrary user CSR of sample8.cu:96-103 at its worst): pass 1 expands x into entry order with a 64 KB slice
  * of x in LDS per workgroup, pass 2 streams val and the expanded x and sums the rows in LDS (one wavefront per

@@ -294,30 +294,43 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 constexpr int PK_R = 64;
 constexpr int PK_SPAN = 1 << 21;
 
-__global__ __launch_bounds__(64) void k_pk_meta(int n, const int *rowptr, const int *col, int *base, int *ngroups, int *maxspan)
-{   // ngroups[b] = entries of block b for now (k_pk_groups turns them into groups); maxspan[0] = widest block, [1] = longest row
+// A RUN block (round 2, third session): every row of the block has the same number of entries L and every entry's column is
+// one more than the entry in the same slot of the row above -- the shape of constant diagonals and stencils away from the
+// matrix edges.  Such a block needs no columns of its own beyond row 0's: column(row r, slot k) = column(row 0, slot k) + r.
+// It stores row 0's L columns as plain int32 (four per 16-byte group) and is marked by base[b] = -1 - L.
+__global__ __launch_bounds__(64) void k_pk_meta(int n, const int *rowptr, const int *col, int *base, int *ngroups, int *maxspan, int runs)
+{   // ngroups[b] = entries of block b for now, -L for a run block (k_pk_groups turns them into groups); maxspan[0] = widest block, [1] = longest row
     const int b = blockIdx.x;
     const long row0 = (long)b * PK_R;
     const int r1 = (int)min((long)n, row0 + PK_R);
     const int s = rowptr[row0], e = rowptr[r1];
     int lo = 0x7fffffff, hi = 0;
     for (int k = s + threadIdx.x; k < e; k += 64) { const int c = col[k]; lo = min(lo, c); hi = max(hi, c); }
-    int len = 0;
-    if (row0 + threadIdx.x < r1) len = rowptr[row0 + threadIdx.x + 1] - rowptr[row0 + threadIdx.x];
+    int len = 0, lmin = 0x7fffffff;
+    if (row0 + threadIdx.x < r1) { len = rowptr[row0 + threadIdx.x + 1] - rowptr[row0 + threadIdx.x]; lmin = len; }
     for (int off = 32; off > 0; off >>= 1) {
         lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); len = max(len, __shfl_down(len, off, 64));
+        lmin = min(lmin, __shfl_down(lmin, off, 64));
+    }
+    const int L = __shfl(len, 0, 64), Lmin = __shfl(lmin, 0, 64);
+    int run = runs && L == Lmin && L > 0 && L <= 0x3fffffff;
+    if (run) {      // uniform
+        int bad = 0;
+        for (int k = s + L + threadIdx.x; k < e; k += 64) bad |= col[k] != col[k - L] + 1;
+        run = __ballot(bad) == 0;
     }
     if (threadIdx.x == 0) {
         if (e == s) { lo = 0; hi = 0; }
-        base[b] = lo; ngroups[b] = e - s;
+        base[b] = run ? -1 - L : lo; ngroups[b] = run ? -L : e - s;
         atomicMax(maxspan, hi - lo); atomicMax(maxspan + 1, len);
+        if (run) atomicAdd(maxspan + 2, 1);
     }
 }
 
 __global__ void k_pk_groups(int nb, int per, int *ngroups)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nb) ngroups[b] = (ngroups[b] + per - 1) / per;
+    if (b < nb) { const int g = ngroups[b]; ngroups[b] = g < 0 ? (-g + 3) / 4 : (g + per - 1) / per; }
 }
 
 // Field j of a 128-bit group (lo, hi): BITS = 21 -> six fields, three per 64-bit half; BITS = 18 -> seven
@@ -342,7 +355,14 @@ __global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const 
     const long row0 = (long)b * PK_R;
     const int r1 = (int)min((long)n, row0 + PK_R);
     const int s = rowptr[row0], e = rowptr[r1];
-    const int ng = (e - s + PER - 1) / PER, bs = base[b];
+    const int bs = base[b];
+    if (bs < 0) {       // run block: row 0's columns as they are
+        const int L = -1 - bs;
+        int *dst = reinterpret_cast<int *>(packed + pofs[b]);
+        for (int k = threadIdx.x; k < ((L + 3) & ~3); k += VB) dst[k] = k < L ? col[s + k] : 0;
+        return;
+    }
+    const int ng = (e - s + PER - 1) / PER;
     for (int g = threadIdx.x; g < ng; g += VB) {
         u64 lo = 0, hi = 0;
         for (int j = 0; j < PER; j++) {
@@ -393,6 +413,58 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     const int cnt = e - s, ng = (cnt + PER - 1) / PER;
     const int po = pofs[bid], bs = pbase[bid];
     const int bv = s & ~1, cntv = e - bv;
+
+    if (bs < 0) {
+        // RUN block (k_pk_meta): every row holds L entries and column(row r, slot k) = column(row 0, slot k) + r.  Nothing but
+        // the values streams; the columns are row 0's L integers, read through the scalar cache (a wavefront is one slot j0 of
+        // 64 rows: its k is uniform), and -- the point -- the x gathers no longer wait for the staged columns: they go out
+        // TOGETHER with the value stream, one memory latency per block instead of two.  Entry order per lane and the order of
+        // the additions are those of the general path below: the same bits.
+        const int L = -1 - bs;
+        const int w = __builtin_amdgcn_readfirstlane(j0);
+        const int *bcol = reinterpret_cast<const int *>(packed + po);
+        const bool live = rl < nrows;
+        v2d pv[VR];
+#pragma unroll
+        for (int r = 0; r < VR; r++) {
+            const int u = 2 * (tid + r * VB);
+            pv[r] = *reinterpret_cast<const v2d *>(val + (long)bv + (u < cntv ? u : 0));
+        }
+        double xv[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; q++) {
+            const int k = w + q * T;                     // uniform
+            const int c0 = bcol[k < L ? k : 0];           // scalar load
+            xv[q] = x[(k < L && live) ? c0 + rl : 0];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < VR; r++) {
+            const int u = 2 * (tid + r * VB);
+            if (u < cntv) *reinterpret_cast<v2d *>(sval + u) = pv[r];
+        }
+        __syncthreads();
+        double acc = 0.0;
+        const int rs = s + rl * L - bv;                    // first entry of this lane's row in the staged values
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < UNR; q++) {
+                const int k = w + q * T;
+                acc = k < L ? fma(sval[rs + k], xv[q], acc) : acc;
+            }
+            for (int k = w + UNR * T; k < L; k += T) acc = fma(sval[rs + k], x[bcol[k] + rl], acc);
+        }
+        __syncthreads();
+        sred[j0][rl] = acc;
+        __syncthreads();
+        if (j0 == 0 && live) {
+            double v = sred[0][rl];
+#pragma unroll
+            for (int j = 1; j < T; j++) v += sred[j][rl];
+            y[row0 + rl] = v;
+        }
+        return;
+    }
 
     v4i pg[GR]; v2d pv[VR];
 #pragma unroll
@@ -489,13 +561,14 @@ static bool packed_ready(const CsrPart &P, hipStream_t s)
     const int nb = (n + PK_R - 1) / PK_R;
     int *ngr = nullptr, *span = nullptr;
     long total = 0;
-    int hspan[2] = {0, 0};
+    int hspan[3] = {0, 0, 0};
+    static const int runs = [] { const char *e = std::getenv("LCG_HIP_PACKED_RUNS"); return e ? atoi(e) : 1; }();    // 0: A/B runs without run blocks
     bool ok = hipMalloc(&P.pk_base, sizeof(int) * (size_t)nb) == hipSuccess && hipMalloc(&P.pk_ofs, sizeof(int) * ((size_t)nb + 1)) == hipSuccess &&
-              hipMalloc(&ngr, sizeof(int) * (size_t)nb) == hipSuccess && hipMalloc(&span, 2 * sizeof(int)) == hipSuccess &&
-              hipMemsetAsync(span, 0, 2 * sizeof(int), s) == hipSuccess;
+              hipMalloc(&ngr, sizeof(int) * (size_t)nb) == hipSuccess && hipMalloc(&span, 3 * sizeof(int)) == hipSuccess &&
+              hipMemsetAsync(span, 0, 3 * sizeof(int), s) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(k_pk_meta, dim3(nb), dim3(64), 0, s, n, P.rowptr, P.col, P.pk_base, ngr, span);
-        ok = hipMemcpyAsync(hspan, span, 2 * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        hipLaunchKernelGGL(k_pk_meta, dim3(nb), dim3(64), 0, s, n, P.rowptr, P.col, P.pk_base, ngr, span, runs);
+        ok = hipMemcpyAsync(hspan, span, 3 * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     }
     if (ok) ok = hspan[0] < PK_SPAN;
     static const int force_bits = [] { const char *e = std::getenv("LCG_HIP_PACKED_BITS"); return e ? atoi(e) : 0; }();   // 21: A/B runs
@@ -524,6 +597,8 @@ static bool packed_ready(const CsrPart &P, hipStream_t s)
         return false;
     }
     P.pk_maxrow = hspan[1];
+    P.pk_runs = hspan[2];
+    P.pk_groups = total;
     P.pk_bits = bits;
     P.pk_state = 1;
     return true;
@@ -707,7 +782,8 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
 #undef PK_LAUNCH
 #undef PK_CASE
                 HIPCHK(hipGetLastError());
-                P.last_kernel = P.pk_bits == 18 ? "k_spmv_ldsp (LDS-staged, 18-bit packed columns)" : "k_spmv_ldsp (LDS-staged, 21-bit packed columns)";
+                P.last_kernel = P.pk_runs > 0 ? (P.pk_bits == 18 ? "k_spmv_ldsp (LDS-staged, run blocks + 18-bit packed columns)" : "k_spmv_ldsp (LDS-staged, run blocks + 21-bit packed columns)")
+                                              : (P.pk_bits == 18 ? "k_spmv_ldsp (LDS-staged, 18-bit packed columns)" : "k_spmv_ldsp (LDS-staged, 21-bit packed columns)");
                 return 0;
             }
         }
@@ -1499,6 +1575,14 @@ const char *lcg_hip_csr_binned_status(lcg_hip_csr_t A)
 {
     if (!A) return "";
     return A->distributed ? A->loc.bn_why : A->main.bn_why;
+}
+
+int64_t lcg_hip_csr_packed_runs(lcg_hip_csr_t A, int64_t *blocks_out)
+{
+    if (!A) return 0;
+    const CsrPart &P = A->distributed ? A->loc : A->main;
+    if (blocks_out) *blocks_out = (P.n_rows + PK_R - 1) / PK_R;
+    return P.pk_state > 0 ? P.pk_runs : 0;
 }
 
 int64_t lcg_hip_csr_last_traffic_model(lcg_hip_csr_t A)

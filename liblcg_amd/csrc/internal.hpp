@@ -173,6 +173,8 @@ struct CsrPart {
     mutable void *pk_data = nullptr;                        // 16 bytes per group of 6 entries
     mutable int pk_maxrow = 0;                              // longest row (chooses the gather batch of the kernel)
     mutable int pk_bits = 21;                               // width of a packed column: 18 (seven per group) or 21 (six)
+    mutable int pk_runs = 0;                                // blocks stored as runs (row 0's columns only; csr.hip: k_pk_meta)
+    mutable long pk_groups = 0;                             // 16-byte groups of the packed columns
     // two-pass "binned" product for scattered columns (csr_binned.hip), plan built on first use
     int64_t n_cols = 0;            // columns the part addresses (0 = unknown: never binned)
     mutable int bn_mode = -1;      // -1 auto (large real matrices whose row blocks span more of x than the L2 holds), 0 never, 1 whenever eligible

@@ -84,6 +84,65 @@ def test_packed_columns_are_bit_identical(api, port):
         B.destroy()
 
 
+def test_run_blocks_of_the_packed_form(api, port):
+    """Run blocks (csr.hip: k_pk_meta / the run path of k_spmv_ldsp): a block of 64 rows whose rows all hold L entries with
+    column(row r, slot k) = column(row 0, slot k) + r keeps row 0's columns only.  Against the plain row-block kernel the
+    product must not change by a bit -- on pure stencils (L = 1 .. 40: one slot per lane, the 9-slot batch, the tail loop),
+    on sizes that leave a partial last block, on matrices where ONE entry of one block breaks the pattern (that block must
+    fall back to its own columns, the others stay runs), and on the generated constant-diagonal system, whose interior
+    blocks must be found to be runs."""
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(99)
+    nblk = C.c_int64()
+    for L, n in ((1, 640), (2, 700), (3, 64), (5, 6400), (9, 1000), (33, 20000), (35, 4096 + 7), (36, 5000), (40, 3000)):
+        ncols = n + 5000
+        offs = np.sort(rng.choice(5000, L, replace=False)).astype(np.int64)
+        col = (np.arange(n)[:, None] + offs[None, :]).astype(np.int32)
+        rp = (np.arange(n + 1) * L).astype(np.int32)
+        for broken in (False, True):
+            c = col.copy()
+            want_runs = (n + 63) // 64
+            if broken and n > 64 and L > 1:
+                c[70, L // 2] = c[70, L // 2 - 1] + 1 if c[70, L // 2 - 1] + 1 < c[70, L // 2] else c[70, L // 2] - 1     # still sorted, still in range
+                if np.array_equal(c, col):
+                    continue
+                want_runs -= 1
+            val = rng.standard_normal(n * L); x = rng.standard_normal(ncols)
+            A = api.CsrMatrix.from_csr(rp, c.reshape(-1), val, n_cols=ncols)
+            xd = torch.from_numpy(x).cuda()
+            y0 = torch.empty(n, dtype=torch.float64, device="cuda"); y1 = torch.full_like(y0, 5.0)
+            A.set_kernel(-64)
+            assert lib.lcg_hip_csr_set_packed(A.h, 0) == 0
+            A.spmv(xd, y0); api.synchronize()
+            assert lib.lcg_hip_csr_set_packed(A.h, 1) == 0
+            A.spmv(xd, y1); api.synchronize()
+            if 64 * L <= 2240:      # the block fits one LDS window: the packed kernel answers
+                assert "run blocks" in lib.lcg_hip_csr_last_kernel(A.h).decode(), (L, n, lib.lcg_hip_csr_last_kernel(A.h))
+                assert lib.lcg_hip_csr_packed_runs(A.h, C.byref(nblk)) == want_runs and nblk.value == (n + 63) // 64, (L, n, broken)
+            assert torch.equal(y0, y1), (L, n, broken)
+            ref = port.csr_matvec(rp, c.reshape(-1), val, x)
+            assert np.abs(y1.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+            A.destroy()
+    # the generated constant-diagonal system: all blocks away from the first and last `band` rows are runs
+    nn, band = 400000, 3000
+    B = api.CsrMatrix.generate(nn, 16, band, True, 5, 0.01)
+    xb = torch.empty(nn, dtype=torch.float64, device="cuda"); api.gen_xtrue(nn, 3, 0, nn, xb)
+    z0 = torch.empty_like(xb); z1 = torch.empty_like(xb)
+    assert lib.lcg_hip_csr_set_packed(B.h, 0) == 0
+    B.spmv(xb, z0); api.synchronize()
+    assert lib.lcg_hip_csr_set_packed(B.h, 1) == 0
+    B.spmv(xb, z1); api.synchronize()
+    runs = lib.lcg_hip_csr_packed_runs(B.h, C.byref(nblk))
+    assert nblk.value - 2 * (band // 64 + 2) <= runs < nblk.value, (runs, nblk.value)
+    assert torch.equal(z0, z1)
+    # a row-random band has none
+    B2 = api.CsrMatrix.generate(nn, 16, band, True, 5, 0.01, pattern=api.GEN_ROW_RANDOM_BAND)
+    assert lib.lcg_hip_csr_set_tiled(B2.h, 0) == 0 and lib.lcg_hip_csr_set_packed(B2.h, 1) == 0
+    B2.spmv(xb, z1); api.synchronize()
+    assert lib.lcg_hip_csr_packed_runs(B2.h, None) == 0 and "run blocks" not in lib.lcg_hip_csr_last_kernel(B2.h).decode()
+
+
 @pytest.mark.parametrize("cplx", [False, True])
 def test_spmv_transpose_and_conjugate(api, port, cplx):
     """op(A).x for the (layout, conjugate) pairs of clcg_axfunc_ptr (clcg.h:40-41): A^T, A^H, conj(A)."""
