@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64) void k_pk_meta(int n, const int *rowptr, const 
 __global__ void k_pk_groups(int nb, int per, int *ngroups)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nb) { const int g = ngroups[b]; ngroups[b] = g < 0 ? (-g + 3) / 4 : (g + per - 1) / per; }
+    if (b < nb) { const int g = ngroups[b]; ngroups[b] = g < 0 ? (-g + 3) / 4 : (per > 0 ? (g + per - 1) / per : 0); }
 }
 
 // Field j of a 128-bit group (lo, hi): BITS = 21 -> six fields, three per 64-bit half; BITS = 18 -> seven
@@ -350,12 +350,13 @@ template <> __device__ __forceinline__ int pk_field<18>(u64 lo, u64 hi, int j)
 template <int BITS>
 __global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const int *col, const int *base, const int *pofs, v4i *packed)
 {
-    constexpr int PER = 128 / BITS;
+    constexpr int PER = BITS > 0 ? 128 / BITS : 1;
     const int b = blockIdx.x;
     const long row0 = (long)b * PK_R;
     const int r1 = (int)min((long)n, row0 + PK_R);
     const int s = rowptr[row0], e = rowptr[r1];
     const int bs = base[b];
+    if (BITS == 0 && bs >= 0) return;       // runs only: the other blocks keep nothing
     if (bs < 0) {       // run block: row 0's columns as they are
         const int L = -1 - bs;
         int *dst = reinterpret_cast<int *>(packed + pofs[b]);
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const 
             const int k = s + PER * g + j;
             const u64 c = k < e ? (u64)(col[k] - bs) : 0;
             if (BITS == 21) { if (j < 3) lo |= c << (21 * j); else hi |= c << (21 * (j - 3)); }
-            else {
+            else if (BITS > 0) {
                 const int sh = BITS * j;
                 if (sh < 64) { lo |= c << sh; if (sh + BITS > 64) hi |= c >> (64 - sh); }
                 else hi |= c << (sh - 64);
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
 #pragma unroll
         for (int r = 0; r < VR; r++) {
             const int u = 2 * (tid + r * VB);
+            // (non-temporal value loads, so that the stream would not push x out of the L2: 581 vs 520 us -- measured and removed)
             pv[r] = *reinterpret_cast<const v2d *>(val + (long)bv + (u < cntv ? u : 0));
         }
         double xv[UNR];
@@ -546,17 +548,120 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     }
 }
 
+// ---- short rows (<= 17 entries on average: 5-point / 7-point stencils, the 1000 x 1000 Laplacian of BASELINE configs[1]) ---------
+// The LDS-staged kernels put 256 or 128 rows of such a matrix into a block and spend it on staging ~1300 entries behind two
+// barriers.  Where the 64-row blocks are RUNS (k_pk_meta) ONE WAVEFRONT owns a block, lane = row: the L columns of row 0 come
+// through the scalar cache, the gathers of x (column + lane: one contiguous run per entry slot) go out at once with the
+// block's values, which are read coalesced (the block's 64 L values are contiguous) and handed to their rows through a
+// wavefront-private piece of LDS -- no barrier anywhere.  (Reading them straight from the row, 8 bytes at a stride of L
+// doubles, was measured first: every 128-byte line is then fetched by L instructions and the L1 does not hold a CU's waves'
+// lines in between -- 20.0 us on the 1M-row Laplacian against 15.9 for the staged kernel.)  The few blocks that are not runs
+// (grid-row boundaries) are walked from the CSR arrays by the same wavefront.  Entry k of a row is added to partial sum
+// k mod T, the partial sums in index order -- the arithmetic of k_spmv_lds1 with VB / T rows per block (T = 1 for up to 8.5
+// entries per row, 2 up to 17), which is the kernel the automatic choice would otherwise take: the same bits.
+template <int T>
+__global__ __launch_bounds__(VB) void k_spmv_run1(int n, int LP, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                  const double *__restrict__ val, const int *__restrict__ pofs,
+                                                  const int *__restrict__ pbase, const int *__restrict__ pcols,
+                                                  const double *__restrict__ x, double *__restrict__ y, const int *done)
+{
+    extern __shared__ double wlds[];                    // [VB / 64][64 * LP]: a wavefront's values, row by row (LP odd: no bank conflicts)
+    if (done && *done) return;
+    constexpr int NB = 8;                               // entries in flight per lane and batch (a multiple of T)
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * (VB / 64) + wv;
+    const long row0 = (long)b * 64;
+    if (row0 >= n) return;
+    const int nrows = (int)min(64L, n - row0);
+    const bool live = lane < nrows;
+    const int bs = pbase[b], po = pofs[b], s = rowptr[row0];
+    double acc[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) acc[j] = 0.0;
+    if (bs < 0) {
+        const int L = -1 - bs;
+        const int *bcol = pcols + 4 * (long)po;
+        double *mine = wlds + (size_t)wv * 64 * LP;
+        const int tot = nrows * L;
+        const float invL = 1.0f / (float)L;
+        double xv[NB];
+#pragma unroll
+        for (int q = 0; q < NB; q++) {                  // the gathers of the first batch leave with the values
+            const int c0 = bcol[q < L ? q : 0];
+            xv[q] = x[(q < L && live) ? c0 + lane : 0];
+        }
+        for (int j0 = 0; j0 < L; j0 += NB) {
+            double v[NB];
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                const int e = (j0 + q) * 64 + lane;
+                v[q] = val[s + ((j0 + q < L && e < tot) ? e : 0)];
+            }
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                const int e = (j0 + q) * 64 + lane;
+                if (j0 + q < L && e < tot) {
+                    int r = (int)(((float)e + 0.5f) * invL);        // e / L (e < 2^16: exact after the correction below)
+                    r -= r * L > e; r += (r + 1) * L <= e;
+                    mine[r * LP + (e - r * L)] = v[q];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double *row = mine + lane * LP;
+        for (int k0 = 0; k0 < L; k0 += NB) {
+            if (k0 > 0) {
+#pragma unroll
+                for (int q = 0; q < NB; q++) {
+                    const int k = k0 + q;
+                    const int c0 = bcol[k < L ? k : 0];
+                    xv[q] = x[(k < L && live) ? c0 + lane : 0];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                const double a = (k0 + q < L && live) ? row[k0 + q] : 0.0;
+                acc[q % T] = (k0 + q < L) ? fma(a, xv[q], acc[q % T]) : acc[q % T];
+            }
+        }
+    } else {
+        // not a run: every lane walks its own row out of the CSR arrays, NB entries at a time -- all columns and values of a
+        // batch requested before the first gather, all gathers before the first product (a one-by-one walk is a chain of
+        // 2 L dependent loads, and 13 % of the Laplacian's blocks take this path)
+        int rs = 0, re = 0;
+        if (live) { rs = rowptr[row0 + lane]; re = rowptr[row0 + lane + 1]; }
+        for (int k0 = rs; __ballot(k0 < re) != 0; k0 += NB) {
+            int c[NB]; double a[NB], xv[NB];
+#pragma unroll
+            for (int q = 0; q < NB; q++) { const bool ok = k0 + q < re; c[q] = col[ok ? k0 + q : 0]; a[q] = val[ok ? k0 + q : 0]; }
+#pragma unroll
+            for (int q = 0; q < NB; q++) xv[q] = x[k0 + q < re ? c[q] : 0];
+#pragma unroll
+            for (int q = 0; q < NB; q++) acc[q % T] = (k0 + q < re) ? fma(a[q], xv[q], acc[q % T]) : acc[q % T];
+        }
+    }
+    double v = acc[0];
+#pragma unroll
+    for (int j = 1; j < T; j++) v += acc[j];
+    if (live) y[row0 + lane] = v;
+}
+
 int device_exclusive_scan(int n, const int *counts, int *rowptr, hipStream_t s, long *total);
 
 // Build the packed columns of P once (device; two short synchronisations).  Returns true when ready.
-static bool packed_ready(const CsrPart &P, hipStream_t s)
+// runs_only (k_spmv_run1, short rows): only the run blocks get anything -- row 0's columns; the other blocks are walked
+// from the CSR arrays -- so the copy costs a few integers per block, and small systems take it too (pk_state = 2).
+static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only)
 {
-    if (P.pk_state != 0) return P.pk_state > 0;
+    if (P.pk_state != 0) return P.pk_state == (runs_only ? 2 : 1);
     P.pk_state = -1;
     static const int env = [] { const char *e = std::getenv("LCG_HIP_PACKED"); return e ? atoi(e) : -1; }();
     const int mode = env >= 0 ? env : P.pk_mode;
     if (mode == 0) return false;
-    if (mode < 0 && P.nnz < (1 << 22)) return false;       // small systems are launch-bound: not worth the memory
+    if (!runs_only && mode < 0 && P.nnz < (1 << 22)) return false;       // small systems are launch-bound: not worth the memory
     const int n = P.n_rows;
     const int nb = (n + PK_R - 1) / PK_R;
     int *ngr = nullptr, *span = nullptr;
@@ -570,17 +675,19 @@ static bool packed_ready(const CsrPart &P, hipStream_t s)
         hipLaunchKernelGGL(k_pk_meta, dim3(nb), dim3(64), 0, s, n, P.rowptr, P.col, P.pk_base, ngr, span, runs);
         ok = hipMemcpyAsync(hspan, span, 3 * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     }
-    if (ok) ok = hspan[0] < PK_SPAN;
+    if (ok) ok = runs_only ? (runs && 2L * hspan[2] >= nb) : hspan[0] < PK_SPAN;     // runs only: worth it when most blocks are runs
     static const int force_bits = [] { const char *e = std::getenv("LCG_HIP_PACKED_BITS"); return e ? atoi(e) : 0; }();   // 21: A/B runs
-    const int bits = (hspan[0] < (1 << 18) && force_bits != 21) ? 18 : 21;     // seven 18-bit columns per group where the blocks are narrow enough
+    const int bits = runs_only ? 0 : ((hspan[0] < (1 << 18) && force_bits != 21) ? 18 : 21);     // seven 18-bit columns per group where the blocks are narrow enough
     if (ok) {
-        hipLaunchKernelGGL(k_pk_groups, dim3((nb + VB - 1) / VB), dim3(VB), 0, s, nb, 128 / bits, ngr);
+        hipLaunchKernelGGL(k_pk_groups, dim3((nb + VB - 1) / VB), dim3(VB), 0, s, nb, runs_only ? 0 : 128 / bits, ngr);
         ok = device_exclusive_scan(nb, ngr, P.pk_ofs, s, &total) == 0;
     }
     if (ok) ok = total > 0 && total < 0x7fffffffL;
     if (ok) ok = hipMalloc(&P.pk_data, 16 * ((size_t)total + 4)) == hipSuccess;
     if (ok) {
-        if (bits == 18)
+        if (runs_only)
+            hipLaunchKernelGGL(k_pk_pack<0>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data));
+        else if (bits == 18)
             hipLaunchKernelGGL(k_pk_pack<18>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data));
         else
             hipLaunchKernelGGL(k_pk_pack<21>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data));
@@ -600,9 +707,10 @@ static bool packed_ready(const CsrPart &P, hipStream_t s)
     P.pk_runs = hspan[2];
     P.pk_groups = total;
     P.pk_bits = bits;
-    P.pk_state = 1;
+    P.pk_state = runs_only ? 2 : 1;
     return true;
 }
+static bool packed_ready(const CsrPart &P, hipStream_t s) { return packed_build(P, s, false); }
 
 // ---- scattered columns: which matrices take the two-pass binned product (csr_binned.hip) -----------------
 // mean column span (largest - smallest column) of the blocks of 64 rows
@@ -766,6 +874,24 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
         int R = 0; bool onewin = false;
         { int rc = lds_shape<V>(P, variant, mean_row, s, &R, &onewin); if (rc) return rc; }
         if constexpr (sizeof(V) == 8 && !ACC) {
+            if constexpr (!PUSH) {
+                // short rows whose blocks of 64 are mostly runs: one wavefront per block, no staging (k_spmv_run1)
+                static const bool run1_off = [] { const char *e = std::getenv("LCG_HIP_RUN1"); return e && atoi(e) == 0; }();
+                if (!run1_off && variant == -1 && (R == 256 || R == 128) && packed_build(P, s, true) && P.pk_maxrow <= 32) {
+                    const unsigned g = (unsigned)(((n + 63) / 64 + VB / 64 - 1) / (VB / 64));
+                    const int LP = P.pk_maxrow | 1;
+                    const size_t lds = sizeof(double) * (VB / 64) * 64 * (size_t)LP;
+                    if (R == 256)
+                        hipLaunchKernelGGL((k_spmv_run1<1>), dim3(g), dim3(VB), lds, s, n, LP, P.rowptr, P.col, reinterpret_cast<const double *>(val), P.pk_ofs, P.pk_base,
+                                           static_cast<const int *>(P.pk_data), reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done);
+                    else
+                        hipLaunchKernelGGL((k_spmv_run1<2>), dim3(g), dim3(VB), lds, s, n, LP, P.rowptr, P.col, reinterpret_cast<const double *>(val), P.pk_ofs, P.pk_base,
+                                           static_cast<const int *>(P.pk_data), reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done);
+                    HIPCHK(hipGetLastError());
+                    P.last_kernel = "k_spmv_run1 (one wavefront per 64-row block, run blocks without staging)";
+                    return 0;
+                }
+            }
             if (R == PK_R && onewin && packed_ready(P, s)) {
                 // gathers per lane in the first batch: enough for the longest row when that is 9..12 per lane
                 const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);

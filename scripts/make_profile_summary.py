@@ -66,11 +66,13 @@ def main():
                        "corrected x2; for the row-block kernels' 8-byte x gathers the doubled figure is an upper bound",
                "variants": {}}
     sizes = {}      # pattern -> (rows, nnz) of the matrices the counters were collected on
+    described = {}  # pattern -> the library's own description of the kernel that ran (lcg_hip_csr_last_kernel)
     for f in glob.glob(os.path.join(src, "pmc_FETCH_SIZE.jsonl")):
         for line in open(f):
             try:
                 e = json.loads(line)
                 sizes[e["pattern"]] = (e["rows"], e["nnz"])
+                described[e["pattern"]] = e.get("kernel", "")
             except (ValueError, KeyError):
                 pass
     for pattern, fams in FAMILY.items():
@@ -84,6 +86,7 @@ def main():
                "collected": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on scripts/ax_variants.py, {summary['collected']}"}
         if pattern in sizes:
             ent["rows"], ent["nnz"] = sizes[pattern]
+            ent["kernel_description"] = described.get(pattern, "")
         hit = sum((mean(k, "TCC_HIT_sum") or 0.0) for k in ks); miss = sum((mean(k, "TCC_MISS_sum") or 0.0) for k in ks)
         if hit + miss > 0:
             ent["l2_hit_rate"] = hit / (hit + miss)

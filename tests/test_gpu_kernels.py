@@ -143,6 +143,62 @@ def test_run_blocks_of_the_packed_form(api, port):
     assert lib.lcg_hip_csr_packed_runs(B2.h, None) == 0 and "run blocks" not in lib.lcg_hip_csr_last_kernel(B2.h).decode()
 
 
+def test_short_row_runs_one_wavefront_per_block(api, port):
+    """k_spmv_run1 (short rows whose 64-row blocks are mostly runs -- stencils): against the LDS-staged kernel the automatic
+    choice would otherwise take (packed copy switched off), bit for bit.  L = 1 .. 17 covers one and two partial sums per row
+    (T = 1 up to 8.5 entries per row, T = 2 up to 17) and more than one batch of 8; sizes leave partial last blocks; every
+    third system has blocks that are not runs (a shortened row per 1000 rows, like the Laplacian's grid-row boundaries), which
+    the kernel walks from the CSR arrays; a system whose blocks are mostly not runs must stay with the staged kernel."""
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(123)
+    case = 0
+    for L in (1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17):
+        for n in (64, 1000, 6400 + 13, 50000):
+            case += 1
+            ncols = n + 3000
+            offs = np.sort(rng.choice(3000, L, replace=False)).astype(np.int64)
+            lens = np.full(n, L)
+            if case % 3 == 0 and L > 1 and n >= 1000:
+                lens[::1000] = L - 1                      # rows that break their block's run
+            rp = np.zeros(n + 1, np.int32); np.cumsum(lens, out=rp[1:])
+            col = np.concatenate([(i + offs[:lens[i]]) for i in range(n)]).astype(np.int32) if n <= 6500 else None
+            if col is None:
+                full = (np.arange(n)[:, None] + offs[None, :])
+                mask = np.arange(L)[None, :] < lens[:, None]
+                col = full[mask].astype(np.int32)
+            val = rng.standard_normal(rp[-1]); x = rng.standard_normal(ncols)
+            A = api.CsrMatrix.from_csr(rp, col, val, n_cols=ncols)
+            xd = torch.from_numpy(x).cuda()
+            y0 = torch.empty(n, dtype=torch.float64, device="cuda"); y1 = torch.full_like(y0, 5.0)
+            assert lib.lcg_hip_csr_set_packed(A.h, 0) == 0
+            A.spmv(xd, y0); api.synchronize()
+            assert "k_spmv_lds1" in lib.lcg_hip_csr_last_kernel(A.h).decode()
+            assert lib.lcg_hip_csr_set_packed(A.h, -1) == 0
+            A.spmv(xd, y1); api.synchronize()
+            assert "k_spmv_run1" in lib.lcg_hip_csr_last_kernel(A.h).decode(), (L, n, lib.lcg_hip_csr_last_kernel(A.h))
+            assert torch.equal(y0, y1), (L, n)
+            ref = port.csr_matvec(rp, col, val, x)
+            assert np.abs(y1.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+            A.destroy()
+    # the Laplacian of configs[1] at a tenth of the size: mostly runs; a ragged matrix of the same density: none -> staged kernel
+    A = api.CsrMatrix.laplace2d(400, 250); n = 100000
+    xd = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 3, 0, n, xd)
+    y0 = torch.empty_like(xd); y1 = torch.empty_like(xd)
+    assert lib.lcg_hip_csr_set_packed(A.h, 0) == 0
+    A.spmv(xd, y0)
+    assert lib.lcg_hip_csr_set_packed(A.h, -1) == 0
+    A.spmv(xd, y1); api.synchronize()
+    nblk = C.c_int64()
+    runs = lib.lcg_hip_csr_packed_runs(A.h, C.byref(nblk))
+    assert "k_spmv_run1" in lib.lcg_hip_csr_last_kernel(A.h).decode() and 0.6 * nblk.value < runs < nblk.value and torch.equal(y0, y1)
+    rp, col = _ragged(rng, 20000, 20000, 9)
+    B = api.CsrMatrix.from_csr(rp, col, rng.standard_normal(rp[-1]))
+    xb = torch.from_numpy(rng.standard_normal(20000)).cuda(); yb = torch.empty_like(xb)
+    B.spmv(xb, yb); api.synchronize()
+    assert "k_spmv_lds1" in lib.lcg_hip_csr_last_kernel(B.h).decode() and lib.lcg_hip_csr_packed_runs(B.h, None) == 0
+
+
 @pytest.mark.parametrize("cplx", [False, True])
 def test_spmv_transpose_and_conjugate(api, port, cplx):
     """op(A).x for the (layout, conjugate) pairs of clcg_axfunc_ptr (clcg.h:40-41): A^T, A^H, conj(A)."""
