@@ -196,11 +196,10 @@ __global__ __launch_bounds__(VB) void k_spmv_lds1d(int n, const int *__restrict_
     if (done && *done) return;
     const int rl = threadIdx.x % R, j0 = threadIdx.x / R;
     const long row = (long)blockIdx.x * R + rl;
-    const double uv = (dp.dbg & 1) ? 1.0 : dp.u[(j0 == 0 && row < n) ? row : 0];
+    const double uv = dp.u[(j0 == 0 && row < n) ? row : 0];
     bool mine;
     const double v = lds1_block<double, R, false>(blockIdx.x, n, rowptr, col, val, x, y, sval, scol, mine);
     double a0 = mine ? v * uv : 0.0, a1 = mine ? v * v : 0.0;
-    if (dp.dbg & 2) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     constexpr int NW = R >= 64 ? R / 64 : 1;        // wavefronts that hold finished rows
     if (w < NW) {
@@ -385,12 +384,28 @@ __global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const 
 // NS > 8: the FIRST batch is predicated (slots past the row's end read entry 0 with a zero
 // coefficient), so rows of up to NS*T entries -- 33 entries on 4 lanes are 9 for one lane, 8 for the
 // others -- are done in one round without a serial tail (0.706 vs 0.722 ms on the headline system).
-template <bool PUSH, int NS, int BITS>
+// end of a block of k_spmv_ldsp<DOT>: the first wavefront holds the finished rows (vfin) and their u; one sum per block
+__device__ __forceinline__ void ldsp_dot_tail(const DotPlan &dp, int bid, int j0, double vfin, double uv)
+{
+    if (j0 != 0) return;                // uniform per wavefront (64 rows per block: wavefront 0 is slot 0)
+    const double a0 = wave_sum(vfin * uv);
+    if ((threadIdx.x & 63) == WSUM_LANE) dp.part[bid] = a0;
+    if (dp.yy) {                        // uniform
+        const double a1 = wave_sum(vfin * vfin);
+        if ((threadIdx.x & 63) == WSUM_LANE) dp.part[dp.stride + bid] = a1;
+    }
+}
+
+// DOT: the block also leaves its rows' share of y.u (and y.y) in dp.part[block] (dp.part[dp.stride + block]): the dot the
+// Krylov loops take right after the product, without a pass of its own over two 80 MB vectors (see k_spmv_lds1d; here one
+// partial per block of 64 rows, folded to <= 512 by k_axp_fold before the scalar step adds them up).
+template <bool PUSH, int NS, int BITS, bool DOT = false>
 __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__ rowptr, const v4i *__restrict__ packed,
                                                   const int *__restrict__ pofs, const int *__restrict__ pbase,
                                                   const double *__restrict__ val, const double *__restrict__ x,
-                                                  double *__restrict__ y, const int *done, PushPlan pp)
+                                                  double *__restrict__ y, const int *done, PushPlan pp, DotPlan dp)
 {
+    static_assert(!(PUSH && DOT), "the sharded product keeps its dots in their own pass");
     if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
     const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
     constexpr int R = PK_R;
@@ -414,6 +429,8 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     const int cnt = e - s, ng = (cnt + PER - 1) / PER;
     const int po = pofs[bid], bs = pbase[bid];
     const int bv = s & ~1, cntv = e - bv;
+    double uv = 0.0;
+    if (DOT) uv = dp.u[(j0 == 0 && rl < nrows) ? row0 + rl : 0];     // requested ahead of the stream: hidden behind it
 
     if (bs < 0) {
         // RUN block (k_pk_meta): every row holds L entries and column(row r, slot k) = column(row 0, slot k) + r.  Nothing but
@@ -459,12 +476,15 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
         __syncthreads();
         sred[j0][rl] = acc;
         __syncthreads();
+        double vfin = 0.0;
         if (j0 == 0 && live) {
             double v = sred[0][rl];
 #pragma unroll
             for (int j = 1; j < T; j++) v += sred[j][rl];
             y[row0 + rl] = v;
+            vfin = v;
         }
+        if (DOT) ldsp_dot_tail(dp, bid, j0, vfin, uv);
         return;
     }
 
@@ -540,11 +560,47 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     __syncthreads();
     sred[j0][rl] = acc;
     __syncthreads();
+    double vfin = 0.0;
     if (j0 == 0 && rl < nrows) {
         double v = sred[0][rl];
 #pragma unroll
         for (int j = 1; j < T; j++) v += sred[j][rl];
         y[row0 + rl] = v;
+        vfin = v;
+    }
+    if (DOT) ldsp_dot_tail(dp, bid, j0, vfin, uv);
+}
+
+// The <= 512-way second stage of a product's per-block sums: block i adds the slice [i * per, (i + 1) * per) of `big` in a
+// fixed order and leaves it in out[i] (the y.y sums, `stride` further on, in out[AXP_CAP + i]).
+__global__ __launch_bounds__(VB) void k_axp_fold(const double *__restrict__ big, int nblk, int stride, int per, int yy, double *__restrict__ out,
+                                                 const int *done)
+{
+    __shared__ double sh[2][VB / 64];
+    if (done && *done) return;
+    const int lo = blockIdx.x * per, hi = min(nblk, lo + per);
+    double a0 = 0.0, a1 = 0.0;
+    for (int j0 = lo; j0 < hi; j0 += 4 * VB) {
+        double t[4], w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int j = j0 + threadIdx.x + q * VB;
+            t[q] = big[j < hi ? j : lo];
+            w[q] = yy ? big[stride + (j < hi ? j : lo)] : 0.0;
+            if (j >= hi) { t[q] = 0.0; w[q] = 0.0; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { a0 += t[q]; a1 += w[q]; }
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == WSUM_LANE) { sh[0][wv] = a0; sh[1][wv] = a1; }
+    __syncthreads();
+    if (threadIdx.x < 2 && (threadIdx.x == 0 || yy)) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < VB / 64; q++) t += sh[threadIdx.x][q];
+        out[threadIdx.x * AXP_CAP + blockIdx.x] = t;
     }
 }
 
@@ -899,7 +955,7 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
 #define PK_LAUNCH(NSS, BB)                                                                                          \
         hipLaunchKernelGGL((k_spmv_ldsp<PUSH, NSS, BB>), dim3((n + PK_R - 1) / PK_R + xb), dim3(VB), 0, s, n, P.rowptr, \
                            static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, reinterpret_cast<const double *>(val), \
-                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, pp)
+                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, pp, DotPlan())
 #define PK_CASE(NSS)                                                                                                \
     case NSS:                                                                                                       \
         if (P.pk_bits == 18) PK_LAUNCH(NSS, 18); else PK_LAUNCH(NSS, 21);                                          \
@@ -983,7 +1039,36 @@ int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int 
     int R = 0; bool onewin = false;
     { int rc = lds_shape<double>(P, -1, A->mean_row, s, &R, &onewin); if (rc) return rc; }
     if (!onewin) return 0;
-    if (R == PK_R && packed_ready(P, s)) return 0;
+    if (R == PK_R && packed_ready(P, s)) {
+        // the packed kernel (large matrices): one partial per block of 64 rows into a buffer of the matrix's own, folded to
+        // <= 512 sums by a second small kernel -- together they replace a pass over two vectors of the matrix's height
+        static const bool big_off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_PACKED"); return e && atoi(e) == 0; }();
+        if (big_off) return 0;
+        const int nblk = (n + PK_R - 1) / PK_R;
+        if (!P.dot_part && hipMalloc(&P.dot_part, sizeof(double) * 2 * (size_t)nblk) != hipSuccess) { (void)hipGetLastError(); P.dot_part = nullptr; return 0; }
+        DotPlan dp; dp.u = u; dp.part = P.dot_part; dp.yy = yy; dp.stride = nblk;
+        const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);
+        const int ns = per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
+#define PKD_LAUNCH(NSS, BB)                                                                                         \
+        hipLaunchKernelGGL((k_spmv_ldsp<false, NSS, BB, true>), dim3(nblk), dim3(VB), 0, s, n, P.rowptr,            \
+                           static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, P.val, x, y, done, PushPlan(), dp)
+#define PKD_CASE(NSS)                                                                                               \
+    case NSS:                                                                                                       \
+        if (P.pk_bits == 18) PKD_LAUNCH(NSS, 18); else PKD_LAUNCH(NSS, 21);                                        \
+        break;
+        switch (ns) { PKD_CASE(8) PKD_CASE(9) PKD_CASE(10) PKD_CASE(12) }
+#undef PKD_LAUNCH
+#undef PKD_CASE
+        HIPCHK(hipGetLastError());
+        const int g2 = std::min(512, (nblk + VB - 1) / VB);
+        const int per = (nblk + g2 - 1) / g2;
+        hipLaunchKernelGGL(k_axp_fold, dim3((nblk + per - 1) / per), dim3(VB), 0, s, P.dot_part, nblk, nblk, per, yy, part, done);
+        HIPCHK(hipGetLastError());
+        P.last_kernel = P.pk_runs > 0 ? "k_spmv_ldsp (LDS-staged, run blocks + packed columns) carrying the dot that follows the product"
+                                      : "k_spmv_ldsp (LDS-staged, packed columns) carrying the dot that follows the product";
+        *slots = (nblk + per - 1) / per;
+        return 1;
+    }
     const int nblk = (n + R - 1) / R;
     // Where it pays (measured, scripts/ax_dot_lab.py + scripts/ab_small.py): systems whose iteration is a chain of kernel
     // latencies -- the product grows by ~0.6 us, a ~3 us pass and its launch go.  At 1M rows (3907 row blocks) the product grew by
@@ -992,8 +1077,6 @@ int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int 
     static const int maxblk = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_MAXBLK"); const int v = e ? atoi(e) : 2048; return v < 1 ? 1 : (v > AXP_CAP ? AXP_CAP : v); }();
     if (nblk > maxblk) return 0;
     DotPlan dp; dp.u = u; dp.part = part; dp.yy = yy;
-    static const int dbg = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_DBG"); return e ? atoi(e) : 0; }();
-    dp.dbg = dbg;
     const int g = nblk;
 #define LDSD_CASE(RR) case RR: hipLaunchKernelGGL((k_spmv_lds1d<RR>), dim3(g), dim3(VB), 0, s, n, P.rowptr, P.col, P.val, x, y, done, dp); break;
     switch (R) {
@@ -1397,6 +1480,7 @@ void free_part(CsrPart &P)
     if (P.pk_base) hipFree(P.pk_base);
     if (P.pk_ofs) hipFree(P.pk_ofs);
     if (P.pk_data) hipFree(P.pk_data);
+    if (P.dot_part) hipFree(P.dot_part);
     P = CsrPart();
 }
 

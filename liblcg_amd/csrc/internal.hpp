@@ -72,7 +72,7 @@ struct DotPlan {
     const double *u = nullptr;
     double *part = nullptr;
     int yy = 0;
-    int dbg = 0;        // lab switches (LCG_HIP_AX_DOT_DBG): 1 no u load, 2 no reduction / store
+    int stride = AXP_CAP;   // distance of the y.y sums from the y.u sums in `part`
 };
 
 // Mirror of the stop state in host-mapped pinned memory; written by the scalar kernels,
@@ -175,6 +175,7 @@ struct CsrPart {
     mutable int pk_bits = 21;                               // width of a packed column: 18 (seven per group) or 21 (six)
     mutable int pk_runs = 0;                                // blocks stored as runs (row 0's columns only; csr.hip: k_pk_meta)
     mutable long pk_groups = 0;                             // 16-byte groups of the packed columns
+    mutable double *dot_part = nullptr;                     // [2][blocks of 64 rows]: per-block sums of a product that carries its dot (k_spmv_ldsp<DOT>)
     // two-pass "binned" product for scattered columns (csr_binned.hip), plan built on first use
     int64_t n_cols = 0;            // columns the part addresses (0 = unknown: never binned)
     mutable int bn_mode = -1;      // -1 auto (large real matrices whose row blocks span more of x than the L2 holds), 0 never, 1 whenever eligible

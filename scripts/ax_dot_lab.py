@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import torch
 from liblcg_amd import _lib, api
 lib = _lib.load()
-reps = int(os.environ.get("REPS", "200"))
+reps = int(os.environ.get("REPS", "100"))
 
 def run(name, A, n):
     x = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 1, 0, n, x)
@@ -28,3 +28,4 @@ A = api.CsrMatrix.laplace2d(1000, 1000); run("laplace 1000^2", A, 1000000); A.de
 A = api.CsrMatrix.laplace2d(300, 300); run("laplace 300^2", A, 90000); A.destroy()
 A = api.CsrMatrix.generate(200000, 16, 3000, True, 1, 0.01); run("diagonals 200K", A, 200000); A.destroy()
 A = api.CsrMatrix.generate(1000000, 16, 30000, True, 1, 0.01); run("diagonals 1M", A, 1000000); A.destroy()
+A = api.CsrMatrix.generate(10000000, 16, 131072, True, 1, 0.01); run("diagonals 10M (the headline)", A, 10000000); A.destroy()

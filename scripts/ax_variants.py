@@ -23,12 +23,23 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--patterns", default="1,2,0")
 ap.add_argument("--modes", default="plain,binned")
 ap.add_argument("--symmetric", type=int, default=1)
+ap.add_argument("--dot", type=int, default=0, help="1: the product the solver loops run -- lcg_hip_spmv_dot, y.x carried where the kernel family can")
 args = ap.parse_args()
 lib = _lib.load()
 NAMES = {0: "scrambled", 1: "constant_diagonals", 2: "row_random_band"}
 n = args.rows
 x = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 1, 0, n, x)
 y = torch.empty_like(x); yref = torch.empty_like(x)
+_res = (_lib.C.c_double * 2)()
+
+
+def product(A, x, y):
+    if args.dot:
+        assert lib.lcg_hip_spmv_dot(A.h, x.data_ptr(), y.data_ptr(), x.data_ptr(), None) == 0
+    else:
+        A.spmv(x, y)
+
+
 for pat in [int(p) for p in args.patterns.split(",")]:
     A = api.CsrMatrix.generate(n, 16, args.band if pat else 0, bool(args.symmetric), 1, 0.01, pattern=pat)
     nnz = A.nnz
@@ -40,13 +51,13 @@ for pat in [int(p) for p in args.patterns.split(",")]:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         api.use_torch_stream()
         t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-        t0.record(); A.spmv(x, y); t1.record(); torch.cuda.synchronize()      # includes building packed columns / the plan
+        t0.record(); product(A, x, y); t1.record(); torch.cuda.synchronize()      # includes building packed columns / the plan
         first_ms = t0.elapsed_time(t1)
         for _ in range(3):
-            A.spmv(x, y)
+            product(A, x, y)
         e0.record()
         for _ in range(args.reps):
-            A.spmv(x, y)
+            product(A, x, y)
         e1.record(); torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / args.reps
         if mode == "plain":

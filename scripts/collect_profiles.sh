@@ -24,11 +24,12 @@ echo "bench kernel trace done"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_configs" -o prof -- \
     python3 "$REPO/scripts/bench_configs.py" c1 c2 c5 > "$OUT/configs_traced.jsonl" 2> "$OUT/trace_configs.err"
 echo "configs kernel trace done"
-# 4. counters, one pass each, on the A.x of every pattern (automatic kernel choice)
+# 4. counters, one pass each, on the A.x of every pattern (automatic kernel choice; --dot 1 = the product as the solver
+#    loops run it, with the dot that follows it carried where the kernel family can)
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
     name=${c// /_}
     timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$name" -o pmc -- \
-        python3 "$REPO/scripts/ax_variants.py" --modes auto --reps 5 > "$OUT/pmc_$name.jsonl" 2> "$OUT/pmc_$name.err"
+        python3 "$REPO/scripts/ax_variants.py" --modes auto --reps 5 --dot 1 > "$OUT/pmc_$name.jsonl" 2> "$OUT/pmc_$name.err"
     echo "pmc $c done"
 done
 # 5. counters on the headline CG iteration (BLAS-1 kernels: the calibration of FETCH_SIZE on known byte counts)

@@ -274,6 +274,22 @@ def test_product_carrying_its_dot(api, port):
         assert lib.lcg_hip_spmv_dot(A.h, xd.data_ptr(), y1.data_ptr(), ud.data_ptr(), res) == 0
         assert (res[0], res[1]) == first
         A.destroy()
+    # the packed kernel of the large matrices (run blocks and blocks with their own columns) carries the dot too: one partial
+    # per block of 64 rows, folded by k_axp_fold; symmetric (runs in the interior) and row-random (no runs) columns
+    for pattern, n in ((api.GEN_DIAGONALS, 300000), (api.GEN_ROW_RANDOM_BAND, 200000)):
+        A = api.CsrMatrix.generate(n, 16, 3000, True, 9, 0.01, pattern=pattern)
+        assert lib.lcg_hip_csr_set_tiled(A.h, 0) == 0 and lib.lcg_hip_csr_set_packed(A.h, 1) == 0
+        xd = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 3, 0, n, xd)
+        ud = torch.empty_like(xd); api.gen_xtrue(n, 4, 0, n, ud)
+        y0 = torch.empty_like(xd); y1 = torch.full_like(xd, 2.0)
+        A.spmv(xd, y0); api.synchronize()
+        assert "k_spmv_ldsp" in lib.lcg_hip_csr_last_kernel(A.h).decode()
+        assert lib.lcg_hip_spmv_dot(A.h, xd.data_ptr(), y1.data_ptr(), ud.data_ptr(), res) == 0
+        assert "carrying the dot" in lib.lcg_hip_csr_last_kernel(A.h).decode() and torch.equal(y0, y1)
+        assert abs(res[0] - float(y0 @ ud)) <= 1e-12 * float(y0.abs() @ ud.abs()) and abs(res[1] - float(y0 @ y0)) <= 1e-12 * float(y0 @ y0)
+        first = (res[0], res[1])
+        assert lib.lcg_hip_spmv_dot(A.h, xd.data_ptr(), y1.data_ptr(), ud.data_ptr(), res) == 0 and (res[0], res[1]) == first
+        A.destroy()
     # more row blocks than the threshold: two launches, same answers
     A = api.CsrMatrix.laplace2d(800, 800); n = 640000
     xd = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 3, 0, n, xd)
