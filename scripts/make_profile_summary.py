@@ -45,10 +45,14 @@ def main():
             shutil.copy(f, os.path.join(out, name))
             if d == "trace_bench":
                 stats = {r["Name"]: r for r in csv.DictReader(open(f))}
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))        # every pass (the per-kernel table, the calibration)
+    aggv = collections.defaultdict(lambda: collections.defaultdict(list))       # the passes on scripts/ax_variants.py only: the per-pattern traffic
     for f in glob.glob(os.path.join(src, "pmc*", "**", "*_counter_collection.csv"), recursive=True):
+        on_variants = os.path.relpath(f, src).startswith("pmc_")
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if on_variants:
+                aggv[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     with open(os.path.join(out, f"{tag}_pmc_per_kernel.csv"), "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(["kernel", "counter", "mean_per_dispatch", "dispatches"])
@@ -57,8 +61,8 @@ def main():
                 v = agg[k][c]
                 w.writerow([k, c, sum(v) / len(v), len(v)])
 
-    def mean(k, c):
-        v = agg[k].get(c)
+    def mean(k, c, table=None):
+        v = (agg if table is None else table)[k].get(c)
         return sum(v) / len(v) if v else None
     summary = {"tag": tag, "collected": datetime.date.today().isoformat(),
                "note": "FETCH_SIZE / WRITE_SIZE are KB per dispatch; on gfx950 FETCH_SIZE counts 1/2 of wide (16 B/lane) coalesced reads "
@@ -76,21 +80,22 @@ def main():
             except (ValueError, KeyError):
                 pass
     for pattern, fams in FAMILY.items():
-        ks = [k for k in agg if any(f in k for f in fams) and "FETCH_SIZE" in agg[k]]
+        ks = [k for k in aggv if any(f in k for f in fams) and "FETCH_SIZE" in aggv[k]]
         if not ks:
             continue
-        fetch = sum(mean(k, "FETCH_SIZE") for k in ks) * 1024
-        write = sum((mean(k, "WRITE_SIZE") or 0.0) for k in ks) * 1024
+        mean_v = lambda k, c: mean(k, c, aggv)
+        fetch = sum(mean_v(k, "FETCH_SIZE") for k in ks) * 1024
+        write = sum((mean_v(k, "WRITE_SIZE") or 0.0) for k in ks) * 1024
         ent = {"kernel": " + ".join(k.split("(")[0].replace("void ", "") for k in ks), "fetch_size_raw_bytes": fetch, "write_size_bytes": write,
                "hbm_bytes_per_launch": 2 * fetch + write,
                "collected": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on scripts/ax_variants.py, {summary['collected']}"}
         if pattern in sizes:
             ent["rows"], ent["nnz"] = sizes[pattern]
             ent["kernel_description"] = described.get(pattern, "")
-        hit = sum((mean(k, "TCC_HIT_sum") or 0.0) for k in ks); miss = sum((mean(k, "TCC_MISS_sum") or 0.0) for k in ks)
+        hit = sum((mean_v(k, "TCC_HIT_sum") or 0.0) for k in ks); miss = sum((mean_v(k, "TCC_MISS_sum") or 0.0) for k in ks)
         if hit + miss > 0:
             ent["l2_hit_rate"] = hit / (hit + miss)
-        req = sum((mean(k, "TCC_EA0_RDREQ_sum") or 0.0) for k in ks)
+        req = sum((mean_v(k, "TCC_EA0_RDREQ_sum") or 0.0) for k in ks)
         if req:
             ent["l2_fabric_read_requests"] = req
         for name, r in stats.items():
