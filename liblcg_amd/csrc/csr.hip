@@ -2,7 +2,7 @@
 // on-device generators of the benchmark systems.
 //
 // A.x is the kernel the whole path is judged on: >= 80 % of the bytes of a CG iteration.
-// It is HBM-bound (0.17 flop/byte): no MFMA.  Two kernels:
+// It is HBM-bound (0.17 flop/byte): no MFMA.  The row-block kernels of this file:
 //
 //  k_spmv_lds1<R>   (default)  One 256-thread block owns R consecutive rows (R*T = 256).
 //      Stage 1: the block's contiguous slice of val/col streams from HBM into LDS with
@@ -12,8 +12,14 @@
 //      consecutive ROWS, so for matrices with diagonal / stencil structure the x gather of a
 //      wavefront is one contiguous run, and for arbitrary columns it is no worse than any
 //      other mapping.  The T partial sums of a row meet in LDS; y is written coalesced.
+//  k_spmv_ldsp      the same mapping for large real matrices with packed block-relative columns (18 / 21 bits) and, where a
+//      64-row block's columns advance by one per row, RUN blocks: row 0's columns only, x gathers sent out with the value
+//      stream (the headline's kernel: DESIGN.md section 3.1a).  <DOT>: carries the dot that follows the product.
+//  k_spmv_run1      short rows (stencils) whose blocks are runs: one wavefront per 64-row block, no barrier.
+//  k_spmv_lds1d     small systems: the plain body + the dot that follows the product (two launches per CG iteration).
 //  k_spmv_wave<T>   T consecutive lanes share a row (T = 64: wavefront per row), partial
 //      sums folded with __shfl_down.  Better for long rows (> ~100 entries).
+// (csr_tiled.hip, csr_binned.hip: the products for columns that do not run along diagonals.)
 //
 // Algorithmic bytes: 12*nnz + 4*(N+1) + 8*N (x) + 8*N (y), real.
 #include <algorithm>
