@@ -270,6 +270,9 @@ def main():
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": source, "bytes_per_launch": shard_bytes, "avg_launch_us": ax_us,
                            "launches": ax_calls}
+        if "k_spmv_ldsp" in kernel and "carrying the dot" in kernel:
+            out["roofline"]["launch_note"] = ("avg_launch_us spans the product kernel AND k_axp_fold, the ~4 us second stage of the d.Ad sums it "
+                                              "carries (rocprofv3 lists the two separately: profiles/*_kernel_stats.csv)")
     if comm_probe is not None:
         out["comm_probe"] = comm_probe
 
