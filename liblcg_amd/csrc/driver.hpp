@@ -35,6 +35,20 @@ struct Driver {
 
     // ---- launches ------------------------------------------------------------------------
     template <class Op> int vec(Op op, uintptr_t align_or = 0) { return vec_n(op, n, align_or); }
+    // a reducing pass whose sums land in table rows row0, row0 + 1, ... beside the rows an earlier pass of the same body left
+    // there (same grid: the per-row counts stay as they are)
+    template <class Op> int vec_rows(Op op, int row0, uintptr_t align_or)
+    {
+        const PartCount keep = pcnt;
+        double *table = c.partials;
+        c.partials = table + (size_t)row0 * MAXG;
+        int rc = vec_n(op, n, align_or);
+        c.partials = table;
+        const int g = pcnt.g[0];
+        pcnt = keep;
+        for (int r = 0; r < Op::NR; r++) pcnt.g[row0 + r] = g;
+        return rc;
+    }
     // same pass over a vector of another length (e.g. the per-block partials of a fused A.x)
     template <class Op> int vec_n(Op op, long n, uintptr_t align_or)
     {

@@ -152,22 +152,9 @@ struct OpCgDir {    // d = b d - g                                         lcg.c
 // all-reduces per iteration once the rows are sharded.  Here A is applied to the GRADIENT,
 // w = A.g, and A.d is carried by the same recurrence as d (d = b d - g  =>  Ad = b Ad - w), so
 //     d.Ad = g.w - b g.g / a_prev        (g_new . A d_old = g.g / a_prev,  d_old.Ad_old = rho / a_prev)
-// and g.g, g.w, m.m, NaN ride in ONE reduction.  Per row: 9 words (update) + 2 (A.g) + 3 (dots).
-struct OpCg1Update {    // d = b d - g; Ad = b Ad - w; m += a d; g += a Ad      lcg.cpp:259-263, 237-243
-    static constexpr int NR = 0, SKIP = SKIP_DONE;
-    DevState *st; double *m, *g, *d, *Ad; const double *w; double ak, bk;
-    __device__ void prep() { ak = st->s[S_AK]; bk = st->s[S_BK]; }
-    template <class T> __device__ void apply(long i, double *)
-    {
-        const T gv = ld<T>(g, i);
-        const T dv = vsub(bk * ld<T>(d, i), gv);
-        const T sv = vsub(bk * ld<T>(Ad, i), ld<T>(w, i));
-        st_(d, i, dv); st_(Ad, i, sv);
-        st_(m, i, vadd(ld<T>(m, i), ak * dv));
-        st_(g, i, vadd(gv, ak * sv));
-    }
-};
-struct OpCg1UpdateSums { // the same update leaving m.m, g.g and the NaN count behind (rows 0, 1, 3; g.w comes with the product: row 2)
+// and g.g, g.w, m.m, NaN ride in ONE reduction.  Per row: 9 words (update, with m.m, g.g, NaN) + 2 (A.g) + 2 (g.w).
+struct OpCg1UpdateSums { // d = b d - g; Ad = b Ad - w; m += a d; g += a Ad (lcg.cpp:259-263, 237-243), leaving m.m, g.g and the NaN
+                         // count behind (lcg.cpp:244-255: sums 0, 1, 3); g.w -- sum 2 -- comes with the product or from the pass after it
     static constexpr int NR = 4, SKIP = SKIP_DONE;
     DevState *st; double *m, *g, *d, *Ad; const double *w; double ak, bk;
     __device__ void prep() { ak = st->s[S_AK]; bk = st->s[S_BK]; }
@@ -182,19 +169,6 @@ struct OpCg1UpdateSums { // the same update leaving m.m, g.g and the NaN count b
         st_(m, i, mv); st_(g, i, gv);
         acc[0] += dotp(mv, mv);
         acc[1] += dotp(gv, gv);
-        acc[3] += nanflag(mv);
-    }
-};
-struct OpCg1Dots {      // m.m, g.g, g.w, NaN                                   lcg.cpp:244-255, 234
-    static constexpr int NR = 4, SKIP = SKIP_DONE;
-    DevState *st; const double *m, *g, *w;
-    __device__ void prep() {}
-    template <class T> __device__ void apply(long i, double *acc)
-    {
-        const T mv = ld<T>(m, i), gv = ld<T>(g, i);
-        acc[0] += dotp(mv, mv);
-        acc[1] += dotp(gv, gv);
-        acc[2] += dotp(gv, ld<T>(w, i));
         acc[3] += nanflag(mv);
     }
 };
@@ -480,19 +454,21 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
             bool first = true;
             k.drv.tail = [&]() -> int { return first ? k.drv.scal(FinCg1Start{}) : k.drv.scal(FinCg1Close{}); };
             rc = k.run_loop([&]() -> int {
-                if (first) { TRY(k.drv.vecf(FinCg1Start{}, OpCg1Update{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w))); first = false; }
-                else TRY(k.drv.vecf(FinCg1Close{}, OpCg1Update{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
+                if (first) { TRY(k.drv.vecf(FinCg1Start{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w))); first = false; }
+                else TRY(k.drv.vecf(FinCg1Close{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
                 TRY(k.ax(g, w));
-                TRY(k.drv.vec(OpCg1Dots{st, m, g, w}, al(m) | al(g) | al(w)));
+                TRY(k.drv.vec_rows(OpDot1{st, g, w}, 2, al(g) | al(w)));
                 return 0;
             });
             k.drv.tail = nullptr;
         } else {
+            // sharded rows (and callbacks that are not the built-in product): m.m, g.g and the NaN count ride in the update pass,
+            // which has m and g in registers anyway; the pass after the product only takes g.w (two words per row instead of three)
             TRY(k.drv.scal(FinCg1Start{}));
             rc = k.run_loop([&]() -> int {
-                TRY(k.drv.vec(OpCg1Update{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
+                TRY(k.drv.vec(OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
                 TRY(k.ax(g, w));
-                TRY(k.drv.vec(OpCg1Dots{st, m, g, w}, al(m) | al(g) | al(w)));
+                TRY(k.drv.vec_rows(OpDot1{st, g, w}, 2, al(g) | al(w)));
                 TRY(k.drv.scal(FinCg1Close{}));
                 return 0;
             });
