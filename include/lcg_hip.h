@@ -254,6 +254,8 @@ int lcg_hip_spmv(lcg_hip_csr_t A, const double *x, double *y);                  
  * MatTranspose / Conjugate products the reference's callbacks are asked for (clcg.h:40-41,
  * clcg.cpp:187; cusparseSpMV with CUSPARSE_OPERATION_*TRANSPOSE in sample9.cu:97). */
 int lcg_hip_spmv_op(lcg_hip_csr_t A, const double *x, double *y, int layout, int conjugate);
+/* (On a sharded matrix: layout = 1 only -- every rank multiplies the transpose of its rows with its slice of x and
+ * ncclReduceScatter sums the contributions into the ranks' row blocks; conj(A).x alone returns LCG_HIP_E_RUNTIME.) */
 /* y = A.x together with the sums the Krylov loops take right after it (lcg.cpp:234 d.Ad, :548-552 Ap.r0, :735-740 As.s and
  * As.As): result2[0] = y.u, result2[1] = y.y (host, after a stream synchronise; NULL = enqueue only).  Where the kernel family
  * allows, the sums ride in the product's epilogue (what the built-in solvers use on one GPU: lcg_hip_csr_last_kernel says

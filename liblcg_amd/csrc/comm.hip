@@ -36,6 +36,7 @@ struct Comm {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -73,6 +74,7 @@ static int load_rccl()
     SYM(CommDestroy, "ncclCommDestroy")
     SYM(AllReduce, "ncclAllReduce")
     SYM(AllGather, "ncclAllGather")
+    SYM(ReduceScatter, "ncclReduceScatter")
     SYM(Send, "ncclSend")
     SYM(Recv, "ncclRecv")
     SYM(GroupStart, "ncclGroupStart")
@@ -695,6 +697,10 @@ void dist_free(lcg_hip_csr *A)
     A->rem_rows = nullptr; A->rem_y = nullptr;
     if (A->xfull) hipFree(A->xfull);
     A->xfull = nullptr; A->distributed = false;
+    // transposes made for the sharded product have the padded global height: not the unsharded matrix's
+    for (int i = 1; i < 4; i++) free_part(A->op[i]);
+    if (A->op_z) hipFree(A->op_z);
+    A->op_z = nullptr;
 }
 
 // Split `main` (global columns) of a shard whose rows are [row0, row0+n_rows) into loc/rem.
@@ -703,6 +709,7 @@ void dist_free(lcg_hip_csr *A)
 int dist_split(lcg_hip_csr *A, int64_t n_global, int nranks, int rank)
 {
     Ctx &c = ctx();
+    for (int i = 1; i < 4; i++) free_part(A->op[i]);     // transposes of the unsharded matrix, if any: another shape from here on
     const int n = A->n_rows;
     const int64_t rpr = (n_global + nranks - 1) / nranks;
     const int64_t row0 = (int64_t)rank * rpr;
@@ -763,6 +770,37 @@ int dist_split(lcg_hip_csr *A, int64_t n_global, int nranks, int rank)
     HIPCHK(hipMemsetAsync(A->xfull, 0, sizeof(double) * (A->is_complex ? 2 : 1) * (size_t)(rpr * nranks), c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
     A->distributed = true;
+    return 0;
+}
+
+// y = this rank's rows of op(A).x for a transposed A (clbicg's A^H.d, clcg.cpp:187): every rank multiplies the transpose of
+// ITS rows with ITS slice of x -- a vector of the matrix's (padded) height -- and ncclReduceScatter(sum) hands each rank the
+// sum of everybody's contributions to its row block.  Strong-scaling cost: the whole height crosses the links once per product
+// (8 N bytes in total, like the all-gather of the north-star product).
+int dist_spmv_op(lcg_hip_csr *A, const CsrPart &T, const double *x, double *y)
+{
+    Ctx &c = ctx();
+    const size_t w = A->is_complex ? 2 : 1;
+    const int *done = c.in_solve ? &c.state->done : nullptr;
+    if (!g_comm.comm && world_size() > 1) {
+        c.err = "op(A).x on a sharded matrix sums the ranks' contributions with RCCL: no communicator (lcg_hip_comm_init)";
+        return LCG_HIP_E_COMM;
+    }
+    const size_t rpr = (size_t)A->rows_per_rank, nt = (size_t)T.n_rows;
+    if (!A->op_z) HIPCHK(hipMalloc(&A->op_z, sizeof(double) * w * (nt + rpr)));
+    double *z = A->op_z, *blk = A->op_z + w * nt;
+    const double mean = T.n_rows ? (double)T.nnz / T.n_rows : 0.0;
+    int rc = spmv_launch(T, A->is_complex, 0, mean, x, z, false, c.stream, done);
+    if (rc) return rc;
+    const bool whole = (size_t)A->n_rows == rpr;         // the last rank's block may be shorter than the reduce-scatter's
+    double *dst = whole ? y : blk;
+    if (g_comm.comm) {
+        ncclResult_t r = g_comm.ReduceScatter(z, dst, w * rpr, ncclDouble, ncclSum, g_comm.comm, c.stream);
+        if (r != ncclSuccess) return comm_fail("ncclReduceScatter", r);
+    } else {
+        HIPCHK(hipMemcpyAsync(dst, z + w * (size_t)A->row0, sizeof(double) * w * (size_t)A->n_rows, hipMemcpyDeviceToDevice, c.stream));
+    }
+    if (!whole) HIPCHK(hipMemcpyAsync(y, blk, sizeof(double) * w * (size_t)A->n_rows, hipMemcpyDeviceToDevice, c.stream));
     return 0;
 }
 

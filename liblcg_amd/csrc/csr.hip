@@ -1546,11 +1546,23 @@ int op_part(lcg_hip_csr *A, int layout, int conjugate, const CsrPart **out)
     if (idx == 0) { *out = &A->main; return 0; }
     CsrPart &T = A->op[idx];
     if (T.rowptr) { *out = &T; return 0; }
-    if (A->distributed || A->n_cols != A->n_rows) return fail(hipErrorInvalidValue, "op(A) needs a square, unsharded matrix", __FILE__, __LINE__);
+    // Sharded rows: this rank holds rows [row0, row0 + n) of A with GLOBAL columns.  Its share of op(A).x = A^T.x (A^H.x) is
+    // (A_r)^T . x_r -- a vector of the matrix's full height, to which every rank contributes and of which every rank keeps
+    // its own row block (comm.hip: dist_spmv_op, a reduce-scatter).  (A_r)^T is materialised like the unsharded transpose:
+    // rows = the global columns, padded to ranks x rows-per-rank so that the reduce-scatter's blocks are equal; columns =
+    // this rank's local rows.  conj(A) alone keeps the row split and is not offered on a sharded matrix.
+    if (A->distributed && !layout) return fail(hipErrorInvalidValue, "conj(A).x is not available on a sharded matrix (A^T and A^H are)", __FILE__, __LINE__);
+    if (!A->distributed && A->n_cols != A->n_rows) return fail(hipErrorInvalidValue, "op(A) needs a square matrix", __FILE__, __LINE__);
     Ctx &c = ctx();
-    const int n = A->n_rows;
+    const int n = A->n_rows;                                    // rows of the source part
+    long nt = n;                                                // rows of the transposed part
+    if (A->distributed) {
+        const long P = (A->n_global + A->rows_per_rank - 1) / A->rows_per_rank;
+        nt = P * A->rows_per_rank;
+        if (nt > 0x7fffffffL) return fail(hipErrorInvalidValue, "op(A): padded height exceeds int32", __FILE__, __LINE__);
+    }
     const long nnz = A->main.nnz;
-    int rc = alloc_part(T, n, nnz, A->is_complex);
+    int rc = alloc_part(T, (int)nt, nnz, A->is_complex);
     if (rc) return rc;
     T.n_cols = n;
     if (!layout) {      // conj(A): same structure
@@ -1560,22 +1572,22 @@ int op_part(lcg_hip_csr *A, int layout, int conjugate, const CsrPart **out)
                            reinterpret_cast<double2 *>(T.val));
     } else {
         int *cnt = nullptr;
-        HIPCHK(hipMalloc(&cnt, sizeof(int) * (size_t)n));
-        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)n, c.stream));
+        HIPCHK(hipMalloc(&cnt, sizeof(int) * (size_t)nt));
+        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)nt, c.stream));
         hipLaunchKernelGGL(k_tr_count, dim3(1024), dim3(VB), 0, c.stream, nnz, A->main.col, cnt);
         long total = 0;
-        rc = device_exclusive_scan(n, cnt, T.rowptr, c.stream, &total);
+        rc = device_exclusive_scan((int)nt, cnt, T.rowptr, c.stream, &total);
         if (rc || total != nnz) { hipFree(cnt); return rc ? rc : fail(hipErrorUnknown, "transpose count", __FILE__, __LINE__); }
-        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)n, c.stream));
-        const unsigned g = (unsigned)((n + VB - 1) / VB);
+        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)nt, c.stream));
+        const unsigned g = (unsigned)((n + VB - 1) / VB), gt = (unsigned)((nt + VB - 1) / VB);
         if (A->is_complex) {
             hipLaunchKernelGGL((k_tr_fill<double2>), dim3(g), dim3(VB), 0, c.stream, n, A->main.rowptr, A->main.col,
                                reinterpret_cast<const double2 *>(A->main.val), T.rowptr, cnt, T.col, reinterpret_cast<double2 *>(T.val), conjugate);
-            hipLaunchKernelGGL((k_row_sort<double2>), dim3(g), dim3(VB), 0, c.stream, n, T.rowptr, T.col, reinterpret_cast<double2 *>(T.val));
+            hipLaunchKernelGGL((k_row_sort<double2>), dim3(gt), dim3(VB), 0, c.stream, (int)nt, T.rowptr, T.col, reinterpret_cast<double2 *>(T.val));
         } else {
             hipLaunchKernelGGL((k_tr_fill<double>), dim3(g), dim3(VB), 0, c.stream, n, A->main.rowptr, A->main.col, A->main.val,
                                T.rowptr, cnt, T.col, T.val, 0);
-            hipLaunchKernelGGL((k_row_sort<double>), dim3(g), dim3(VB), 0, c.stream, n, T.rowptr, T.col, T.val);
+            hipLaunchKernelGGL((k_row_sort<double>), dim3(gt), dim3(VB), 0, c.stream, (int)nt, T.rowptr, T.col, T.val);
         }
         hipError_t e = hipStreamSynchronize(c.stream);
         hipFree(cnt);
@@ -1852,6 +1864,7 @@ int lcg_hip_spmv_op(lcg_hip_csr_t A, const double *x, double *y, int layout, int
     const CsrPart *P = nullptr;
     int rc = op_part(A, layout, conjugate, &P);
     if (rc) return rc;
+    if (A->distributed) return dist_spmv_op(A, *P, x, y);
     return spmv_launch(*P, A->is_complex, A->variant, A->mean_row, x, y, false, c.stream,
                        c.in_solve ? &c.state->done : nullptr);
 }

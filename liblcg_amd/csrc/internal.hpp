@@ -215,6 +215,7 @@ struct lcg_hip_csr {
     int *rem_rows = nullptr;    // local row of each remc row
     double *rem_y = nullptr;    // remc . xfull, scattered into y after the local product
     double *xfull = nullptr;    // gather buffer
+    double *op_z = nullptr;     // (A_r)^T . x_r over the padded global height, and one rows-per-rank block behind it (dist_spmv_op)
     void *halo = nullptr;       // neighbour-exchange plan (comm.hip)
     void *direct = nullptr;     // direct (peer-mapped) exchange state (comm.hip, mode 2)
 };
@@ -251,5 +252,6 @@ int comm_allreduce(double *dev, int count, hipStream_t s);
 bool comm_active();
 bool xg_box(XgBox *out);        // true when the direct all-reduce is connected and enabled
 int dist_spmv(lcg_hip_csr *A, const double *x, double *y);
+int dist_spmv_op(lcg_hip_csr *A, const CsrPart &T, const double *x, double *y);     // y = this rank's rows of A^T.x / A^H.x (T = (A_r)^T, csr.hip: op_part)
 
 } // namespace lcgh

@@ -63,6 +63,19 @@ def main(out_path):
                           api.lcg_default_parameters(epsilon=1e-6), A, api.LCG_CG)
     res["cgpfp/meta"] = np.array([info.ret, info.iterations, info.residual, len(seen)]); res["cgpfp/x"] = m.cpu().numpy()
 
+    # real, non-symmetric, generated: A^T.x sharded against unsharded
+    G = api.CsrMatrix.generate(30000, 16, 500, False, 4, 0.01)
+    if sharded:
+        G.distribute(30000, mode)
+    xr = torch.empty(30000, dtype=torch.float64, device="cuda"); api.gen_xtrue(30000, 5, 0, 30000, xr)
+    yr = torch.empty_like(xr)
+    assert lib.lcg_hip_spmv_op(G.h, xr.data_ptr(), yr.data_ptr(), 1, 0) == 0, lib.lcg_hip_last_error()
+    api.synchronize()
+    res["opT_real/y"] = yr.cpu().numpy()
+    G.spmv(xr, yr); api.synchronize()
+    res["op_real/y"] = yr.cpu().numpy()
+    G.destroy()
+
     nc, row, col, val, bc = read_coo_system(os.path.join(GOLDEN, "case_1K_cA"), True)
     rp, ci, v = coo_to_csr_host(nc, row, col, val)
     Ac = api.CsrMatrix.from_csr(rp, ci, v)
@@ -70,7 +83,17 @@ def main(out_path):
         Ac.distribute(nc, mode)
     bcd = torch.from_numpy(bc).cuda()
     cpara = api.clcg_default_parameters(epsilon=1e-10, abs_diff=1)
-    for name, sid in (("c_bicg_sym", api.CLCG_BICG_SYM), ("c_cgs", api.CLCG_CGS), ("c_tfqmr", api.CLCG_TFQMR)):
+    # A^H.x and A^T.x on the sharded matrix (every rank multiplies the transpose of its rows, ncclReduceScatter sums the
+    # contributions): the product itself and clbicg (clcg.cpp:77-226), whose second product per iteration is A^H.d
+    rng = np.random.default_rng(11)
+    xc = torch.from_numpy(rng.standard_normal(nc) + 1j * rng.standard_normal(nc)).cuda()
+    yc = torch.empty_like(xc)
+    for tag, layout, conj in (("opH", 1, 1), ("opT", 1, 0)):
+        assert lib.lcg_hip_spmv_op(Ac.h, xc.data_ptr(), yc.data_ptr(), layout, conj) == 0, lib.lcg_hip_last_error()
+        api.synchronize()
+        res[f"{tag}/y"] = yc.cpu().numpy()
+    res["op_conj_only_rc"] = np.array(lib.lcg_hip_spmv_op(Ac.h, xc.data_ptr(), yc.data_ptr(), 0, 1))
+    for name, sid in (("c_bicg", api.CLCG_BICG), ("c_bicg_sym", api.CLCG_BICG_SYM), ("c_cgs", api.CLCG_CGS), ("c_tfqmr", api.CLCG_TFQMR)):
         m = torch.zeros(nc, dtype=torch.complex128, device="cuda")
         info = api.clcg_solver("clcg_hip_csr_ax", None, m, bcd, nc, cpara, Ac, sid, shadow_seed=7)
         res[f"{name}/meta"] = np.array([info.ret, info.iterations, info.residual])

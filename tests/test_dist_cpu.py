@@ -127,8 +127,21 @@ def _worker(rank, world, port_no, n, band, q, schedule="classic"):
         assert reductions[0] == t
     err = gdot(m - xt, m - xt) ** 0.5
     mall = gather(m)[:n]
+    # 3. op(A).x = A^T.x on the sharded matrix as comm.hip: dist_spmv_op places it: every rank multiplies the transpose of ITS
+    #    rows with ITS slice of x over the padded global height, the sum over ranks is scattered back in rows-per-rank blocks
+    #    (gloo has no reduce-scatter: all-reduce + own block is the same sum).  Non-symmetric values so that A^T != A.
+    g2_ = orc.gen_init(n, 16, band, False, 5, 0.01)
+    rp2, ci2, v2 = orc.gen_rows(g2_, r0, r1)
+    xs = orc.gen_xtrue(g2_, r0, r1)
+    z = np.zeros(glen)
+    for i in range(r1 - r0):
+        s, e = rp2[i], rp2[i + 1]
+        np.add.at(z, ci2[s:e], v2[s:e] * xs[i])
+    zt = torch.from_numpy(z); dist.all_reduce(zt)
+    yT = zt.numpy()[rank * rpr: rank * rpr + (r1 - r0)]
+    yT_all = gather(yT)[:n]
     if rank == 0:
-        q.put((t, err, mall))
+        q.put((t, err, mall, yT_all))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -144,7 +157,7 @@ def test_sharded_cg_matches_single_process(world, band, schedule, port):
     procs = [ctx.Process(target=_worker, args=(r, world, port_no, n, band, q, schedule)) for r in range(world)]
     for p in procs:
         p.start()
-    t, err, mall = q.get(timeout=120)
+    t, err, mall, yT_all = q.get(timeout=120)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -157,6 +170,14 @@ def test_sharded_cg_matches_single_process(world, band, schedule, port):
     assert abs(t - ref["iters"]) <= 1
     assert np.linalg.norm(mall - ref["x"]) / np.linalg.norm(ref["x"]) <= 1e-9
     assert err <= 1e-5 * np.linalg.norm(xt)
+    # the sharded transposed product against scipy's on the whole matrix
+    import scipy.sparse as sp
+    g2 = port.gen_init(n, 16, band, False, 5, 0.01)
+    rp2, ci2, v2 = port.gen_rows(g2)
+    A2 = sp.csr_matrix((v2, ci2, rp2), shape=(n, n))
+    want = A2.T @ port.gen_xtrue(g2)
+    assert np.abs(yT_all - want).max() <= 1e-12 * np.abs(want).max()
+    assert np.abs(want - A2 @ port.gen_xtrue(g2)).max() > 1e-3 * np.abs(want).max()      # A^T != A
 
 
 def test_partition_rules():

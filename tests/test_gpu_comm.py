@@ -112,13 +112,19 @@ def test_sharded_loops_converge_like_the_unsharded_ones(tmp_path, mode):
     plain = _solve_cases(tmp_path, "plain", {})
     forced = _solve_cases(tmp_path, "forced", {"LCG_HIP_FORCE_COMM": "1", "LCG_HIP_DIST_MODE": mode, "MASTER_PORT": "29548"})
     bands = {"cg": (1e-9, 3, 0.0), "pcg": (1e-9, 3, 0.0), "cgs": (1e-9, 3, 0.0), "bicgstab": (1e-7, 3, 0.15),
-             "bicgstab2": (1e-7, 3, 0.15), "c_bicg_sym": (5e-5, 3, 0.12), "c_cgs": (5e-5, 3, 0.12), "c_tfqmr": (5e-5, 3, 0.12)}
+             "bicgstab2": (1e-7, 3, 0.15), "c_bicg": (5e-5, 3, 0.12), "c_bicg_sym": (5e-5, 3, 0.12), "c_cgs": (5e-5, 3, 0.12), "c_tfqmr": (5e-5, 3, 0.12)}
     for name, (xtol, it_abs, it_rel) in bands.items():
         rp, ip, _ = plain[f"{name}/meta"]; rf, itf, resf = forced[f"{name}/meta"]
         assert rp == rf == 0, name
         assert abs(itf - ip) <= max(it_abs, it_rel * ip), (name, ip, itf)
         xp, xf = plain[f"{name}/x"], forced[f"{name}/x"]
         assert np.linalg.norm(xf - xp) / np.linalg.norm(xp) <= xtol, name
+    # op(A).x on the sharded matrix (A^H, A^T; complex and real): the one-rank reduce-scatter hands back what the unsharded
+    # transpose computes, bit for bit (same materialised transpose, same kernels); conj(A) alone is refused when sharded
+    for tag in ("opH", "opT", "opT_real", "op_real"):
+        assert np.array_equal(forced[f"{tag}/y"], plain[f"{tag}/y"]), tag
+    assert np.abs(plain["opT_real/y"] - plain["op_real/y"]).max() > 1e-3          # A != A^T: the transpose really was taken
+    assert int(plain["op_conj_only_rc"]) == 0 and int(forced["op_conj_only_rc"]) == -2000
     assert tuple(forced["cg13/meta"][:2]) == tuple(plain["cg13/meta"][:2]) == (-1019, 13)
     assert np.linalg.norm(forced["cg13/x"] - plain["cg13/x"]) / np.linalg.norm(plain["cg13/x"]) <= 1e-10
     assert forced["cgpfp/meta"][0] == 0 and abs(forced["cgpfp/meta"][1] - plain["cgpfp/meta"][1]) <= 2
