@@ -158,7 +158,11 @@ int clcg_hip_solver(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, double *
                     int n_size, const clcg_para *param, void *instance, int solver_id, int mem);
 /* clcg_solver_preconditioned_cuda() (clcg_cuda.h:105-108) -> clpcg (clcg_cuda.cu:403-558): PCG for
  * complex-symmetric A with unconjugated products; monitors |r|^2/max(|m|^2,1) (or |r|/N), as that
- * CUDA loop does.  Mfp has the complex callback type; clcg_hip_jacobi_mx is the ready-made one. */
+ * CUDA loop does.  Mfp has the complex callback type; clcg_hip_jacobi_mx is the ready-made one.
+ * solver_id = CLCG_PBICG runs clpbicg instead (clcg_solver_preconditioned_eigen's default, clcg_eigen.h:87-92,
+ * clcg_eigen.cpp:685-802): preconditioned BiCG with two products per iteration, A.p and conj(A).ps (the callback's
+ * conjugate flag), Eigen's conjugating dot and the CPU loops' 4th-power stop rule (|<r,r>|^2 / max(|<m,m>|^2, 1), or
+ * |r|^2 / N with abs_diff); every other id runs clpcg.  Neither loop has a CPU twin in the reference that builds here. */
 int clcg_hip_solver_preconditioned(clcg_hip_axfunc_ptr Afp, clcg_hip_axfunc_ptr Mfp, clcg_hip_progress_ptr Pfp,
                                    double *m, const double *B, int n_size, const clcg_para *param,
                                    void *instance, int solver_id, int mem);

@@ -261,6 +261,74 @@ struct FinZPcg {        // sums: |m|^2, |r|^2, (r.s).re, (r.s).im
     }
 };
 
+// ---- preconditioned BiCG (reference: Eigen back-end only, clcg_eigen.cpp:685-802) --------------------------------------
+// Eigen's a.dot(b) conjugates a; the stop rule is the 4th-power one of the CPU loops (std::norm of the inner products).
+// The shadow residual is recomputed from the OLD residual every iteration (rsk = conj(rk) - conj(ak) Asx, :767), as written.
+struct OpZPbInit {      // p = z; ps = conj(z); rs = conj(r); |m|^2, |r|^2, <rs,z>          clcg_eigen.cpp:707-716
+    static constexpr int NR = 4, SKIP = SKIP_NEVER;
+    DevState *st; const double *z, *r, *m; double *p, *ps, *rs;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const double2 zv = L(z, i), rv = L(r, i), rc = cconj(rv);
+        S(p, i, zv); S(ps, i, cconj(zv)); S(rs, i, rc);
+        acc[0] += cnorm(L(m, i)); acc[1] += cnorm(rv);
+        acc_inner(acc + 2, rc, zv);
+    }
+};
+struct OpZPbUpd {       // m += a p; rs = conj(r) - conj(a) Asx; r -= a Ax                    clcg_eigen.cpp:766-768
+    static constexpr int NR = 0, SKIP = SKIP_DONE;
+    DevState *st; double *m, *r, *rs; const double *p, *Ax, *Asx; double2 ak;
+    __device__ void prep() { ak = lds2(st, C_AK); }
+    template <class T> __device__ void apply(long i, double *)
+    {
+        const double2 rv = L(r, i);
+        S(m, i, cfma(ak, L(p, i), L(m, i)));
+        S(rs, i, cfma(cneg(cconj(ak)), L(Asx, i), cconj(rv)));
+        S(r, i, cfma(cneg(ak), L(Ax, i), rv));
+    }
+};
+struct OpZPbDots {      // |m|^2, |r|^2, <rs,z>, NaN                                           clcg_eigen.cpp:770-777
+    static constexpr int NR = 5, SKIP = SKIP_DONE;
+    DevState *st; const double *m, *r, *rs, *z;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const double2 mv = L(m, i);
+        acc[0] += cnorm(mv); acc[1] += cnorm(L(r, i));
+        acc_inner(acc + 2, L(rs, i), L(z, i));
+        acc[4] += cnan(mv);
+    }
+};
+struct OpZPbUpdJacobi { // built-in Jacobi: the update, z = r .* invdiag and the sums in one pass
+    static constexpr int NR = 5, SKIP = SKIP_DONE;
+    DevState *st; double *m, *r, *rs, *z; const double *p, *Ax, *Asx, *inv; double2 ak;
+    __device__ void prep() { ak = lds2(st, C_AK); }
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const double2 r0 = L(r, i);
+        const double2 mv = cfma(ak, L(p, i), L(m, i));
+        const double2 rsv = cfma(cneg(cconj(ak)), L(Asx, i), cconj(r0));
+        const double2 rv = cfma(cneg(ak), L(Ax, i), r0);
+        const double2 zv = cmul(L(inv, i), rv);
+        S(m, i, mv); S(rs, i, rsv); S(r, i, rv); S(z, i, zv);
+        acc[0] += cnorm(mv); acc[1] += cnorm(rv);
+        acc_inner(acc + 2, rsv, zv);
+        acc[4] += cnan(mv);
+    }
+};
+struct OpZPbDir {       // p = z + b p; ps = conj(z) + conj(b) ps                               clcg_eigen.cpp:781-782
+    static constexpr int NR = 0, SKIP = SKIP_DIR;
+    DevState *st; double *p, *ps; const double *z; double2 bk;
+    __device__ void prep() { bk = lds2(st, C_BK); }
+    template <class T> __device__ void apply(long i, double *)
+    {
+        const double2 zv = L(z, i);
+        S(p, i, cfma(bk, L(p, i), zv));
+        S(ps, i, cfma(cconj(bk), L(ps, i), cconj(zv)));
+    }
+};
+
 // ---- CGS / BiCGStab / TFQMR shared ----------------------------------------------------------------
 template <int MODE>   // 0 CGS: p = u = r; 1 BiCGStab: p = r; 2 TFQMR: p = u = r, d = 0
 struct OpZShadowInit {  // r = B - Ax ...; |m|^2, |r|^2, <rbar0, r>
@@ -577,6 +645,51 @@ static int solve_cpcg(clcg_hip_axfunc_ptr Afp, clcg_hip_axfunc_ptr Mfp, clcg_hip
     return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
 }
 
+static int solve_cpbicg(clcg_hip_axfunc_ptr Afp, clcg_hip_axfunc_ptr Mfp, clcg_hip_progress_ptr Pfp, double *m,
+                        const double *B, int n, const clcg_para *param, void *inst, int mem)
+{
+    const clcg_para p = param ? *param : clcg_hip_default_parameters();
+    TRY(ccheck_args(p, n, m, B));                                       // clcg_eigen.cpp:693-697
+    if (Mfp == nullptr) return LCG_NULL_PRECONDITION_MATRIX;
+    TRY(ensure_init());
+    Ctx &c = ctx();
+    const size_t nb = sizeof(double) * 2 * (size_t)n;
+    HostBridge hb; TRY(hb.open(mem, m, B, nb, c.stream));
+    Workspace ws; double *r, *rs, *z, *pk, *ps, *Ax, *Asx;
+    TRY(ws.get(r, nullptr, nb)); TRY(ws.get(rs, nullptr, nb)); TRY(ws.get(z, nullptr, nb)); TRY(ws.get(pk, nullptr, nb));
+    TRY(ws.get(ps, nullptr, nb)); TRY(ws.get(Ax, nullptr, nb)); TRY(ws.get(Asx, nullptr, nb));
+    CplxCommon k(c, n, p, inst, Afp, Pfp, m);
+    TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
+    DevState *st = c.state;
+    const double *inv = nullptr;        // built-in Jacobi on a complex handle: fold M^-1 into the update
+    if (Mfp == clcg_hip_jacobi_mx && inst) {
+        const lcg_hip_csr *A = static_cast<const lcg_hip_csr *>(inst);
+        if (A->is_complex && A->n_rows == n) inv = A->invdiag;
+    }
+
+    TRY(k.ax(m, Ax));                                                   // :702
+    TRY(k.drv.vec(OpZResid{st, Ax, B, r}));                             // :704
+    TRY(k.drv.checked_mx([&] { Mfp(inst, r, z, n, 0, 0); }));           // :705
+    TRY(k.drv.vec(OpZPbInit{st, z, r, m, pk, ps, rs}));                 // :707-716
+    TRY(k.drv.scal(FinZInit<false>{}));                                 // :719-736
+    int rc = k.run_loop([&]() -> int {
+        TRY(k.ax(pk, Ax));                                              // :760
+        TRY(k.axop(ps, Asx, 0, 1));                                     // :761  conj(A).ps
+        TRY(k.drv.vec(OpZDot<true>{st, ps, Ax}));                       // :763
+        if (inv) {
+            TRY(k.drv.vecf(FinZAlpha{C_RHO}, OpZPbUpdJacobi{st, m, r, rs, z, pk, Ax, Asx, inv, {}}));     // :764 | :766-777
+        } else {
+            TRY(k.drv.vecf(FinZAlpha{C_RHO}, OpZPbUpd{st, m, r, rs, pk, Ax, Asx, {}}));                   // :764 | :766-768
+            TRY(k.drv.checked_mx([&] { Mfp(inst, r, z, n, 0, 0); }));   // :775
+            TRY(k.drv.vec(OpZPbDots{st, m, r, rs, z}));                 // :770-777
+        }
+        TRY(k.drv.vecf(FinZClose<0>{}, OpZPbDir{st, pk, ps, z, {}}));   // :778-779 | :781-782
+        return 0;
+    });
+    int rc2 = hb.close(c.stream);
+    return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
+}
+
 static int solve_bicg_sym(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pfp, double *m, const double *B, int n,
                           const clcg_para *param, void *inst, int mem)
 {
@@ -733,13 +846,14 @@ extern "C" int clcg_hip_solver(clcg_hip_axfunc_ptr Afp, clcg_hip_progress_ptr Pf
     }
 }
 
-// clcg_solver_preconditioned_cuda (clcg_cuda.h:105-108) -> clpcg (clcg_cuda.cu:403-558); solver_id is
-// accepted for signature parity (CLCG_PCG is the only preconditioned complex loop ported here).
+// clcg_solver_preconditioned_cuda (clcg_cuda.h:105-108) -> clpcg (clcg_cuda.cu:403-558);
+// clcg_solver_preconditioned_eigen (clcg_eigen.h:87-92, clcg_eigen.cpp:78-93): CLCG_PBICG -> clpbicg, CLCG_PCG -> clpcg.
+// Here: CLCG_PBICG runs clpbicg, every other id clpcg (the CUDA entry's only loop and this entry's default).
 extern "C" int clcg_hip_solver_preconditioned(clcg_hip_axfunc_ptr Afp, clcg_hip_axfunc_ptr Mfp, clcg_hip_progress_ptr Pfp,
                                               double *m, const double *B, int n, const clcg_para *param,
                                               void *instance, int solver_id, int mem)
 {
-    (void)solver_id;
+    if (solver_id == CLCG_PBICG) return solve_cpbicg(Afp, Mfp, Pfp, m, B, n, param, instance, mem);
     return solve_cpcg(Afp, Mfp, Pfp, m, B, n, param, instance, mem);
 }
 

@@ -1,6 +1,8 @@
 /*
  * clcg_oracle.c -- TEST INFRASTRUCTURE (see lcg_oracle.h).  Parity: PINNED
- * against the compiled reference (tests/test_oracle_vs_ref.py).
+ * against the compiled reference (tests/test_oracle_vs_ref.py) -- except the two
+ * preconditioned loops orc_clpcg and orc_clpbicg, which say "PARITY UNPINNED" at
+ * their definitions: the reference has them in its CUDA / Eigen back-ends only.
  *
  * Complex (c128) solvers of liblcg's native back-end, restated in C99
  * `double _Complex`.  libstdc++'s std::complex<double> operators and GCC's
@@ -205,6 +207,56 @@ int orc_clpcg(orc_caxfunc Afp, orc_caxfunc Mfp, orc_cprogress Pfp, zc *m, const 
     }
 out:
     free(r); free(d); free(s); free(Ax);
+    return ret;
+}
+
+/* ------------------------------------------------- preconditioned BiCG
+ * PARITY UNPINNED like orc_clpcg: clpbicg exists only in the reference's Eigen back-end (clcg_eigen.cpp:685-802; the
+ * default of clcg_solver_preconditioned_eigen, clcg_eigen.h:87-92) and Eigen3 is not in the image.  Restated from that
+ * source with Eigen's conventions spelled out: a.dot(b) = sum conj(a_i) b_i; std::norm(z) = |z|^2, so the stop rule is the
+ * 4th-power one of the CPU loops (m_mod = |<m,m>|^2 clamped to 1, rk_mod = |<r,r>|^2; abs_diff: sqrt(rk_mod) / n).  Two
+ * products per iteration: A.p and conj(A).ps (Afp(psk, Asx, MatNormal, Conjugate), :761).  The shadow residual is NOT a
+ * recurrence: rsk = conj(rk_old) - conj(ak) Asx every iteration (:767), restated as written.  No NaN scan in the loop. */
+int orc_clpbicg(orc_caxfunc Afp, orc_caxfunc Mfp, orc_cprogress Pfp, zc *m, const zc *B, int n,
+                const orc_cpara *param, void *inst)
+{
+    orc_cpara p = param ? *param : orc_cdefaults;
+    int ret = ccheck_args(&p, n, m, B);                         /* clcg_eigen.cpp:693-697 */
+    if (ret) return ret;
+    zc *r = malloc(sizeof(zc) * n), *rs = malloc(sizeof(zc) * n), *z = malloc(sizeof(zc) * n), *pk = malloc(sizeof(zc) * n),
+       *ps = malloc(sizeof(zc) * n), *Ax = malloc(sizeof(zc) * n), *Asx = malloc(sizeof(zc) * n);
+    int t = 0;
+    Afp(inst, m, Ax, n, 0, 0);                                  /* :702 */
+    for (int i = 0; i < n; i++) r[i] = B[i] - Ax[i];            /* :704 */
+    Mfp(inst, r, z, n, 0, 0);                                   /* :705 */
+    for (int i = 0; i < n; i++) { pk[i] = z[i]; rs[i] = conj(r[i]); ps[i] = conj(z[i]); }   /* :707-709 */
+    zc rho = orc_cinner(rs, z, n);                              /* :711 rsk.dot(zk) */
+    double m4 = m4_of(m, n);                                    /* :713-714 */
+    double r4 = zsquare(orc_cinner(r, r, n));                   /* :716 */
+    if (calready_done(&p, Pfp, inst, m, r4, m4, n)) { ret = ORC_ALREADY_OPTIMIZIED; goto out; }    /* :719-736 */
+    while (!cloop_head(&p, Pfp, inst, m, r4, m4, n, &t, &ret)) { /* :741-758 */
+        Afp(inst, pk, Ax, n, 0, 0);                             /* :760 */
+        Afp(inst, ps, Asx, n, 0, 1);                            /* :761 conj(A).ps */
+        zc pAx = orc_cinner(ps, Ax, n);                         /* :763 psk.dot(Ax) */
+        zc ak = rho / pAx;                                      /* :764 */
+        for (int i = 0; i < n; i++) {                           /* :766-768 */
+            m[i] = m[i] + ak * pk[i];
+            rs[i] = conj(r[i]) - conj(ak) * Asx[i];
+            r[i] = r[i] - ak * Ax[i];
+        }
+        m4 = m4_of(m, n);                                       /* :770-771 */
+        r4 = zsquare(orc_cinner(r, r, n));                      /* :773 */
+        Mfp(inst, r, z, n, 0, 0);                               /* :775 */
+        zc rho2 = orc_cinner(rs, z, n);                         /* :777 */
+        zc bk = rho2 / rho;                                     /* :778 */
+        rho = rho2;
+        for (int i = 0; i < n; i++) {                           /* :781-782 */
+            pk[i] = z[i] + bk * pk[i];
+            ps[i] = conj(z[i]) + conj(bk) * ps[i];
+        }
+    }
+out:
+    free(r); free(rs); free(z); free(pk); free(ps); free(Ax); free(Asx);
     return ret;
 }
 

@@ -183,6 +183,12 @@ int orc_csolve_csr_pcg(orc_csr *A, double *m, const double *B, const orc_cpara *
     return orc_clpcg(orc_csr_cax, orc_cjacobi_mx, orc_record_cprogress, (zc *)m, (const zc *)B, A->n, param, A);
 }
 
+int orc_csolve_csr_pbicg(orc_csr *A, double *m, const double *B, const orc_cpara *param)
+{
+    A->iters = 0; A->last_residual = 0.0; A->n_ax = 0;
+    return orc_clpbicg(orc_csr_cax, orc_cjacobi_mx, orc_record_cprogress, (zc *)m, (const zc *)B, A->n, param, A);
+}
+
 /* lcg_solver_constrained (lcg.h:111-113): LCG_PG = 5, LCG_SPG = 6 */
 int orc_solve_csr_box(int solver_id, orc_csr *A, double *m, const double *B, const double *low,
                       const double *hig, const orc_para *param)

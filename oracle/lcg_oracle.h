@@ -111,6 +111,8 @@ int orc_clbicg(orc_caxfunc Afp, orc_cprogress Pfp, double _Complex *m, const dou
 /* PARITY UNPINNED (CUDA/Eigen-only in the reference): see clcg_oracle.c */
 int orc_clpcg(orc_caxfunc Afp, orc_caxfunc Mfp, orc_cprogress Pfp, double _Complex *m,
               const double _Complex *B, int n, const orc_cpara *param, void *instance);  /* clcg_cuda.cu:403-558 */
+int orc_clpbicg(orc_caxfunc Afp, orc_caxfunc Mfp, orc_cprogress Pfp, double _Complex *m,
+                const double _Complex *B, int n, const orc_cpara *param, void *instance);  /* clcg_eigen.cpp:685-802 (UNPINNED) */
 int orc_clbicg_symmetric(orc_caxfunc Afp, orc_cprogress Pfp, double _Complex *m,
                          const double _Complex *B, int n, const orc_cpara *param,
                          void *instance);                           /* clcg.cpp:228-364 */
@@ -173,7 +175,9 @@ int  orc_record_cprogress(void *instance, const double _Complex *m, double conve
 int orc_solve_csr(int solver_id, int jacobi, orc_csr *A, double *m, const double *B,
                   const orc_para *param);
 int orc_csolve_csr_pcg(orc_csr *A, double *m_interleaved, const double *B_interleaved,
-                       const orc_cpara *param);     /* Jacobi: invdiag holds interleaved complex reciprocals */
+                       const orc_cpara *param);
+int orc_csolve_csr_pbicg(orc_csr *A, double *m_interleaved, const double *B_interleaved,
+                       const orc_cpara *param);    /* orc_clpbicg with the same complex Jacobi */     /* Jacobi: invdiag holds interleaved complex reciprocals */
 int orc_solve_csr_box(int solver_id, orc_csr *A, double *m, const double *B, const double *low,
                       const double *hig, const orc_para *param);
 int orc_csolve_csr(int solver_id, orc_csr *A, double *m_interleaved, const double *B_interleaved,

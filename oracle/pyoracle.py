@@ -151,6 +151,21 @@ class Oracle:
         ret = self.lib.orc_csolve_csr_pcg(C.byref(inst), _ptr(m), _ptr(b), C.byref(para))
         return dict(x=m, ret=ret, iters=inst.iters, residual=inst.last_residual, n_ax=inst.n_ax)
 
+    def csolve_pbicg(self, rowptr, col, val, b, m0=None, para=None):
+        """Preconditioned complex BiCG with Jacobi (restated from clcg_eigen.cpp:685-802; parity UNPINNED: Eigen back-end
+        only in the reference).  Port only."""
+        n = len(rowptr) - 1
+        val = np.ascontiguousarray(val, np.complex128)
+        inv = np.ascontiguousarray(1.0 / self.csr_diag(rowptr, col, val), np.complex128)
+        keep = (np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32), val, inv)
+        inst = CsrInst(n, _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]), 1, 0, 0.0, 0)
+        m = np.zeros(n, np.complex128) if m0 is None else np.array(m0, np.complex128)
+        b = np.ascontiguousarray(b, np.complex128)
+        para = para or default_cpara()
+        self.lib.orc_csolve_csr_pbicg.restype = C.c_int
+        ret = self.lib.orc_csolve_csr_pbicg(C.byref(inst), _ptr(m), _ptr(b), C.byref(para))
+        return dict(x=m, ret=ret, iters=inst.iters, residual=inst.last_residual, n_ax=inst.n_ax)
+
     def csolve(self, solver_id, rowptr, col, val, b, m0=None, para=None, rbar0=None, threads=1):
         """Complex solve.  `rbar0` is required by the port for CGS/BiCGStab/TFQMR; the
         reference draws its own from time(0) and reports the bracket as seed_before/after."""

@@ -66,6 +66,40 @@ def test_bicgstab2_counts_two_iterations_per_pass_with_abs_diff(api, port, golde
 
 
 @pytest.mark.parametrize("case", ["1K", "10K"])
+def test_complex_pbicg_jacobi(api, port, case1kc, case10kc, case):
+    """clpbicg (clcg_eigen.cpp:685-802; CLCG_PBICG through clcg_solver_preconditioned, the Eigen entry's default,
+    clcg_eigen.h:87-92) with the complex Jacobi.  Oracle = restatement of the Eigen source (parity unpinned), plus the known
+    answers.  The first dozen iterates track the oracle tightly; converged runs within the bands of the other complex
+    BiCG-type loops; the fused built-in Jacobi and a user-written preconditioner walk the same iterates."""
+    from oracle import pyoracle as po
+    n, rp, ci, v, b, xs = case1kc if case == "1K" else case10kc
+    A = api.CsrMatrix.from_csr(rp, ci, v)
+    A.build_jacobi()
+    bd = torch.from_numpy(b).cuda()
+    m = torch.zeros(n, dtype=torch.complex128, device="cuda")
+    info = api.clcg_solver_preconditioned("clcg_hip_csr_ax", "clcg_hip_jacobi_mx", None, m, bd, n,
+                                          api.clcg_default_parameters(epsilon=1e-10, abs_diff=1), A, api.CLCG_PBICG)
+    ref = port.csolve_pbicg(rp, ci, v, b, para=po.default_cpara(epsilon=1e-10, abs_diff=1))
+    x = m.cpu().numpy()
+    assert info.ret == ref["ret"] == 0 and info.residual <= 1e-10
+    assert abs(info.iterations - ref["iters"]) <= 0.12 * ref["iters"]
+    assert np.linalg.norm(x - ref["x"]) / np.linalg.norm(ref["x"]) <= 5e-5
+    assert np.linalg.norm(x - xs) <= 1e-3
+    p12 = api.clcg_default_parameters(epsilon=1e-10, abs_diff=1, max_iterations=12)
+    m1 = torch.zeros_like(m); m2 = torch.zeros_like(m)
+    i1 = api.clcg_solver_preconditioned("clcg_hip_csr_ax", "clcg_hip_jacobi_mx", None, m1, bd, n, p12, A, api.CLCG_PBICG)
+    r12 = port.csolve_pbicg(rp, ci, v, b, para=po.default_cpara(epsilon=1e-10, abs_diff=1, max_iterations=12))
+    assert i1.ret == r12["ret"] == -1019 and i1.iterations == 12
+    assert np.linalg.norm(m1.cpu().numpy() - r12["x"]) <= 1e-9 * np.linalg.norm(r12["x"])
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    i2 = api.clcg_solver_preconditioned("clcg_hip_csr_ax", lambda inst, xp, zp, nn, lay, cj: lib.clcg_hip_jacobi_mx(A.h, xp, zp, nn, 0, 0),
+                                        None, m2, bd, n, p12, A, api.CLCG_PBICG)
+    assert i2.ret == -1019 and (m1 - m2).abs().max().item() <= 1e-8 * m1.abs().max().item()
+    assert api.clcg_solver_preconditioned("clcg_hip_csr_ax", None, None, m1, bd, n, p12, A, api.CLCG_PBICG).ret == -1018
+
+
+@pytest.mark.parametrize("case", ["1K", "10K"])
 def test_complex_pcg_jacobi_sample10_workload(api, port, case1kc, case10kc, case):
     """clpcg (clcg_cuda.cu:403-558) with the complex Jacobi of sample10.cu:117,193 -- the reference's own
     GPU workload for these fixtures.  Oracle = restatement of the CUDA source (parity unpinned: no CPU

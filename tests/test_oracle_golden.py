@@ -68,6 +68,23 @@ def test_clpcg_restatement_against_known_answers(port, case1kc, case10kc):
         assert res <= 1.05e-10
 
 
+def test_clpbicg_restatement_against_known_answers(port, case1kc, case10kc):
+    """orc_clpbicg (restated from clcg_eigen.cpp:685-802) has no reference pin either: the Eigen back-end is the only
+    place it exists.  What can be checked: it solves the bundled complex systems -- its stop rule is the CPU loops'
+    4th-power one, so eps = 1e-10 / abs_diff stops at |r|^2 / N <= 1e-10 -- ; its monitored value is |r|^2 / N of its
+    answer recomputed independently; it takes two products per iteration (A.p and conj(A).ps) plus the set-up one."""
+    for (n, rp, ci, v, b, xs), iters, dist in ((case1kc, 322, 1e-4), (case10kc, 453, 5e-4)):
+        r = port.csolve_pbicg(rp, ci, v, b, para=po.default_cpara(epsilon=1e-10, abs_diff=1))
+        assert r["ret"] == 0 and r["iters"] == iters and r["n_ax"] == 2 * iters + 1
+        assert np.linalg.norm(r["x"] - xs) <= dist
+        res = np.linalg.norm(port.csr_matvec(rp, ci, v, r["x"]) - b) ** 2 / n
+        assert res <= 1.05e-10 and abs(res - r["residual"]) <= 1e-3 * r["residual"]
+    # capped: the REAL enum's code, as every CPU complex loop returns it (clcg_eigen.cpp:751-755)
+    n, rp, ci, v, b, xs = case1kc
+    r = port.csolve_pbicg(rp, ci, v, b, para=po.default_cpara(epsilon=1e-10, abs_diff=1, max_iterations=7))
+    assert r["ret"] == -1019 and r["iters"] == 7
+
+
 def test_known_answer_case_10K(port, case10k):
     """CG at eps=1e-20/abs_diff reaches the fp64 floor of case_10K_B."""
     n, rp, ci, v, b, xs = case10k
