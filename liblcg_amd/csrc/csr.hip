@@ -621,20 +621,16 @@ __global__ __launch_bounds__(VB) void k_axp_fold(const double *__restrict__ big,
 // (grid-row boundaries) are walked from the CSR arrays by the same wavefront.  Entry k of a row is added to partial sum
 // k mod T, the partial sums in index order -- the arithmetic of k_spmv_lds1 with VB / T rows per block (T = 1 for up to 8.5
 // entries per row, 2 up to 17), which is the kernel the automatic choice would otherwise take: the same bits.
+// the work of one wavefront on block b (< number of 64-row blocks); returns the finished y of row 64 b + lane (0 past the end)
 template <int T>
-__global__ __launch_bounds__(VB) void k_spmv_run1(int n, int LP, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                  const double *__restrict__ val, const int *__restrict__ pofs,
-                                                  const int *__restrict__ pbase, const int *__restrict__ pcols,
-                                                  const double *__restrict__ x, double *__restrict__ y, const int *done)
+__device__ __forceinline__ double run1_block(int b, int wv, int n, int LP, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                             const double *__restrict__ val, const int *__restrict__ pofs,
+                                             const int *__restrict__ pbase, const int *__restrict__ pcols,
+                                             const double *__restrict__ x, double *__restrict__ y, double *wlds)
 {
-    extern __shared__ double wlds[];                    // [VB / 64][64 * LP]: a wavefront's values, row by row (LP odd: no bank conflicts)
-    if (done && *done) return;
     constexpr int NB = 8;                               // entries in flight per lane and batch (a multiple of T)
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int b = blockIdx.x * (VB / 64) + wv;
     const long row0 = (long)b * 64;
-    if (row0 >= n) return;
     const int nrows = (int)min(64L, n - row0);
     const bool live = lane < nrows;
     const int bs = pbase[b], po = pofs[b], s = rowptr[row0];
@@ -709,7 +705,68 @@ __global__ __launch_bounds__(VB) void k_spmv_run1(int n, int LP, const int *__re
 #pragma unroll
     for (int j = 1; j < T; j++) v += acc[j];
     if (live) y[row0 + lane] = v;
+    return live ? v : 0.0;
 }
+
+template <int T>
+__global__ __launch_bounds__(VB) void k_spmv_run1(int n, int LP, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                  const double *__restrict__ val, const int *__restrict__ pofs,
+                                                  const int *__restrict__ pbase, const int *__restrict__ pcols,
+                                                  const double *__restrict__ x, double *__restrict__ y, const int *done)
+{
+    extern __shared__ double wlds[];                    // [VB / 64][64 * LP]: a wavefront's values, row by row (LP odd: no bank conflicts)
+    if (done && *done) return;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * (VB / 64) + wv;
+    if ((long)b * 64 >= n) return;
+    (void)run1_block<T>(b, wv, n, LP, rowptr, col, val, pofs, pbase, pcols, x, y, wlds);
+}
+
+// The same product carrying the dot that follows it (see k_spmv_lds1d): EIGHT wavefronts per workgroup -- there is no
+// barrier in the product, so the workgroup's size is free -- each adds its rows' y_i u_i (y_i y_i) with one DPP sum, and the
+// workgroup leaves ONE partial per running sum: a quarter of the partials a 256-thread grid would hand the consuming pass
+// (1954 instead of 3907 on the 1M-row Laplacian, whose every block re-adds them; sixteen wavefronts were measured too:
+// 17.9 us per product against 15.4 -- large workgroups fill the CUs less evenly -- and four: 15.2).
+constexpr int RUN1D_WG = 512;
+template <int T>
+__global__ __launch_bounds__(RUN1D_WG) void k_spmv_run1d(int n, int LP, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                         const double *__restrict__ val, const int *__restrict__ pofs,
+                                                         const int *__restrict__ pbase, const int *__restrict__ pcols,
+                                                         const double *__restrict__ x, double *__restrict__ y, const int *done, DotPlan dp)
+{
+    extern __shared__ double wlds[];                    // [16][64 * LP]
+    __shared__ double wsum[2][RUN1D_WG / 64];
+    __shared__ int arrived;
+    if (done && *done) return;
+    if (threadIdx.x == 0) arrived = 0;
+    __syncthreads();                                    // the only barrier, before anybody has started: costs nothing
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * (RUN1D_WG / 64) + wv;
+    double a0 = 0.0, a1 = 0.0;
+    if ((long)b * 64 < n) {
+        const long row = (long)b * 64 + lane;
+        const double uv = dp.u[row < n ? row : 0];      // requested ahead of the block's loads
+        const double v = run1_block<T>(b, wv, n, LP, rowptr, col, val, pofs, pbase, pcols, x, y, wlds);
+        a0 = wave_sum(v * uv);                          // v = 0 on the lanes past the end
+        if (dp.yy) a1 = wave_sum(v * v);
+    }
+    // No barrier at the end (a workgroup would hold its slots until its slowest wavefront -- the blocks that are not runs --
+    // is through): every wavefront leaves its sums in LDS and takes a ticket; whoever draws the last one adds them up in
+    // wavefront order (the LDS serves a wavefront's store before its ticket, so the last ticket sees every store).
+    if (lane == WSUM_LANE) {
+        wsum[0][wv] = a0; wsum[1][wv] = a1;
+        const int ticket = __hip_atomic_fetch_add(&arrived, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (ticket == RUN1D_WG / 64 - 1) {
+            double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < RUN1D_WG / 64; q++) { t0 += wsum[0][q]; t1 += wsum[1][q]; }
+            dp.part[blockIdx.x] = t0;
+            if (dp.yy) dp.part[dp.stride + blockIdx.x] = t1;
+        }
+    }
+}
+
 
 int device_exclusive_scan(int n, const int *counts, int *rowptr, hipStream_t s, long *total);
 
@@ -1076,6 +1133,26 @@ int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int 
         return 1;
     }
     const int nblk = (n + R - 1) / R;
+    static const bool run1_off = [] { const char *e = std::getenv("LCG_HIP_RUN1"); return e && atoi(e) == 0; }();
+    if (!run1_off && (R == 256 || R == 128) && packed_build(P, s, true) && P.pk_maxrow <= 32) {
+        // short-row stencils (k_spmv_run1d): eight wavefronts, one partial per workgroup of 512 rows
+        const int nwg = (int)((((long)n + 63) / 64 + RUN1D_WG / 64 - 1) / (RUN1D_WG / 64));
+        if (nwg <= AXP_CAP) {
+            DotPlan dp; dp.u = u; dp.part = part; dp.yy = yy;
+            const int LP = P.pk_maxrow | 1;
+            const size_t lds = sizeof(double) * (RUN1D_WG / 64) * 64 * (size_t)LP;
+            if (R == 256)
+                hipLaunchKernelGGL((k_spmv_run1d<1>), dim3(nwg), dim3(RUN1D_WG), lds, s, n, LP, P.rowptr, P.col, P.val, P.pk_ofs, P.pk_base,
+                                   static_cast<const int *>(P.pk_data), x, y, done, dp);
+            else
+                hipLaunchKernelGGL((k_spmv_run1d<2>), dim3(nwg), dim3(RUN1D_WG), lds, s, n, LP, P.rowptr, P.col, P.val, P.pk_ofs, P.pk_base,
+                                   static_cast<const int *>(P.pk_data), x, y, done, dp);
+            HIPCHK(hipGetLastError());
+            P.last_kernel = "k_spmv_run1d (one wavefront per 64-row block, run blocks without staging) carrying the dot that follows the product";
+            *slots = nwg;
+            return 1;
+        }
+    }
     // Where it pays (measured, scripts/ax_dot_lab.py + scripts/ab_small.py): systems whose iteration is a chain of kernel
     // latencies -- the product grows by ~0.6 us, a ~3 us pass and its launch go.  At 1M rows (3907 row blocks) the product grew by
     // 3.2 us and every block of the consuming pass re-added 3907 partials: 39.2 vs 38.5 us per PCG iteration, so from

@@ -290,9 +290,24 @@ def test_product_carrying_its_dot(api, port):
         first = (res[0], res[1])
         assert lib.lcg_hip_spmv_dot(A.h, xd.data_ptr(), y1.data_ptr(), ud.data_ptr(), res) == 0 and (res[0], res[1]) == first
         A.destroy()
-    # more row blocks than the threshold: two launches, same answers
+    # short-row stencils: the one-wavefront-per-block kernel carries the dot too (k_spmv_run1d, a ticket instead of a barrier)
     A = api.CsrMatrix.laplace2d(800, 800); n = 640000
     xd = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 3, 0, n, xd)
+    ud = torch.empty_like(xd); api.gen_xtrue(n, 8, 0, n, ud)
+    y0 = torch.empty_like(xd); y1 = torch.empty_like(xd)
+    A.spmv(xd, y0)
+    assert "k_spmv_run1 " in lib.lcg_hip_csr_last_kernel(A.h).decode()
+    for _ in range(2):
+        assert lib.lcg_hip_spmv_dot(A.h, xd.data_ptr(), y1.data_ptr(), ud.data_ptr(), res) == 0
+        assert "k_spmv_run1d" in lib.lcg_hip_csr_last_kernel(A.h).decode() and torch.equal(y0, y1)
+        assert abs(res[0] - float(y0 @ ud)) <= 1e-12 * float(y0.abs() @ ud.abs()) and abs(res[1] - float(y0 @ y0)) <= 1e-12 * float(y0 @ y0)
+    A.destroy()
+    # more row blocks than the threshold and no runs: two launches, same answers
+    n = 700000
+    rp, col = _ragged(rng, n, n, 9)
+    val = rng.standard_normal(rp[-1])
+    A = api.CsrMatrix.from_csr(rp, col, val)
+    xd = torch.from_numpy(rng.standard_normal(n)).cuda()
     y0 = torch.empty_like(xd); y1 = torch.empty_like(xd)
     A.spmv(xd, y0)
     assert lib.lcg_hip_spmv_dot(A.h, xd.data_ptr(), y1.data_ptr(), xd.data_ptr(), res) == 0
