@@ -52,3 +52,56 @@ def test_packed_columns_fuzz(port):
         A.destroy()
         done += 1
     assert done >= 30
+
+
+def test_run_blocks_fuzz(port):
+    """Mixtures of run blocks, near-runs and ragged blocks (csr.hip: k_pk_meta, the run paths of k_spmv_ldsp and k_spmv_run1):
+    every 64-row block of a matrix is drawn as (a) a run with its own L and offsets -- unsorted, with repeated columns now and
+    then --, (b) the same with one entry moved, (c) rows of equal length but unrelated columns, or (d) ragged rows; L short
+    (the one-wavefront-per-block kernel) or around 33 (the packed kernel).  The automatic choice must reproduce the plain
+    row-block kernel (packed copy switched off) bit for bit, and the oracle to 1e-12."""
+    from liblcg_amd import _lib, api
+    lib = _lib.load()
+    rng = np.random.default_rng(4242)
+    kernels = set()
+    for case in range(24):
+        short = case % 2 == 0
+        nblocks = int(rng.integers(1, 40))
+        n = 64 * nblocks - int(rng.integers(0, 64))
+        ncols = n + 6000
+        Lmain = int(rng.integers(1, 9)) if short else int(rng.integers(28, 36))
+        rows_cols = []
+        for b in range(nblocks):
+            r0, r1 = 64 * b, min(n, 64 * b + 64)
+            kind = rng.choice(["run", "run", "run", "near", "equal", "ragged"])
+            L = Lmain if rng.random() < 0.8 else max(1, Lmain + int(rng.integers(-2, 3)))
+            offs = rng.integers(0, 5000, L)                      # unsorted, repeats possible
+            for i in range(r0, r1):
+                if kind in ("run", "near"):
+                    c = i + offs
+                elif kind == "equal":
+                    c = rng.integers(0, ncols, L)
+                else:
+                    c = rng.integers(0, ncols, int(rng.integers(0, L + 3)))
+                rows_cols.append(np.asarray(c, np.int64))
+            if kind == "near" and r1 - r0 > 2 and L > 0:
+                i = int(rng.integers(r0 + 1, r1)); rows_cols[i] = rows_cols[i].copy(); rows_cols[i][int(rng.integers(0, L))] += 1
+        lens = np.array([len(c) for c in rows_cols])
+        rp = np.zeros(n + 1, np.int32); np.cumsum(lens, out=rp[1:])
+        if rp[-1] == 0:
+            continue
+        col = np.concatenate(rows_cols).astype(np.int32)
+        val = rng.standard_normal(rp[-1]); x = rng.standard_normal(ncols)
+        A = api.CsrMatrix.from_csr(rp, col, val, n_cols=ncols)
+        xd = torch.from_numpy(x).cuda()
+        y0 = torch.empty(n, dtype=torch.float64, device="cuda"); y1 = torch.full_like(y0, -3.0)
+        assert lib.lcg_hip_csr_set_packed(A.h, 0) == 0
+        A.spmv(xd, y0); api.synchronize()
+        assert lib.lcg_hip_csr_set_packed(A.h, 1) == 0           # short rows: runs only when most blocks are runs; else the packed copy
+        A.spmv(xd, y1); api.synchronize()
+        kernels.add(lib.lcg_hip_csr_last_kernel(A.h).decode().split(" ")[0])
+        assert torch.equal(y0, y1), (case, n, Lmain, lib.lcg_hip_csr_last_kernel(A.h))
+        ref = port.csr_matvec(rp, col, val, x)
+        assert np.abs(y1.cpu().numpy() - ref).max() <= 1e-12 * max(1e-300, np.abs(ref).max()), case
+        A.destroy()
+    assert {"k_spmv_run1", "k_spmv_ldsp"} <= kernels, kernels
