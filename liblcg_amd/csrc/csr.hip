@@ -996,7 +996,9 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
             if constexpr (!PUSH) {
                 // short rows whose blocks of 64 are mostly runs: one wavefront per block, no staging (k_spmv_run1)
                 static const bool run1_off = [] { const char *e = std::getenv("LCG_HIP_RUN1"); return e && atoi(e) == 0; }();
-                if (!run1_off && variant == -1 && (R == 256 || R == 128) && packed_build(P, s, true) && P.pk_maxrow <= 32) {
+                // (its wavefront-private LDS is dynamic: 4 wavefronts x 64 rows x LP doubles must stay within the 64 KB a launch
+                //  may ask for without further ado -- rows of up to 30 entries)
+                if (!run1_off && variant == -1 && (R == 256 || R == 128) && packed_build(P, s, true) && P.pk_maxrow <= 30) {
                     const unsigned g = (unsigned)(((n + 63) / 64 + VB / 64 - 1) / (VB / 64));
                     const int LP = P.pk_maxrow | 1;
                     const size_t lds = sizeof(double) * (VB / 64) * 64 * (size_t)LP;
@@ -1134,8 +1136,9 @@ int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int 
     }
     const int nblk = (n + R - 1) / R;
     static const bool run1_off = [] { const char *e = std::getenv("LCG_HIP_RUN1"); return e && atoi(e) == 0; }();
-    if (!run1_off && (R == 256 || R == 128) && packed_build(P, s, true) && P.pk_maxrow <= 32) {
-        // short-row stencils (k_spmv_run1d): eight wavefronts, one partial per workgroup of 512 rows
+    if (!run1_off && (R == 256 || R == 128) && packed_build(P, s, true) && P.pk_maxrow <= 15) {
+        // short-row stencils (k_spmv_run1d): eight wavefronts, one partial per workgroup of 512 rows (8 x 64 x LP doubles of
+        // dynamic LDS: rows of up to 15 entries; longer ones take the plain product and the separate pass)
         const int nwg = (int)((((long)n + 63) / 64 + RUN1D_WG / 64 - 1) / (RUN1D_WG / 64));
         if (nwg <= AXP_CAP) {
             DotPlan dp; dp.u = u; dp.part = part; dp.yy = yy;

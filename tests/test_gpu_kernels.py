@@ -152,8 +152,9 @@ def test_short_row_runs_one_wavefront_per_block(api, port):
     from liblcg_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(123)
+    res2 = (C.c_double * 2)()
     case = 0
-    for L in (1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17):
+    for L in (1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17):
         for n in (64, 1000, 6400 + 13, 50000):
             case += 1
             ncols = n + 3000
@@ -180,6 +181,15 @@ def test_short_row_runs_one_wavefront_per_block(api, port):
             assert torch.equal(y0, y1), (L, n)
             ref = port.csr_matvec(rp, col, val, x)
             assert np.abs(y1.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+            # the same product carrying y.u and y.y: k_spmv_run1d up to 15 entries per row (its eight wavefronts' LDS), the
+            # staged kernel's twin or two launches beyond -- y unchanged, sums to rounding
+            u = rng.standard_normal(n); ud = torch.from_numpy(u).cuda()
+            y1.fill_(7.0)
+            assert lib.lcg_hip_spmv_dot(A.h, xd.data_ptr(), y1.data_ptr(), ud.data_ptr(), res2) == 0
+            kern = lib.lcg_hip_csr_last_kernel(A.h).decode()
+            assert ("k_spmv_run1d" in kern) == (L <= 15), (L, n, kern)
+            assert torch.equal(y0, y1), (L, n, kern)
+            assert abs(res2[0] - float(ref @ u)) <= 1e-12 * float(np.abs(ref) @ np.abs(u)) and abs(res2[1] - float(ref @ ref)) <= 1e-12 * float(ref @ ref)
             A.destroy()
     # the Laplacian of configs[1] at a tenth of the size: mostly runs; a ragged matrix of the same density: none -> staged kernel
     A = api.CsrMatrix.laplace2d(400, 250); n = 100000
