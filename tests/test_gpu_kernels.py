@@ -547,3 +547,40 @@ def test_full_size_properties(api):
     assert ((m - xt).norm() / xt.norm()).item() <= 1e-5
     A.spmv(m, Ax); api.synchronize()
     assert ((Ax - b).norm().item() / n) <= 1.01e-10                       # the monitored quantity, recomputed
+
+
+@pytest.mark.parametrize("pattern", ["constant_diagonals", "row_random_band"])
+def test_near_the_int32_limit(api, pattern):
+    """The largest system the int32 CSR of the reference's interface can hold at this density: 60M rows, 1.98e9 entries
+    (92 % of 2^31), 24 GB of matrix -- entry offsets, the packed / tiled copies and the per-block tables all near their
+    limits.  Size-independent properties: linearity, A = A^T, agreement of the chosen kernel with a lanes-per-row kernel
+    down to the last rows, and a CG solve whose monitored residual is the residual of its answer."""
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    n = 60_000_000
+    A = api.CsrMatrix.generate(n, 16, 131072, True, 1, 0.01, pattern=api.GEN_DIAGONALS if pattern == "constant_diagonals" else api.GEN_ROW_RANDOM_BAND)
+    assert 0.9 * 2**31 < A.nnz < 2**31
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    y = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    Ax, Ay, Az = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    A.spmv(x, Ax); A.spmv(y, Ay); api.synchronize()
+    assert ("run blocks" if pattern == "constant_diagonals" else "k_tile_spmv") in lib.lcg_hip_csr_last_kernel(A.h).decode()
+    z = x + 2.0 * y
+    A.spmv(z, Az); api.synchronize()
+    assert (Az - (Ax + 2.0 * Ay)).abs().max().item() <= 1e-12 * Az.abs().max().item()
+    assert abs(api.dot(x, Ay) - api.dot(y, Ax)) <= 1e-12 * abs(api.dot(x, Ay))
+    del y, Ay, z
+    A.set_kernel(8); A.spmv(x, Az); api.synchronize(); A.set_kernel(0)
+    assert (Az - Ax).abs().max().item() <= 1e-12 * Ax.abs().max().item()
+    assert (Az[-4096:] - Ax[-4096:]).abs().max().item() <= 1e-12 * Ax.abs().max().item() and Ax[-4096:].abs().min().item() > 0
+    xt = torch.empty_like(x); api.gen_xtrue(n, 1, 0, n, xt)
+    b = torch.empty_like(x); A.spmv(xt, b); api.synchronize()
+    m = torch.zeros_like(x)
+    info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=1e-10, abs_diff=1), A, api.LCG_CG)
+    assert info.ret == 0 and info.residual <= 1e-10 and 50 <= info.iterations <= 400
+    assert ((m - xt).norm() / xt.norm()).item() <= 5.5e-5
+    A.spmv(m, Ax); api.synchronize()
+    true_res = (Ax - b).norm().item() / n
+    assert true_res <= 1.05e-10 and abs(true_res - info.residual) <= 0.05 * info.residual
+    A.destroy()
