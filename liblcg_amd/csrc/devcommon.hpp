@@ -235,7 +235,7 @@ __device__ __forceinline__ void push_block(const PushPlan &pp, int b)
 {
     int s = 0;
     while (s + 1 < pp.nseg && b >= pp.first_block[s + 1]) s++;
-    if (pp.nseg > 0) {
+    if (pp.nseg > 0 && threadIdx.x < VB) {     // (workgroups wider than VB threads -- k_tile_spmv2 -- push with their first VB)
         const long off = (long)(b - pp.first_block[s]) * PUSH_CHUNK;
         const long cnt = min((long)PUSH_CHUNK, pp.count[s] - off);
         const double *src = pp.src[s] + off;

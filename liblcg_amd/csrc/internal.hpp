@@ -245,6 +245,7 @@ int tiled_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, co
 void tiled_free(CsrPart &P);
 long tiled_traffic_bytes(const CsrPart &P);
 long tiled_tile_copy_bytes(const CsrPart &P);
+size_t tiled_plan_bytes(const CsrPart &P);
 int op_part(lcg_hip_csr *A, int layout, int conjugate, const CsrPart **out);
 
 // comm.hip

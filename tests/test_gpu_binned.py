@@ -168,7 +168,10 @@ def test_automatic_choice_and_solvers(api, lib, port):
         A.spmv(x, y); api.synchronize()
         assert want in lib.lcg_hip_csr_last_kernel(A.h), (pattern, lib.lcg_hip_csr_last_kernel(A.h), lib.lcg_hip_csr_binned_status(A.h), lib.lcg_hip_csr_tiled_status(A.h))
         if want != b"k_spmv_ldsp":
-            assert lib.lcg_hip_csr_last_traffic_model(A.h) >= 12 * A.nnz
+            # what the kernels stream by construction: binned 28.5 B per entry; tiled 2 KB per step of 192 entries (three
+            # 21-bit (row, column) pairs per 64-bit word: 10.67 B per entry) + x, y and the tile lists
+            model = lib.lcg_hip_csr_last_traffic_model(A.h)
+            assert (12 if want == b"k_bin_expand" else 10.66) * A.nnz <= model <= 40 * A.nnz, (want, model / A.nnz)
             assert lib.lcg_hip_csr_set_binned(A.h, 0) == 0 and lib.lcg_hip_csr_set_tiled(A.h, 0) == 0
             A.spmv(x, y2); api.synchronize()
             assert b"k_spmv" in lib.lcg_hip_csr_last_kernel(A.h)
