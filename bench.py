@@ -270,6 +270,7 @@ def main():
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": source, "bytes_per_launch": shard_bytes, "avg_launch_us": ax_us,
                            "launches": ax_calls}
+        out["roofline"].update(physical_fractions(lib, S.A, ax_us, traffic, sharded))
         if "k_spmv_ldsp" in kernel and "carrying the dot" in kernel:
             out["roofline"]["launch_note"] = ("avg_launch_us spans the product kernel AND k_axp_fold, the ~4 us second stage of the d.Ad sums it "
                                               "carries (rocprofv3 lists the two separately: profiles/*_kernel_stats.csv)")
@@ -289,9 +290,24 @@ def main():
             dst.copy_(src)
         torch.cuda.synchronize()
         copy_gbs = 10 * 2 * src.numel() * 8 / (time.perf_counter() - t0) / 1e9
-        out["roofline"]["device_copy_GBs_this_box"] = copy_gbs
-        out["roofline"]["frac_of_device_copy"] = out["roofline"]["achieved"] / copy_gbs
-        del src, dst
+        del dst
+        big = torch.ones(1 << 29, dtype=torch.float64, device="cuda")      # a pure read: the sum of 4 GiB
+        for _ in range(2):
+            big.sum()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            big.sum()
+        torch.cuda.synchronize()
+        read_gbs = 5 * big.numel() * 8 / (time.perf_counter() - t0) / 1e9
+        del src, big
+        rf = out["roofline"]
+        rf["device_copy_GBs_this_box"] = copy_gbs
+        rf["device_read_GBs_this_box"] = read_gbs
+        # `achieved` counts ALGORITHMIC bytes, more than a compressing kernel moves: beside a measured rate of this box
+        # it is an effective rate, not a physical one -- the physical one is must_move_GBs
+        rf["effective_over_device_copy"] = rf["achieved"] / copy_gbs
+        rf["must_move_over_device_read"] = rf["must_move_GBs"] / read_gbs if rf.get("must_move_GBs") else None
 
     if world == 1 and not sharded and not args.no_variants:
         out["variants"] = variants(args, System, S, lib, api, n, spmv_bytes, iteration_bytes)
@@ -327,9 +343,7 @@ def variants(args, System, S, lib, api, n, spmv_bytes, iteration_bytes):
                  "algorithmic_GBs": byts / (ax_us * 1e-6) / 1e9 if ax_us > 0 else None, "nnz": V.nnz,
                  "whole_iteration_algorithmic_GBs": iteration_bytes(V.nnz) / (med / args.steps) / 1e9,
                  "kernel": lib.lcg_hip_csr_last_kernel(V.A.h).decode()}
-        model = lib.lcg_hip_csr_last_traffic_model(V.A.h)
-        if model:
-            entry["streamed_bytes_by_construction"] = model
+        entry.update(physical_fractions(lib, V.A, ax_us, pmc_traffic(pattern, entry["kernel"], V.nnz)[0], False))
         if check:
             entry["solution_check"] = check
         res[pattern] = entry
@@ -337,6 +351,29 @@ def variants(args, System, S, lib, api, n, spmv_bytes, iteration_bytes):
             V.A.destroy()
             del V
     return res
+
+
+def physical_fractions(lib, A, ax_us, traffic, sharded):
+    """What moves, beside the contractual `frac` (algorithmic bytes of the CSR formula / time / 8 TB/s): `must_move_bytes` = what the
+    kernel family that ran streams by construction (values, its own column format, row pointers, x once, y:
+    lcg_hip_csr_last_traffic_model), `frac_must_move` = that / time / peak; `frac_traffic` = the PMC-counted bytes / time / peak
+    (when a collection on the same kernel exists); and what the first product paid for the kernel's copy of the matrix."""
+    import ctypes as C
+    out = {}
+    model = int(lib.lcg_hip_csr_last_traffic_model(A.h))
+    if model > 0 and ax_us > 0:
+        out["must_move_bytes"] = model
+        out["must_move_GBs"] = model / (ax_us * 1e-6) / 1e9
+        out["frac_must_move"] = out["must_move_GBs"] / HBM_PEAK_GBS
+        if sharded:
+            out["must_move_note"] = "local part of the shard only (the remote-column part and the exchange are not in the model)"
+    if traffic and ax_us > 0:
+        out["frac_traffic"] = traffic / (ax_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+    ms, extra = C.c_double(0.0), C.c_int64(0)
+    if lib.lcg_hip_csr_plan_info(A.h, C.byref(ms), C.byref(extra)) == 0:
+        out["plan_build_ms"] = ms.value
+        out["plan_extra_bytes"] = extra.value
+    return out
 
 
 def pmc_traffic(pattern, kernel, nnz=None):

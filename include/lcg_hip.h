@@ -216,27 +216,39 @@ int64_t lcg_hip_csr_packed_runs(lcg_hip_csr_t A, int64_t *blocks_out);
  * mode: -1 automatic (real matrices of >= 4M entries and >= 1M columns whose 64-row blocks span on average
  * >= 2^20 columns; LCG_HIP_BINNED_SPAN changes that threshold), 0 never (frees the plan), 1 whenever eligible.
  * LCG_HIP_BINNED=0/1 overrides for the whole process.  y differs from the row-block kernels' y in the last
- * bits (products are rounded before the add); it is bit-identical from call to call and from plan to plan.
+ * bits (products are rounded before the add); on gfx950 it is bit-identical from call to call and from plan to plan
+ * (lanes of one ds_add_f64 that meet in a row are serialised by the LDS in lane order: verified by test, not an ISA promise).
  * The packed, tiled and binned forms are COPIES of the matrix made at the first product: a caller who rewrites the
  * arrays of an adopted matrix (lcg_hip_csr_create with adopt != 0) afterwards drops them with set_*(A, 0) and
  * re-arms the automatic choice with set_*(A, -1). */
 int lcg_hip_csr_set_binned(lcg_hip_csr_t A, int mode);
 /* One-pass "tiled" A.x for matrices whose rows draw their columns at random from a band: the row-block kernels
- * find x in the L2 there but move a 128-byte line per 8-byte gather.  A workgroup owns 4 x 1024 rows (sums in LDS),
- * walks the column tiles they touch, copies each tile of x (4096 entries) into LDS and streams the rows' entries of
- * that tile (val + a 32-bit (row, column) pair: 12 B per entry, as CSR).  mode: -1 automatic (real matrices of
- * >= 4M entries whose columns do not run along diagonals and whose (workgroup, tile) pairs hold >= 500 entries on
+ * find x in the L2 there but move a 128-byte line per 8-byte gather.  A workgroup owns 8 x 1024 rows (sums in LDS),
+ * walks the column tiles they touch (2048 columns; a loader wavefront copies the next tile of x into LDS by LDS-DMA while
+ * eight consumer wavefronts stream the rows' entries of the current one: 2 KB per step of 192 entries = values + three
+ * 21-bit (row, column) pairs per 64-bit word, 10.67 B per entry where CSR has 12).  mode: -1 automatic (real matrices of
+ * >= 4M entries whose columns do not run along diagonals and whose (workgroup, tile) pairs hold >= 700 entries on
  * average: LCG_HIP_TILED_FILL), 0 never (frees the plan), 1 whenever eligible; LCG_HIP_TILED=0/1 overrides for the
- * process.  Same determinism and the same last-bit deviation from the row-block kernels as the binned product. */
+ * process.  Same last-bit deviation from the row-block kernels as the binned product; y is bit-identical from call to
+ * call and from plan to plan ON gfx950 (a row is summed by one wavefront in stream order; lanes of one ds_add_f64 that meet
+ * in a row are serialised by the LDS in lane order -- verified by tests/test_gpu_binned.py, not promised by the ISA). */
 int lcg_hip_csr_set_tiled(lcg_hip_csr_t A, int mode);
 const char *lcg_hip_csr_tiled_status(lcg_hip_csr_t A);
 /* Why A has (or has not) a binned plan: "ready", or the reason it is not used (static string). */
 const char *lcg_hip_csr_binned_status(lcg_hip_csr_t A);
 /* Name of the kernel family the latest product with A used (static string; "" before the first product). */
 const char *lcg_hip_csr_last_kernel(lcg_hip_csr_t A);
-/* Bytes the latest product's kernels stream per call by construction when that is not the CSR formula
- * (binned product: both passes, x slices and y); 0 otherwise. */
+/* Bytes the latest product's kernels stream from / to memory per call BY CONSTRUCTION -- what must move for the kernel
+ * family that ran: CSR row-block kernels 12 B per entry; packed columns 8 B + 16 B per group of 6-7 columns (run blocks:
+ * row 0's columns only); tiled product 2 KB per step of 192 entries (10.67 B per entry) + tile lists; binned product both
+ * passes (28.5 B per entry) -- each plus row pointers, x once and y.  0 for complex matrices and before the first product.
+ * (SURVEY's algorithmic figure, 12 nnz + 4 (N + 1) + 16 N, is what bench.py's roofline.achieved is quoted on; this is the
+ * physical companion: bench.py's roofline.must_move_bytes.) */
 int64_t lcg_hip_csr_last_traffic_model(lcg_hip_csr_t A);
+/* What the first product spent on A beside the CSR arrays: *build_ms = host time of choosing a kernel family and building
+ * its copy of the matrix (packed columns / tiled stream / binned streams; the builders drain the stream), *extra_bytes =
+ * device memory those copies hold.  Either pointer may be NULL. */
+int lcg_hip_csr_plan_info(lcg_hip_csr_t A, double *build_ms, int64_t *extra_bytes);
 /* Extract the diagonal and keep its reciprocal for lcg_hip_jacobi_mx
  * (lcg_smDcsr_get_diagonal algebra_cuda.cu:40-57,85-92; clcg_smZcsr_get_diagonal
  * lcg_complex_cuda.cu:46-63).  diag_out (device, n values) may be NULL. */

@@ -77,6 +77,7 @@ SIGNATURES = {
     "lcg_hip_csr_binned_status": (C.c_char_p, [vp]),
     "lcg_hip_csr_last_kernel": (C.c_char_p, [vp]),
     "lcg_hip_csr_last_traffic_model": (C.c_int64, [vp]),
+    "lcg_hip_csr_plan_info": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "lcg_hip_csr_build_jacobi": (C.c_int, [vp, vp]),
     "lcg_hip_csr_ax": (None, [vp, vp, vp, C.c_int]),
     "lcg_hip_jacobi_mx": (None, [vp, vp, vp, C.c_int]),

@@ -27,6 +27,8 @@
 #include <functional>
 #include <numeric>
 
+#include <chrono>
+
 #include "devcommon.hpp"
 
 namespace lcgh {
@@ -773,6 +775,12 @@ int device_exclusive_scan(int n, const int *counts, int *rowptr, hipStream_t s, 
 // Build the packed columns of P once (device; two short synchronisations).  Returns true when ready.
 // runs_only (k_spmv_run1, short rows): only the run blocks get anything -- row 0's columns; the other blocks are walked
 // from the CSR arrays -- so the copy costs a few integers per block, and small systems take it too (pk_state = 2).
+struct PlanTimer {      // adds the host time of a build (it ends on a drained stream) to the part's plan_ms
+    const CsrPart &P; hipStream_t s; std::chrono::steady_clock::time_point t0;
+    PlanTimer(const CsrPart &p, hipStream_t st) : P(p), s(st), t0(std::chrono::steady_clock::now()) {}
+    ~PlanTimer() { (void)hipStreamSynchronize(s); P.plan_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only)
 {
     if (P.pk_state != 0) return P.pk_state == (runs_only ? 2 : 1);
@@ -781,6 +789,7 @@ static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only)
     const int mode = env >= 0 ? env : P.pk_mode;
     if (mode == 0) return false;
     if (!runs_only && mode < 0 && P.nnz < (1 << 22)) return false;       // small systems are launch-bound: not worth the memory
+    PlanTimer timer(P, s);
     const int n = P.n_rows;
     const int nb = (n + PK_R - 1) / PK_R;
     int *ngr = nullptr, *span = nullptr;
@@ -857,9 +866,12 @@ static bool binned_chosen(const CsrPart &P, hipStream_t s)
     static const int env = [] { const char *e = std::getenv("LCG_HIP_BINNED"); return e ? atoi(e) : -1; }();
     const int mode = env >= 0 ? env : P.bn_mode;
     if (mode == 0 || P.n_cols <= 0 || P.nnz <= 0) { P.bn_state = -1; P.bn_why = mode == 0 ? "switched off" : "empty matrix or unknown column count"; return false; }
-    if (mode < 0) {
+    if (mode < 0 && (P.nnz < (1 << 22) || P.n_cols < (1 << 20))) {
         // automatic: only where x cannot sit in a cache (>= 1M columns) and the matrix is worth a second copy
-        if (P.nnz < (1 << 22) || P.n_cols < (1 << 20)) { P.bn_state = -1; P.bn_why = "automatic mode: fewer than 4M entries or 1M columns"; return false; }
+        P.bn_state = -1; P.bn_why = "automatic mode: fewer than 4M entries or 1M columns"; return false;
+    }
+    PlanTimer timer(P, s);
+    if (mode < 0) {
         if (P.mean_span < 0.0) {
             unsigned long long *d = nullptr, h = 0;
             const int nb = (P.n_rows + PK_R - 1) / PK_R;
@@ -902,9 +914,10 @@ static bool tiled_chosen(const CsrPart &P, hipStream_t s)
     static const int env = [] { const char *e = std::getenv("LCG_HIP_TILED"); return e ? atoi(e) : -1; }();
     const int mode = env >= 0 ? env : P.tl_mode;
     if (mode == 0 || P.n_cols <= 0 || P.nnz <= 0) { P.tl_state = -1; P.tl_why = mode == 0 ? "switched off" : "empty matrix or unknown column count"; return false; }
+    if (mode < 0 && (P.nnz < (1 << 22) || P.n_cols < (1 << 18))) { P.tl_state = -1; P.tl_why = "automatic mode: fewer than 4M entries or 256K columns"; return false; }
+    PlanTimer timer(P, s);
     double min_fill = 0.0;
     if (mode < 0) {
-        if (P.nnz < (1 << 22) || P.n_cols < (1 << 18)) { P.tl_state = -1; P.tl_why = "automatic mode: fewer than 4M entries or 256K columns"; return false; }
         if (P.diag_like < 0.0) {
             unsigned long long *d = nullptr, h = 0;
             bool ok = hipMalloc(&d, sizeof h) == hipSuccess && hipMemsetAsync(d, 0, sizeof h, s) == hipSuccess;
@@ -917,7 +930,9 @@ static bool tiled_chosen(const CsrPart &P, hipStream_t s)
             P.diag_like = (double)h / (double)P.nnz;
         }
         if (P.diag_like > 0.5) { P.tl_state = -1; P.tl_why = "automatic mode: the columns run along diagonals (the row-block kernels gather contiguously)"; return false; }
-        static const double fill = [] { const char *e = std::getenv("LCG_HIP_TILED_FILL"); return e ? atof(e) : 500.0; }();
+        // least mean number of entries per (workgroup of 8192 rows, tile of 2048 columns) pair.  Measured at N = 1e7, 33 per row (round 3):
+        // W = 524288, 1052 per pair: tiled 1.01-1.17 ms, binned 1.70; W = 1048576, 527 per pair: tiled 1.96 ms, binned 1.72
+        static const double fill = [] { const char *e = std::getenv("LCG_HIP_TILED_FILL"); return e ? atof(e) : 700.0; }();
         min_fill = fill;
     }
     const int rc = tiled_ready(P, s, min_fill);
@@ -1895,9 +1910,37 @@ int64_t lcg_hip_csr_packed_runs(lcg_hip_csr_t A, int64_t *blocks_out)
 
 int64_t lcg_hip_csr_last_traffic_model(lcg_hip_csr_t A)
 {
-    if (!A) return 0;
+    if (!A || A->is_complex) return 0;
     const CsrPart &P = A->distributed ? A->loc : A->main;
-    return P.bn_state > 0 ? binned_traffic_bytes(P) : (P.tl_state > 0 ? tiled_traffic_bytes(P) : 0);
+    const char *k = P.last_kernel;
+    if (!k || !*k) return 0;
+    const int64_t n = P.n_rows, ncols = P.n_cols > 0 ? P.n_cols : P.n_rows;
+    const int64_t vectors = 4 * (n + 1) + 8 * ncols + 8 * n;       // row pointers, x once, y
+    const int64_t nb = (n + PK_R - 1) / PK_R;
+    if (std::strncmp(k, "k_bin_", 6) == 0) return binned_traffic_bytes(P);
+    if (std::strncmp(k, "k_tile", 6) == 0) return tiled_traffic_bytes(P);
+    if (std::strncmp(k, "k_spmv_ldsp", 11) == 0)       // values + packed columns (run blocks: row 0's columns only) + two words per block
+        return 8 * P.nnz + 16 * (int64_t)P.pk_groups + 8 * nb + vectors;
+    if (std::strncmp(k, "k_spmv_run1", 11) == 0) {     // values + row 0's columns of the run blocks + the CSR columns of the other blocks
+        const double other = nb > 0 ? 1.0 - (double)P.pk_runs / (double)nb : 1.0;
+        return 8 * P.nnz + (int64_t)(4.0 * other * (double)P.nnz) + 16 * (int64_t)P.pk_groups + 8 * nb + vectors;
+    }
+    return 12 * P.nnz + vectors;                        // the CSR arrays as they are
+}
+
+int lcg_hip_csr_plan_info(lcg_hip_csr_t A, double *build_ms, int64_t *extra_bytes)
+{
+    if (!A) return LCG_HIP_E_ARG;
+    const CsrPart &P = A->distributed ? A->loc : A->main;
+    if (build_ms) *build_ms = P.plan_ms;
+    if (extra_bytes) {
+        int64_t b = 0;
+        if (P.pk_state > 0) b += 16 * ((int64_t)P.pk_groups + 4) + 8 * (((int64_t)P.n_rows + PK_R - 1) / PK_R + 1);
+        if (P.bn_plan) b += (int64_t)binned_plan_bytes(P);
+        if (P.tl_plan) b += (int64_t)tiled_plan_bytes(P);
+        *extra_bytes = b;
+    }
+    return 0;
 }
 
 int lcg_hip_csr_build_jacobi(lcg_hip_csr_t A, double *diag_out)

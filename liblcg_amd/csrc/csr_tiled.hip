@@ -103,7 +103,8 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_tile_spmv2(int n, int nwg, co
     const int nt = ntile[g];
     const int so = sofs[g];
     if (w == NW) {
-        // ---- the loader: tile j into half j & 1 of the buffer; barrier j tells the consumers it has landed, and tells the
+        // ---- the loader (a second loader wavefront sharing the tile was measured: 1175 -> 1105 us where the tiles come from beyond
+        // the L2 -- W = 524288 --, nothing where they do not): tile j into half j & 1 of the buffer; barrier j tells the consumers it has landed, and tells the
         // loader that they are through with tile j - 1, whose half tile j + 1 goes into
         const bool x16 = (((uintptr_t)x) & 15) == 0;
         for (int j = 0; j < nt; j++) {
@@ -168,7 +169,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_tile_spmv2(int n, int nwg, co
                 const double a0 = v0[i], a1 = v1[i], a2 = v2[i];
                 const u64t id = ia[i];
                 const unsigned e0 = (unsigned)id & TL_EMASK, e1 = (unsigned)(id >> 21) & TL_EMASK, e2 = (unsigned)(id >> 42) & TL_EMASK;
-                const int q0 = TL_STEP * s + l, q1 = q0 + 64, q2 = q0 + 128;   // this lane's three entries, relative to the bin
+                // this lane's three entries, relative to the bin: CONSECUTIVE positions, so that the entries a row has in one tile --
+                // neighbours in the stream -- meet in one lane and not in one ds_add_f64 (same-address lanes serialise)
+                const int q0 = TL_STEP * s + 3 * l, q1 = q0 + 1, q2 = q0 + 2;
                 const int send = TL_STEP * (s + 1);
                 for (;;) {
                     const bool m0 = q0 >= a && q0 < b, m1 = q1 >= a && q1 < b, m2 = q2 >= a && q2 < b;
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(64) void k_tl_place(int n, int TL_NW, const int *__
             int lo = r0, hi = r1 - 1;
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (rowptr[mid] <= k) lo = mid; else hi = mid - 1; }
             const int p = gs[cmap[so + t] * TL_NW + w] + rank;          // position in the bin
-            const int st = p / TL_STEP, r = p - st * TL_STEP, pl = r >> 6, ln = r & 63;
+            const int st = p / TL_STEP, r = p - st * TL_STEP, ln = r / 3, pl = r - 3 * ln;
             u64t *blk = sb + (long)st * TL_BLK;
             // a step's block: words [2 l + k] = plane k < 2 of lane l, [128 + 2 l] = plane 2, [128 + 2 l + 1] = the packed pairs
             blk[pl < 2 ? 2 * ln + pl : 128 + 2 * ln] = (u64t)__double_as_longlong(val[k]);

@@ -190,6 +190,7 @@ struct CsrPart {
     mutable void *tl_plan = nullptr;
     mutable const char *tl_why = "not tried";
     mutable const char *last_kernel = "";   // name of the kernel family the latest product used
+    mutable double plan_ms = 0.0;           // host time spent choosing a kernel family and building its copy of the matrix (first product)
 };
 
 } // namespace lcgh
