@@ -88,6 +88,12 @@ def main(ref_path, out_path):
         assert lib.lcg_hip_barrier() == 0
         dist.barrier()
         A.destroy()
+    if "cplx/x1" not in ref.files:      # the full-size run of tests/test_gpu_config3.py carries no complex case
+        dist.barrier()
+        lib.lcg_hip_p2p_disconnect()
+        dist.destroy_process_group()
+        json.dump(res, open(out_path, "w"))
+        return
     # complex system (bundled case_10K_cA, complex symmetric): row slice with GLOBAL columns, 16-byte
     # elements through the pushes, the landing zone and the remote-column product
     from liblcg_amd.coo_io import coo_to_csr_host, read_coo_system
