@@ -285,6 +285,37 @@ __global__ __launch_bounds__(VB) void k_scatter_add(int nr, const int *__restric
     const int j = blockIdx.x * VB + threadIdx.x;
     if (j < nr) { const int i = rows[j]; y[i] = vadd(y[i], part[j]); }
 }
+// a block's share of sum_j u[row_j] * (what the block added to y[row_j]): the remote-column part of the y.u a sharded product
+// carries (the local product leaves the rest: csr.hip, csr_part_ax_dot) -- one partial per block, fixed order
+// `big` (may be null): the local product's per-block sums; this block also adds its slice [blockIdx * per, + per) of them -- the
+// second stage of the local sums costs no launch of its own
+__device__ __forceinline__ void block_dot_store(double c, double *out, const double *__restrict__ big = nullptr, int nbig = 0, int per = 0)
+{
+    __shared__ double sh[VB / 64];
+    if (big) {
+        const int lo = blockIdx.x * per, hi = min(nbig, lo + per);
+        for (int j = lo + (int)threadIdx.x; j < hi; j += VB) c += big[j];
+    }
+    const double t = wave_sum(c);
+    if ((threadIdx.x & 63) == WSUM_LANE) sh[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < VB / 64; k++) v += sh[k];
+        out[blockIdx.x] = v;
+    }
+}
+__global__ __launch_bounds__(VB) void k_scatter_add_dot(int nr, const int *__restrict__ rows, const double *__restrict__ part,
+                                                        double *__restrict__ y, const double *__restrict__ u, double *__restrict__ dot_out,
+                                                        const double *__restrict__ big, int nbig, int per, const int *done)
+{
+    if (done && *done) return;
+    const int j = blockIdx.x * VB + threadIdx.x;
+    double c = 0.0;
+    if (j < nr) { const int i = rows[j]; const double p = part[j]; y[i] += p; c = u[i] * p; }
+    block_dot_store(c, dot_out, big, nbig, per);
+}
 
 static int alloc_cols(CsrPart &P, int n, long nnz, bool cplx)
 {
@@ -470,12 +501,15 @@ __device__ __forceinline__ double2 ld_land(const double2 *p)
 }
 // LAND: no k_recv in front -- every block waits for the neighbours' flags itself and gathers x straight
 // from the uncached landing zone with system-scope loads (xfull then IS the landing-zone half of this call).
-template <class V, int T, bool TOY, bool LAND = false>
+template <class V, int T, bool TOY, bool LAND = false, bool DOT = false>
 __global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                const V *__restrict__ val, const int *__restrict__ rows,
                                                const V *__restrict__ xfull, V *__restrict__ y, const int *done,
-                                               WaitPlan wp = WaitPlan(), DevState *st = nullptr)
+                                               WaitPlan wp = WaitPlan(), DevState *st = nullptr,
+                                               const double *__restrict__ u = nullptr, double *__restrict__ dot_out = nullptr,
+                                               const double *__restrict__ big = nullptr, int nbig = 0, int per = 0)
 {
+    static_assert(!DOT || (TOY && !LAND && sizeof(V) == 8), "the remote part carries its share of y.u in the single-stream real form");
     if (LAND && !wait_flags<false>(wp)) {
         if (st && blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->status = ST_COMM; }
         return;
@@ -511,6 +545,7 @@ __global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ r
 #pragma unroll
     for (int off = T / 2; off > 0; off >>= 1) acc = vadd(acc, shfl_down_v(acc, off, T));
     if (j < nr && lane == 0) { if (TOY) y[i] = vadd(yold, acc); else y[j] = acc; }
+    if constexpr (DOT) block_dot_store((j < nr && lane == 0) ? u[i] * acc : 0.0, dot_out, big, nbig, per);
 }
 
 static void direct_free(lcg_hip_csr *A)
@@ -804,9 +839,14 @@ int dist_spmv_op(lcg_hip_csr *A, const CsrPart &T, const double *x, double *y)
     return 0;
 }
 
-int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
+// u != nullptr: the product also leaves y.u as partial sums in part[0 .. *slots) -- the local product's (folded to <= 512), then one per
+// block of the remote-column finisher.  *fused says whether it did (when not, the plain product was made).
+static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const double *u, double *part, int *slots, bool *fused)
 {
     Ctx &c = ctx();
+    if (fused) *fused = false;
+    bool dot = u != nullptr && !A->is_complex;
+    int nslot = 0;
     const size_t w = A->is_complex ? 2 : 1;
     const int *done = c.in_solve ? &c.state->done : nullptr;
     if (A->dist_mode < 0) {
@@ -834,7 +874,20 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
         const double mean_l = A->n_rows ? (double)A->loc.nnz / A->n_rows : 0.0;
         // test hook (tests/test_gpu_direct.py): this rank computes but never pushes -- what a dead link looks like to its neighbours
         static const bool withhold = std::getenv("LCG_HIP_TEST_WITHHOLD_PUSH") != nullptr;
-        int rc = withhold ? spmv_launch(A->loc, A->is_complex, A->variant, mean_l, x, y, false, c.stream, done)
+        static const bool one_stream_ = [] { const char *e = std::getenv("LCG_HIP_DIRECT_STREAMS"); return !(e && atoi(e) == 2); }();
+        static const bool land_ = [] { const char *e = std::getenv("LCG_HIP_DIRECT_LAND"); return e && atoi(e) == 1; }();
+        // the remote part's share of the dot rides in the single-stream k_remote; its blocks must fit behind the local sums
+        const long rem_blocks = A->remc.n_rows > 0 ? ((long)A->remc.n_rows * 4 + VB - 1) / VB : 0;
+        dot = dot && !withhold && one_stream_ && !land_ && 512 + rem_blocks <= AXP_CAP;
+        int rc = 0, f = 0;
+        int nbig = 0;       // per-block sums of the local product the finisher folds (0: the local product folded them itself)
+        if (dot) {
+            f = csr_part_ax_dot(A->loc, A->variant, mean_l, x, y, u, 0, part, &nslot, c.stream, done, &pp, A->remc.n_rows > 0 ? &nbig : nullptr);
+            if (f < 0) return f;
+        }
+        dot = f == 1;
+        if (!dot)
+            rc = withhold ? spmv_launch(A->loc, A->is_complex, A->variant, mean_l, x, y, false, c.stream, done)
                           : spmv_launch_push(A->loc, A->is_complex, A->variant, mean_l, x, y, c.stream, done, pp);
         if (rc) return rc;
         // One stream by default: product (+ pushing blocks) | k_recv | k_remote, no event at all.
@@ -893,12 +946,21 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
             hipLaunchKernelGGL((k_remote<double, TT, true, true>), dim3(g), dim3(VB), 0, rs, nr, A->remc.rowptr, A->remc.col, \
                                A->remc.val, A->rem_rows, landing, y, done, wp, st);                                  \
     } while (0)
-#define REMOTE_CASE(TT) case TT: if (land) REMOTE_LAND(TT); else if (one_stream) REMOTE_LAUNCH(TT, true, y); else REMOTE_LAUNCH(TT, false, sums); break;
+#define REMOTE_DOT(TT)                                                                                               \
+    do {                                                                                                             \
+        const unsigned g = (unsigned)(((long)nr * TT + VB - 1) / VB);                                                \
+        hipLaunchKernelGGL((k_remote<double, TT, true, false, true>), dim3(g), dim3(VB), 0, rs, nr, A->remc.rowptr, A->remc.col, \
+                           A->remc.val, A->rem_rows, A->xfull, y, done, WaitPlan(), (DevState *)nullptr, u, part + nslot, \
+                           nbig ? A->loc.dot_part : nullptr, nbig, (int)((nbig + g - 1) / g));                           \
+        nslot += (int)g;                                                                                             \
+    } while (0)
+#define REMOTE_CASE(TT) case TT: if (dot) REMOTE_DOT(TT); else if (land) REMOTE_LAND(TT); else if (one_stream) REMOTE_LAUNCH(TT, true, y); else REMOTE_LAUNCH(TT, false, sums); break;
             switch (T) {
                 REMOTE_CASE(1) REMOTE_CASE(2) REMOTE_CASE(4)
             default: return fail(hipErrorInvalidValue, "bad lanes-per-row for the remote-column product", __FILE__, __LINE__);
             }
 #undef REMOTE_CASE
+#undef REMOTE_DOT
 #undef REMOTE_LAND
 #undef REMOTE_LAUNCH
             HIPCHK(hipGetLastError());
@@ -918,6 +980,7 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
             HIPCHK(hipEventRecord(c.ev_b, rs));
             HIPCHK(hipStreamWaitEvent(c.stream, c.ev_b, 0));
         }
+        if (dot) { *slots = nslot; *fused = true; }
         return 0;
     }
     double *mine = A->xfull + w * (size_t)(A->row0);
@@ -945,9 +1008,31 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
     HIPCHK(hipEventRecord(c.ev_b, c.comm_stream));
     // ... while the locally-owned columns are multiplied here; then y[row] += rem_y
     const double mean_l = A->n_rows ? (double)A->loc.nnz / A->n_rows : 0.0;
-    rc = spmv_launch(A->loc, A->is_complex, A->variant, mean_l, x, y, false, c.stream, done);
+    int nbig01 = 0;
+    {
+        const long rem_blocks = (A->remc.n_rows + VB - 1) / VB;
+        dot = dot && 512 + rem_blocks <= AXP_CAP;
+        int f = 0;
+        if (dot) {
+            f = csr_part_ax_dot(A->loc, A->variant, mean_l, x, y, u, 0, part, &nslot, c.stream, done, nullptr, A->remc.n_rows > 0 ? &nbig01 : nullptr);
+            if (f < 0) return f;
+        }
+        dot = f == 1;
+    }
+    if (!dot) rc = spmv_launch(A->loc, A->is_complex, A->variant, mean_l, x, y, false, c.stream, done);
     if (rc) return rc;
     HIPCHK(hipStreamWaitEvent(c.stream, c.ev_b, 0));
+    if (dot) {
+        if (A->remc.n_rows > 0) {
+            const unsigned g = (unsigned)((A->remc.n_rows + VB - 1) / VB);
+            hipLaunchKernelGGL(k_scatter_add_dot, dim3(g), dim3(VB), 0, c.stream, A->remc.n_rows, A->rem_rows, A->rem_y, y, u, part + nslot,
+                               nbig01 ? A->loc.dot_part : nullptr, nbig01, (int)((nbig01 + g - 1) / g), done);
+            HIPCHK(hipGetLastError());
+            nslot += (int)g;
+        }
+        *slots = nslot; *fused = true;
+        return 0;
+    }
     if (A->remc.n_rows > 0) {
         const unsigned g = (unsigned)((A->remc.n_rows + VB - 1) / VB);
         if (A->is_complex)
@@ -959,6 +1044,16 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y)
         HIPCHK(hipGetLastError());
     }
     return rc;
+}
+
+int dist_spmv(lcg_hip_csr *A, const double *x, double *y) { return dist_spmv_impl(A, x, y, nullptr, nullptr, nullptr, nullptr); }
+
+int dist_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots)
+{
+    static const bool off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_SHARDED"); return e && atoi(e) == 0; }();     // A/B runs
+    bool fused = false;
+    const int rc = dist_spmv_impl(A, x, y, (yy || off) ? nullptr : u, part, slots, &fused);
+    return rc ? (rc > 0 ? -rc : rc) : (fused ? 1 : 2);
 }
 
 } // namespace lcgh

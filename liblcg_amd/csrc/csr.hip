@@ -413,7 +413,6 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
                                                   const double *__restrict__ val, const double *__restrict__ x,
                                                   double *__restrict__ y, const int *done, PushPlan pp, DotPlan dp)
 {
-    static_assert(!(PUSH && DOT), "the sharded product keeps its dots in their own pass");
     if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
     const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
     constexpr int R = PK_R;
@@ -1104,13 +1103,65 @@ int spmv_launch_push(const CsrPart &P, bool is_complex, int variant, double mean
     return spmv_dispatch<double, false, true>(P, variant, mean_row, x, y, s, done, pp);
 }
 
-// A.x with the dot(s) that follow it in the Krylov loops carried in the product (k_spmv_lds1d): one GPU, real, the LDS-staged
-// one-window family.  Everything else answers 0 and the caller multiplies and reduces in two launches as before.
+// The packed kernel carrying y.u (and y.y): one partial per block of 64 rows into a buffer of the part's own, folded to <= 512 sums
+// by a second small kernel into part[0 .. *slots) (y.y: part[AXP_CAP ..)) -- together they replace a pass over two vectors of the
+// part's height.  pp != nullptr: the product of a row shard with its pushing blocks in front (comm.hip).  1 = launched, 0 = this
+// part does not take the packed kernel (nothing was launched), < 0 failure.
+// nofold != nullptr: the second stage is left to the caller (comm.hip folds the per-block sums in the kernel that finishes the
+// shard's product anyway): *nofold = number of per-block sums waiting in P.dot_part, nothing is written to `part`.
+int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double *x, double *y, const double *u, int yy, double *part,
+                    int *slots, hipStream_t s, const int *done, const PushPlan *pp, int *nofold)
+{
+    const int n = P.n_rows;
+    if (n <= 0 || (variant != 0 && variant != -1)) return 0;
+    if (mean_row > 160.0 || ((((uintptr_t)P.val | (uintptr_t)P.col) & 15) != 0)) return 0;
+    if ((!pp && binned_chosen(P, s)) || tiled_chosen(P, s)) return 0;
+    int R = 0; bool onewin = false;
+    { int rc = lds_shape<double>(P, -1, mean_row, s, &R, &onewin); if (rc) return rc; }
+    if (!onewin || R != PK_R || !packed_ready(P, s)) return 0;
+    static const bool big_off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_PACKED"); return e && atoi(e) == 0; }();
+    if (big_off) return 0;
+    const int nblk = (n + PK_R - 1) / PK_R;
+    if (!P.dot_part && hipMalloc(&P.dot_part, sizeof(double) * 2 * (size_t)nblk) != hipSuccess) { (void)hipGetLastError(); P.dot_part = nullptr; return 0; }
+    DotPlan dp; dp.u = u; dp.part = P.dot_part; dp.yy = yy; dp.stride = nblk;
+    const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);
+    const int ns = per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
+    const PushPlan ppv = pp ? *pp : PushPlan();
+    const unsigned xb = pp ? (unsigned)pp->nblocks : 0u;
+#define PKD_LAUNCH(PU, NSS, BB)                                                                                     \
+        hipLaunchKernelGGL((k_spmv_ldsp<PU, NSS, BB, true>), dim3(nblk + xb), dim3(VB), 0, s, n, P.rowptr,          \
+                           static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, P.val, x, y, done, ppv, dp)
+#define PKD_CASE(NSS)                                                                                               \
+    case NSS:                                                                                                       \
+        if (pp) { if (P.pk_bits == 18) PKD_LAUNCH(true, NSS, 18); else PKD_LAUNCH(true, NSS, 21); }                 \
+        else { if (P.pk_bits == 18) PKD_LAUNCH(false, NSS, 18); else PKD_LAUNCH(false, NSS, 21); }                  \
+        break;
+    switch (ns) { PKD_CASE(8) PKD_CASE(9) PKD_CASE(10) PKD_CASE(12) }
+#undef PKD_LAUNCH
+#undef PKD_CASE
+    HIPCHK(hipGetLastError());
+    P.last_kernel = P.pk_runs > 0 ? "k_spmv_ldsp (LDS-staged, run blocks + packed columns) carrying the dot that follows the product"
+                                  : "k_spmv_ldsp (LDS-staged, packed columns) carrying the dot that follows the product";
+    if (nofold) { *nofold = nblk; *slots = 0; return 1; }
+    const int g2 = std::min(512, (nblk + VB - 1) / VB);
+    const int per = (nblk + g2 - 1) / g2;
+    hipLaunchKernelGGL(k_axp_fold, dim3((nblk + per - 1) / per), dim3(VB), 0, s, P.dot_part, nblk, nblk, per, yy, part, done);
+    HIPCHK(hipGetLastError());
+    P.last_kernel = P.pk_runs > 0 ? "k_spmv_ldsp (LDS-staged, run blocks + packed columns) carrying the dot that follows the product"
+                                  : "k_spmv_ldsp (LDS-staged, packed columns) carrying the dot that follows the product";
+    *slots = (nblk + per - 1) / per;
+    return 1;
+}
+
+// A.x with the dot(s) that follow it in the Krylov loops carried in the product (k_spmv_lds1d / k_spmv_ldsp<DOT> / k_spmv_run1d): real
+// matrices, the LDS-staged one-window family.  Everything else answers 0 and the caller multiplies and reduces in two launches as before.
+int dist_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots);     // comm.hip
 int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots, hipStream_t s,
                const int *done)
 {
     static const bool off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT"); return e && atoi(e) == 0; }();
-    if (off || !A || A->is_complex || A->distributed || A->n_rows <= 0) return 0;
+    if (off || !A || A->is_complex || A->n_rows <= 0) return 0;
+    if (A->distributed) return dist_ax_dot(A, x, y, u, yy, part, slots);
     const CsrPart &P = A->main;
     const int n = P.n_rows;
     if (A->variant != 0 && A->variant != -1) return 0;
@@ -1119,36 +1170,7 @@ int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int 
     int R = 0; bool onewin = false;
     { int rc = lds_shape<double>(P, -1, A->mean_row, s, &R, &onewin); if (rc) return rc; }
     if (!onewin) return 0;
-    if (R == PK_R && packed_ready(P, s)) {
-        // the packed kernel (large matrices): one partial per block of 64 rows into a buffer of the matrix's own, folded to
-        // <= 512 sums by a second small kernel -- together they replace a pass over two vectors of the matrix's height
-        static const bool big_off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_PACKED"); return e && atoi(e) == 0; }();
-        if (big_off) return 0;
-        const int nblk = (n + PK_R - 1) / PK_R;
-        if (!P.dot_part && hipMalloc(&P.dot_part, sizeof(double) * 2 * (size_t)nblk) != hipSuccess) { (void)hipGetLastError(); P.dot_part = nullptr; return 0; }
-        DotPlan dp; dp.u = u; dp.part = P.dot_part; dp.yy = yy; dp.stride = nblk;
-        const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);
-        const int ns = per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
-#define PKD_LAUNCH(NSS, BB)                                                                                         \
-        hipLaunchKernelGGL((k_spmv_ldsp<false, NSS, BB, true>), dim3(nblk), dim3(VB), 0, s, n, P.rowptr,            \
-                           static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, P.val, x, y, done, PushPlan(), dp)
-#define PKD_CASE(NSS)                                                                                               \
-    case NSS:                                                                                                       \
-        if (P.pk_bits == 18) PKD_LAUNCH(NSS, 18); else PKD_LAUNCH(NSS, 21);                                        \
-        break;
-        switch (ns) { PKD_CASE(8) PKD_CASE(9) PKD_CASE(10) PKD_CASE(12) }
-#undef PKD_LAUNCH
-#undef PKD_CASE
-        HIPCHK(hipGetLastError());
-        const int g2 = std::min(512, (nblk + VB - 1) / VB);
-        const int per = (nblk + g2 - 1) / g2;
-        hipLaunchKernelGGL(k_axp_fold, dim3((nblk + per - 1) / per), dim3(VB), 0, s, P.dot_part, nblk, nblk, per, yy, part, done);
-        HIPCHK(hipGetLastError());
-        P.last_kernel = P.pk_runs > 0 ? "k_spmv_ldsp (LDS-staged, run blocks + packed columns) carrying the dot that follows the product"
-                                      : "k_spmv_ldsp (LDS-staged, packed columns) carrying the dot that follows the product";
-        *slots = (nblk + per - 1) / per;
-        return 1;
-    }
+    if (R == PK_R && packed_ready(P, s)) return csr_part_ax_dot(P, A->variant, A->mean_row, x, y, u, yy, part, slots, s, done, nullptr, nullptr);
     const int nblk = (n + R - 1) / R;
     static const bool run1_off = [] { const char *e = std::getenv("LCG_HIP_RUN1"); return e && atoi(e) == 0; }();
     if (!run1_off && (R == 256 || R == 128) && packed_build(P, s, true) && P.pk_maxrow <= 15) {

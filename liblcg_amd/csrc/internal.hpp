@@ -234,6 +234,9 @@ int jacobi_launch(const lcg_hip_csr *A, const double *x, double *z, int n, hipSt
 // part[AXP_CAP ..)); 0 = this matrix / kernel family cannot (nothing was launched: the caller multiplies and reduces as before); < 0 failure
 int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots, hipStream_t s,
                const int *done_flag);
+// the packed kernel of one part carrying y.u (and y.y), optionally with a shard's pushing blocks in front: 1 launched, 0 not this part
+int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double *x, double *y, const double *u, int yy, double *part,
+                    int *slots, hipStream_t s, const int *done_flag, const PushPlan *pp, int *nofold);
 // csr_binned.hip
 int binned_ready(const CsrPart &P, hipStream_t s);      // 1 plan ready, 0 not eligible, < 0 failure
 int binned_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done_flag);
@@ -254,6 +257,9 @@ int comm_allreduce(double *dev, int count, hipStream_t s);
 bool comm_active();
 bool xg_box(XgBox *out);        // true when the direct all-reduce is connected and enabled
 int dist_spmv(lcg_hip_csr *A, const double *x, double *y);
+// the sharded product, carrying y.u where it can: the local product's partial sums (folded) followed by the remote-column finisher's, in
+// part[0 .. *slots).  The product is ALWAYS made: 1 = with the sum, 2 = without it (the caller reduces in its own pass), < 0 failure
+int dist_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots);
 int dist_spmv_op(lcg_hip_csr *A, const CsrPart &T, const double *x, double *y);     // y = this rank's rows of A^T.x / A^H.x (T = (A_r)^T, csr.hip: op_part)
 
 } // namespace lcgh

@@ -361,7 +361,8 @@ struct RealCommon {
     int ax_dot(const double *x, double *y, const double *u, bool yy, int row, bool *fused)
     {
         int f = 0, slots = 0;
-        const bool builtin = Afp == lcg_hip_csr_ax && inst != nullptr && !comm_active();
+        // (sharded rows: csr_ax_dot hands over to comm.hip, which always makes the product and answers 1 when it carried the sum, 2 when not)
+        const bool builtin = Afp == lcg_hip_csr_ax && inst != nullptr;
         int rc = drv.timed_ax([&] {
             if (builtin) f = csr_ax_dot(static_cast<lcg_hip_csr *>(inst), x, y, u, yy ? 1 : 0, c.ax_partials, &slots, c.stream, &c.state->done);
             if (f == 0) Afp(inst, x, y, n);
@@ -423,7 +424,10 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
         bool fused; TRY(k.ax_dot(g, w, g, false, 0, &fused));
         if (!fused) TRY(k.drv.vec(OpDot1{st, g, w}, al(g) | al(w)));
         int rc;
-        if (fused && Pfp == nullptr) {
+        // The product that closes a body only serves the NEXT body's step length: the body the iteration cap ends the solve with goes
+        // without it (K iterations = K + 1 products, as in the reference's loop: lcg.cpp:168, 232).
+        auto last_body = [&]() { return p.max_iterations > 0 && k.drv.enq + 1 >= p.max_iterations; };
+        if (fused && Pfp == nullptr && !comm_active()) {
             // The product carries g.w, the update pass the other sums of the body: a body is TWO launches, `[step] update + sums |
             // A.g + g.w`; the scalar step that closes body k rides in the update of body k+1, the last one is closed by the tail.
             bool first = true;
@@ -431,6 +435,7 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
             rc = k.run_loop([&]() -> int {
                 if (first) { TRY(k.drv.vecf(FinCg1Start{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w))); first = false; }
                 else TRY(k.drv.vecf(FinCg1Close{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
+                if (last_body()) return 0;
                 bool f; TRY(k.ax_dot(g, w, g, false, 2, &f));
                 if (!f) { c.err = "A.x stopped carrying its dot in the middle of a solve"; return LCG_HIP_E_ARG; }
                 return 0;
@@ -438,12 +443,15 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
             k.drv.tail = nullptr;
         } else if (fused) {
             // with a progress callback the state is read after every body: the same passes with the scalar step as its own
-            // kernel at the end of the body (the same arithmetic: bit-identical iterates)
+            // kernel at the end of the body (the same arithmetic: bit-identical iterates).  Sharded rows take this form too: the step
+            // is where the ranks' sums meet (update + m.m, g.g, NaN | product, pushes, remote part + g.w | reduce, exchange, step)
             TRY(k.drv.scal(FinCg1Start{}));
             rc = k.run_loop([&]() -> int {
                 TRY(k.drv.vec(OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
-                bool f; TRY(k.ax_dot(g, w, g, false, 2, &f));
-                if (!f) { c.err = "A.x stopped carrying its dot in the middle of a solve"; return LCG_HIP_E_ARG; }
+                if (!last_body()) {
+                    bool f; TRY(k.ax_dot(g, w, g, false, 2, &f));
+                    if (!f) { c.err = "A.x stopped carrying its dot in the middle of a solve"; return LCG_HIP_E_ARG; }
+                }
                 TRY(k.drv.scal(FinCg1Close{}));
                 return 0;
             });
@@ -456,6 +464,7 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
             rc = k.run_loop([&]() -> int {
                 if (first) { TRY(k.drv.vecf(FinCg1Start{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w))); first = false; }
                 else TRY(k.drv.vecf(FinCg1Close{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
+                if (last_body()) return 0;
                 TRY(k.ax(g, w));
                 TRY(k.drv.vec_rows(OpDot1{st, g, w}, 2, al(g) | al(w)));
                 return 0;
@@ -467,8 +476,10 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
             TRY(k.drv.scal(FinCg1Start{}));
             rc = k.run_loop([&]() -> int {
                 TRY(k.drv.vec(OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
-                TRY(k.ax(g, w));
-                TRY(k.drv.vec_rows(OpDot1{st, g, w}, 2, al(g) | al(w)));
+                if (!last_body()) {
+                    bool f; TRY(k.ax_dot(g, w, g, false, 2, &f));   // (a product that cannot carry the sum is made all the same)
+                    if (!f) TRY(k.drv.vec_rows(OpDot1{st, g, w}, 2, al(g) | al(w)));
+                }
                 TRY(k.drv.scal(FinCg1Close{}));
                 return 0;
             });
