@@ -234,6 +234,16 @@ int lcg_hip_csr_set_binned(lcg_hip_csr_t A, int mode);
  * in a row are serialised by the LDS in lane order -- verified by tests/test_gpu_binned.py, not promised by the ISA). */
 int lcg_hip_csr_set_tiled(lcg_hip_csr_t A, int mode);
 const char *lcg_hip_csr_tiled_status(lcg_hip_csr_t A);
+/* Row ranges: a matrix whose rows fall into different column-pattern classes (a stencil in most rows, scattered columns in the
+ * rest) is multiplied range by range, every range choosing its own kernel family among the ones above; the rows are cut where
+ * the class of their 2048-row chunks changes (share of entries that continue a diagonal, mean column span of a 64-row block).
+ * A range's product is bit-identical to the product of that range as a matrix of its own.  mode: -1 automatic (real matrices of
+ * >= 4M entries, ranges of >= 256K entries, at most 8), 0 never, 1 whenever two classes are found; LCG_HIP_RANGES=0/1 overrides
+ * for the process.  lcg_hip_csr_last_kernel then reads "rows [a, b): <kernel> | rows [b, c): <kernel> ...".
+ * The reference has no counterpart (its A.x is the user's callback: lcg.h:37-38); speed only. */
+int lcg_hip_csr_set_ranges(lcg_hip_csr_t A, int mode);
+/* Number of row ranges the latest product used (0: one kernel family for all rows); first_row[0 .. min(cap, ranges)) = their first rows. */
+int lcg_hip_csr_ranges(lcg_hip_csr_t A, int cap, int *first_row);
 /* Why A has (or has not) a binned plan: "ready", or the reason it is not used (static string). */
 const char *lcg_hip_csr_binned_status(lcg_hip_csr_t A);
 /* Name of the kernel family the latest product with A used (static string; "" before the first product). */

@@ -73,6 +73,8 @@ SIGNATURES = {
     "lcg_hip_csr_packed_runs": (C.c_int64, [vp, C.POINTER(C.c_int64)]),
     "lcg_hip_csr_set_binned": (C.c_int, [vp, C.c_int]),
     "lcg_hip_csr_set_tiled": (C.c_int, [vp, C.c_int]),
+    "lcg_hip_csr_set_ranges": (C.c_int, [vp, C.c_int]),
+    "lcg_hip_csr_ranges": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
     "lcg_hip_csr_tiled_status": (C.c_char_p, [vp]),
     "lcg_hip_csr_binned_status": (C.c_char_p, [vp]),
     "lcg_hip_csr_last_kernel": (C.c_char_p, [vp]),

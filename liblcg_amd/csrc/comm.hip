@@ -289,7 +289,9 @@ __global__ __launch_bounds__(VB) void k_scatter_add(int nr, const int *__restric
 // carries (the local product leaves the rest: csr.hip, csr_part_ax_dot) -- one partial per block, fixed order
 // `big` (may be null): the local product's per-block sums; this block also adds its slice [blockIdx * per, + per) of them -- the
 // second stage of the local sums costs no launch of its own
-__device__ __forceinline__ void block_dot_store(double c, double *out, const double *__restrict__ big = nullptr, int nbig = 0, int per = 0)
+// fp.fin != 0: the block whose sum arrives last also closes the iteration body (devcommon.hpp: finish_body)
+__device__ __forceinline__ void block_dot_store(double c, double *out, const FinishPlan &fp, const double *__restrict__ big = nullptr,
+                                                int nbig = 0, int per = 0)
 {
     __shared__ double sh[VB / 64];
     if (big) {
@@ -299,22 +301,23 @@ __device__ __forceinline__ void block_dot_store(double c, double *out, const dou
     const double t = wave_sum(c);
     if ((threadIdx.x & 63) == WSUM_LANE) sh[threadIdx.x >> 6] = t;
     __syncthreads();
+    double v = 0.0;
     if (threadIdx.x == 0) {
-        double v = 0.0;
 #pragma unroll
         for (int k = 0; k < VB / 64; k++) v += sh[k];
-        out[blockIdx.x] = v;
+        if (!fp.fin) out[blockIdx.x] = v;
     }
+    if (fp.fin) finish_body(fp, out + blockIdx.x, v);
 }
 __global__ __launch_bounds__(VB) void k_scatter_add_dot(int nr, const int *__restrict__ rows, const double *__restrict__ part,
                                                         double *__restrict__ y, const double *__restrict__ u, double *__restrict__ dot_out,
-                                                        const double *__restrict__ big, int nbig, int per, const int *done)
+                                                        const double *__restrict__ big, int nbig, int per, const int *done, FinishPlan fp)
 {
     if (done && *done) return;
     const int j = blockIdx.x * VB + threadIdx.x;
     double c = 0.0;
     if (j < nr) { const int i = rows[j]; const double p = part[j]; y[i] += p; c = u[i] * p; }
-    block_dot_store(c, dot_out, big, nbig, per);
+    block_dot_store(c, dot_out, fp, big, nbig, per);
 }
 
 static int alloc_cols(CsrPart &P, int n, long nnz, bool cplx)
@@ -507,7 +510,8 @@ __global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ r
                                                const V *__restrict__ xfull, V *__restrict__ y, const int *done,
                                                WaitPlan wp = WaitPlan(), DevState *st = nullptr,
                                                const double *__restrict__ u = nullptr, double *__restrict__ dot_out = nullptr,
-                                               const double *__restrict__ big = nullptr, int nbig = 0, int per = 0)
+                                               const double *__restrict__ big = nullptr, int nbig = 0, int per = 0,
+                                               FinishPlan fp = FinishPlan())
 {
     static_assert(!DOT || (TOY && !LAND && sizeof(V) == 8), "the remote part carries its share of y.u in the single-stream real form");
     if (LAND && !wait_flags<false>(wp)) {
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ r
 #pragma unroll
     for (int off = T / 2; off > 0; off >>= 1) acc = vadd(acc, shfl_down_v(acc, off, T));
     if (j < nr && lane == 0) { if (TOY) y[i] = vadd(yold, acc); else y[j] = acc; }
-    if constexpr (DOT) block_dot_store((j < nr && lane == 0) ? u[i] * acc : 0.0, dot_out, big, nbig, per);
+    if constexpr (DOT) block_dot_store((j < nr && lane == 0) ? u[i] * acc : 0.0, dot_out, fp, big, nbig, per);
 }
 
 static void direct_free(lcg_hip_csr *A)
@@ -841,10 +845,14 @@ int dist_spmv_op(lcg_hip_csr *A, const CsrPart &T, const double *x, double *y)
 
 // u != nullptr: the product also leaves y.u as partial sums in part[0 .. *slots) -- the local product's (folded to <= 512), then one per
 // block of the remote-column finisher.  *fused says whether it did (when not, the plain product was made).
-static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const double *u, double *part, int *slots, bool *fused)
+// fp (with fp->fin set): the kernel that completes the sum also closes the iteration body with its last block (finish_body); when the
+// product is made without it, fp->fin is cleared.
+static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const double *u, double *part, int *slots, bool *fused, FinishPlan *fp)
 {
     Ctx &c = ctx();
     if (fused) *fused = false;
+    FinishPlan fin;                     // what the finishing kernel is handed (fin.fin == 0: nothing)
+    if (fp) { fin = *fp; fp->fin = FIN_NONE; }
     bool dot = u != nullptr && !A->is_complex;
     int nslot = 0;
     const size_t w = A->is_complex ? 2 : 1;
@@ -882,10 +890,13 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
         int rc = 0, f = 0;
         int nbig = 0;       // per-block sums of the local product the finisher folds (0: the local product folded them itself)
         if (dot) {
-            f = csr_part_ax_dot(A->loc, A->variant, mean_l, x, y, u, 0, part, &nslot, c.stream, done, &pp, A->remc.n_rows > 0 ? &nbig : nullptr);
+            // (without remote columns the fold of the local sums is the kernel that completes them)
+            f = csr_part_ax_dot(A->loc, A->variant, mean_l, x, y, u, 0, part, &nslot, c.stream, done, &pp, A->remc.n_rows > 0 ? &nbig : nullptr,
+                                A->remc.n_rows > 0 ? nullptr : &fin);
             if (f < 0) return f;
         }
         dot = f == 1;
+        if (!dot) fin.fin = FIN_NONE;
         if (!dot)
             rc = withhold ? spmv_launch(A->loc, A->is_complex, A->variant, mean_l, x, y, false, c.stream, done)
                           : spmv_launch_push(A->loc, A->is_complex, A->variant, mean_l, x, y, c.stream, done, pp);
@@ -949,9 +960,10 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
 #define REMOTE_DOT(TT)                                                                                               \
     do {                                                                                                             \
         const unsigned g = (unsigned)(((long)nr * TT + VB - 1) / VB);                                                \
+        fin.pc.axp = part; fin.pc.ax_n = nslot + (int)g;                                                             \
         hipLaunchKernelGGL((k_remote<double, TT, true, false, true>), dim3(g), dim3(VB), 0, rs, nr, A->remc.rowptr, A->remc.col, \
                            A->remc.val, A->rem_rows, A->xfull, y, done, WaitPlan(), (DevState *)nullptr, u, part + nslot, \
-                           nbig ? A->loc.dot_part : nullptr, nbig, (int)((nbig + g - 1) / g));                           \
+                           nbig ? A->loc.dot_part : nullptr, nbig, (int)((nbig + g - 1) / g), fin);                      \
         nslot += (int)g;                                                                                             \
     } while (0)
 #define REMOTE_CASE(TT) case TT: if (dot) REMOTE_DOT(TT); else if (land) REMOTE_LAND(TT); else if (one_stream) REMOTE_LAUNCH(TT, true, y); else REMOTE_LAUNCH(TT, false, sums); break;
@@ -980,7 +992,7 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
             HIPCHK(hipEventRecord(c.ev_b, rs));
             HIPCHK(hipStreamWaitEvent(c.stream, c.ev_b, 0));
         }
-        if (dot) { *slots = nslot; *fused = true; }
+        if (dot) { *slots = nslot; *fused = true; if (fp) fp->fin = fin.fin; }
         return 0;
     }
     double *mine = A->xfull + w * (size_t)(A->row0);
@@ -1014,10 +1026,12 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
         dot = dot && 512 + rem_blocks <= AXP_CAP;
         int f = 0;
         if (dot) {
-            f = csr_part_ax_dot(A->loc, A->variant, mean_l, x, y, u, 0, part, &nslot, c.stream, done, nullptr, A->remc.n_rows > 0 ? &nbig01 : nullptr);
+            f = csr_part_ax_dot(A->loc, A->variant, mean_l, x, y, u, 0, part, &nslot, c.stream, done, nullptr, A->remc.n_rows > 0 ? &nbig01 : nullptr,
+                                A->remc.n_rows > 0 ? nullptr : &fin);
             if (f < 0) return f;
         }
         dot = f == 1;
+        if (!dot) fin.fin = FIN_NONE;
     }
     if (!dot) rc = spmv_launch(A->loc, A->is_complex, A->variant, mean_l, x, y, false, c.stream, done);
     if (rc) return rc;
@@ -1025,12 +1039,13 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
     if (dot) {
         if (A->remc.n_rows > 0) {
             const unsigned g = (unsigned)((A->remc.n_rows + VB - 1) / VB);
+            fin.pc.axp = part; fin.pc.ax_n = nslot + (int)g;
             hipLaunchKernelGGL(k_scatter_add_dot, dim3(g), dim3(VB), 0, c.stream, A->remc.n_rows, A->rem_rows, A->rem_y, y, u, part + nslot,
-                               nbig01 ? A->loc.dot_part : nullptr, nbig01, (int)((nbig01 + g - 1) / g), done);
+                               nbig01 ? A->loc.dot_part : nullptr, nbig01, (int)((nbig01 + g - 1) / g), done, fin);
             HIPCHK(hipGetLastError());
             nslot += (int)g;
         }
-        *slots = nslot; *fused = true;
+        *slots = nslot; *fused = true; if (fp) fp->fin = fin.fin;
         return 0;
     }
     if (A->remc.n_rows > 0) {
@@ -1046,13 +1061,20 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
     return rc;
 }
 
-int dist_spmv(lcg_hip_csr *A, const double *x, double *y) { return dist_spmv_impl(A, x, y, nullptr, nullptr, nullptr, nullptr); }
+int dist_spmv(lcg_hip_csr *A, const double *x, double *y) { return dist_spmv_impl(A, x, y, nullptr, nullptr, nullptr, nullptr, nullptr); }
 
-int dist_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots)
+int dist_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots, FinishPlan *fp)
 {
     static const bool off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_SHARDED"); return e && atoi(e) == 0; }();     // A/B runs
+    // The step in the finishing kernel's last block (finish_body) is OPT-IN (LCG_HIP_FINISHER=1): measured on the one-rank rehearsal of
+    // the 8-way shard it buys nothing -- 101.2 vs 100.4 us per iteration at K = 500, 116.5 vs 114.1 at K = 20 (slow box), 101.2 vs 101.7
+    // and 112.9 vs 113.8 (fast box): what a scalar step costs is its chain of dependent memory round trips (partials, mailbox
+    // stores, their acknowledgement, the poll, the peers' sums, the state), and that chain is as long at the end of a kernel as in
+    // a kernel of its own; the launch it saves is hidden behind the previous kernel's tail anyway.
+    static const bool fin_on = [] { const char *e = std::getenv("LCG_HIP_FINISHER"); return e && atoi(e) == 1; }();
+    if (fp && !fin_on) fp->fin = FIN_NONE;
     bool fused = false;
-    const int rc = dist_spmv_impl(A, x, y, (yy || off) ? nullptr : u, part, slots, &fused);
+    const int rc = dist_spmv_impl(A, x, y, (yy || off) ? nullptr : u, part, slots, &fused, fp);
     return rc ? (rc > 0 ? -rc : rc) : (fused ? 1 : 2);
 }
 

@@ -580,8 +580,10 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
 
 // The <= 512-way second stage of a product's per-block sums: block i adds the slice [i * per, (i + 1) * per) of `big` in a
 // fixed order and leaves it in out[i] (the y.y sums, `stride` further on, in out[AXP_CAP + i]).
+// fp.fin != 0 (sharded rows without remote columns, y.u only): the block whose sum is the last to arrive also closes the body
+// (devcommon.hpp: finish_body).
 __global__ __launch_bounds__(VB) void k_axp_fold(const double *__restrict__ big, int nblk, int stride, int per, int yy, double *__restrict__ out,
-                                                 const int *done)
+                                                 const int *done, FinishPlan fp)
 {
     __shared__ double sh[2][VB / 64];
     if (done && *done) return;
@@ -603,12 +605,13 @@ __global__ __launch_bounds__(VB) void k_axp_fold(const double *__restrict__ big,
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == WSUM_LANE) { sh[0][wv] = a0; sh[1][wv] = a1; }
     __syncthreads();
+    double t = 0.0;
     if (threadIdx.x < 2 && (threadIdx.x == 0 || yy)) {
-        double t = 0.0;
 #pragma unroll
         for (int q = 0; q < VB / 64; q++) t += sh[threadIdx.x][q];
-        out[threadIdx.x * AXP_CAP + blockIdx.x] = t;
+        if (!fp.fin || threadIdx.x == 1) out[threadIdx.x * AXP_CAP + blockIdx.x] = t;
     }
+    if (fp.fin) finish_body(fp, out + blockIdx.x, t);
 }
 
 // ---- short rows (<= 17 entries on average: 5-point / 7-point stencils, the 1000 x 1000 Laplacian of BASELINE configs[1]) ---------
@@ -966,6 +969,165 @@ static int lds_shape(const CsrPart &P, int variant, double mean_row, hipStream_t
     return 0;
 }
 
+// ---- row ranges: one kernel family per stretch of rows ----------------------------------------------------------------------
+// The choices above (run blocks / packed columns, tiled, binned) are made for a whole part from whole-part statistics.  A matrix
+// that is a stencil in most of its rows and scattered in the rest would take ONE of them for all rows: the packed form is refused
+// as soon as one 64-row block spans 2^21 columns, and the binned product costs the structured rows 2-3x.  So the rows are cut
+// into chunks of RG_CHUNK, every chunk is classed by the two statistics the whole-part choices use -- the share of entries whose
+// column is one more than the entry above them (k_diag_like) and the mean column span of a 64-row block (k_span_sum) --, equal
+// neighbours are merged, stretches too small to pay for a launch of their own join a neighbour, and each remaining stretch
+// becomes a VIEW of the part (its own row-pointer origin, the same col / val, offsets absolute) that chooses its kernel family
+// like any part.  Rows are never reordered and every row is still summed by the kernel it would get in a matrix of its own
+// class: the product of a range is bit-identical to the product of that range as a stand-alone matrix.
+constexpr int RG_CHUNK = 2048;
+constexpr int RG_MAX = 8;           // most ranges (more classes changes than that: no split)
+struct RangePlan {
+    std::vector<CsrPart> parts;
+    std::vector<int> r0;            // first row of each range
+    std::vector<const char *> seen; // last_kernel of each range when `desc` was composed
+    std::string desc;
+};
+
+// per 64-row block: [0] column span, [1] diagonal-like entries, [2] entries
+__global__ __launch_bounds__(64) void k_range_stats(int n, const int *__restrict__ rowptr, const int *__restrict__ col, unsigned int *stats)
+{
+    const long row0 = (long)blockIdx.x * PK_R;
+    const int r1 = (int)min((long)n, row0 + PK_R);
+    const int s = rowptr[row0], e = rowptr[r1];
+    int lo = 0x7fffffff, hi = 0;
+    for (int k = s + threadIdx.x; k < e; k += 64) { const int c = col[k]; lo = min(lo, c); hi = max(hi, c); }
+    unsigned cnt = 0;
+    const long i = row0 + threadIdx.x;
+    if (i < r1 && i + 1 < n) {
+        const int a = rowptr[i], b = rowptr[i + 1], c = rowptr[i + 2];
+        const int m = min(b - a, c - b);
+        for (int q = 0; q < m; q++) cnt += col[a + q] + 1 == col[b + q];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); cnt += __shfl_down(cnt, off, 64);
+    }
+    if (threadIdx.x == 0) {
+        unsigned int *st = stats + 3 * (long)blockIdx.x;
+        st[0] = e > s ? (unsigned)(hi - lo) : 0u; st[1] = cnt; st[2] = (unsigned)(e - s);
+    }
+}
+
+static void ranges_free(const CsrPart &P);
+void free_part(CsrPart &P);
+
+static bool ranges_chosen(const CsrPart &P, hipStream_t s)
+{
+    if (P.rg_state != 0) return P.rg_state > 0;
+    P.rg_state = -1;
+    static const int env = [] { const char *e = std::getenv("LCG_HIP_RANGES"); return e ? atoi(e) : -1; }();
+    const int mode = env >= 0 ? env : P.rg_mode;
+    const int n = P.n_rows;
+    if (mode == 0 || P.end_abs >= 0 || n < 2 * RG_CHUNK || P.n_cols <= 0 || P.nnz <= 0) return false;
+    if (mode < 0 && P.nnz < (1 << 22)) return false;
+    PlanTimer timer(P, s);
+    const int nb = (n + PK_R - 1) / PK_R;
+    constexpr int BPC = RG_CHUNK / PK_R;         // blocks per chunk
+    const int nc = (nb + BPC - 1) / BPC;
+    std::vector<unsigned int> hb(3 * (size_t)nb);
+    {
+        unsigned int *d = nullptr;
+        bool ok = hipMalloc(&d, sizeof(unsigned int) * hb.size()) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(k_range_stats, dim3(nb), dim3(64), 0, s, n, P.rowptr, P.col, d);
+            ok = hipMemcpyAsync(hb.data(), d, sizeof(unsigned int) * hb.size(), hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipStreamSynchronize(s) == hipSuccess;
+        }
+        if (d) hipFree(d);
+        if (!ok) { (void)hipGetLastError(); return false; }
+    }
+    // class of a stretch from its sums: 0 structured (diagonals / stencils), 1 columns drawn per row inside a band, 2 scattered; -1 empty
+    auto classify = [](double span_sum, double dl, double ent, double blocks) {
+        if (ent <= 0.0 || blocks <= 0.0) return -1;
+        return dl / ent > 0.5 ? 0 : (span_sum / blocks >= span_threshold() ? 2 : 1);
+    };
+    auto block_class = [&](int b) { return classify((double)hb[3 * (size_t)b], (double)hb[3 * (size_t)b + 1], (double)hb[3 * (size_t)b + 2], 1.0); };
+    std::vector<int> cls(nc);
+    std::vector<double> cent(nc);
+    for (int c = 0; c < nc; c++) {
+        double sp = 0.0, dl = 0.0, ent = 0.0, blocks = 0.0;
+        for (int b = c * BPC; b < std::min(nb, (c + 1) * BPC); b++)
+            if (hb[3 * (size_t)b + 2]) { sp += hb[3 * (size_t)b]; dl += hb[3 * (size_t)b + 1]; ent += hb[3 * (size_t)b + 2]; blocks += 1.0; }
+        cls[c] = classify(sp, dl, ent, blocks); cent[c] = ent;
+    }
+    for (int c = 0; c < nc; c++) if (cls[c] < 0) cls[c] = c > 0 ? cls[c - 1] : 0;      // empty chunks follow their predecessor
+    struct Run { int c0, c1, k; double ent; };
+    std::vector<Run> runs;
+    for (int c = 0; c < nc; c++) {
+        if (runs.empty() || runs.back().k != cls[c]) runs.push_back({c, c + 1, cls[c], 0.0});
+        runs.back().c1 = c + 1; runs.back().ent += cent[c];
+    }
+    // a stretch with fewer entries than a launch of its own is worth joins its larger neighbour (smallest first)
+    const double min_ent = mode > 0 ? 1.0 : (double)(1 << 18);
+    for (;;) {
+        if (runs.size() < 2) break;
+        size_t w = 0;
+        for (size_t i = 1; i < runs.size(); i++) if (runs[i].ent < runs[w].ent) w = i;
+        if (runs[w].ent >= min_ent && runs.size() <= (size_t)RG_MAX) break;
+        const size_t to = w == 0 ? 1 : (w + 1 == runs.size() ? w - 1 : (runs[w - 1].ent >= runs[w + 1].ent ? w - 1 : w + 1));
+        runs[to].c0 = std::min(runs[to].c0, runs[w].c0); runs[to].c1 = std::max(runs[to].c1, runs[w].c1); runs[to].ent += runs[w].ent;
+        runs.erase(runs.begin() + (long)w);
+        for (size_t i = 0; i + 1 < runs.size();)      // neighbours of one class become one stretch
+            if (runs[i].k == runs[i + 1].k) { runs[i].c1 = runs[i + 1].c1; runs[i].ent += runs[i + 1].ent; runs.erase(runs.begin() + (long)i + 1); }
+            else i++;
+    }
+    if (runs.size() < 2) return false;
+    // The cuts, to the 64-row block: inside the two chunks that meet at a cut the boundary goes where the fewest blocks end up on
+    // the side of the other class (one wide block inside a structured range would cost that whole range its packed columns).
+    std::vector<int> cutb(runs.size() + 1);          // in blocks
+    cutb[0] = 0; cutb[runs.size()] = nb;
+    for (size_t i = 1; i < runs.size(); i++) {
+        const int ka = runs[i - 1].k;
+        const int b0 = std::max(cutb[i - 1], (runs[i].c0 - 1) * BPC), b1 = std::min(nb, (runs[i].c0 + 1) * BPC);
+        int wrong = 0;
+        for (int b = b0; b < b1; b++) { const int k = block_class(b); wrong += k == ka; }     // cut at b0: every block of class a on the wrong side
+        int best = wrong, at = b0;
+        for (int b = b0; b < b1; b++) {
+            const int k = block_class(b);
+            wrong += (k >= 0 && k != ka) - (k == ka);                                     // cut behind block b
+            if (wrong < best) { best = wrong; at = b + 1; }
+        }
+        cutb[i] = at;
+    }
+    // row pointers at the cuts
+    std::vector<int> cut(runs.size() + 1);
+    for (size_t i = 0; i <= runs.size(); i++) {
+        const long r = std::min<long>(n, (long)cutb[i] * PK_R);
+        if (hipMemcpyAsync(&cut[i], P.rowptr + r, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) { (void)hipGetLastError(); return false; }
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return false; }
+    RangePlan *R = new RangePlan();
+    for (size_t i = 0; i < runs.size(); i++) {
+        const int r0 = (int)std::min<long>(n, (long)cutb[i] * PK_R), r1 = (int)std::min<long>(n, (long)cutb[i + 1] * PK_R);
+        if (r1 <= r0) continue;
+        CsrPart V;
+        V.n_rows = r1 - r0; V.nnz = cut[i + 1] - cut[i]; V.rowptr = P.rowptr + r0; V.col = P.col; V.val = P.val;
+        V.owned = false; V.padded = r1 < n ? true : P.padded;       // (behind an inner range lies the next range)
+        V.end_abs = cut[i + 1]; V.n_cols = P.n_cols;
+        V.pk_mode = P.pk_mode; V.bn_mode = P.bn_mode; V.tl_mode = P.tl_mode; V.rg_mode = 0; V.rg_state = -1;
+        R->parts.push_back(V); R->r0.push_back(r0); R->seen.push_back(nullptr);
+    }
+    if (R->parts.size() < 2) { delete R; return false; }
+    P.rg_plan = R; P.rg_state = 1;
+    if (std::getenv("LCG_HIP_DEBUG_BINNED")) {
+        std::fprintf(stderr, "[lcg_hip] row ranges of %d rows:", n);
+        for (size_t i = 0; i < R->parts.size(); i++) std::fprintf(stderr, " [%d, %d) %ld entries;", R->r0[i], R->r0[i] + R->parts[i].n_rows, (long)R->parts[i].nnz);
+        std::fprintf(stderr, "\n");
+    }
+    return true;
+}
+
+static void ranges_free(const CsrPart &P)
+{
+    RangePlan *R = static_cast<RangePlan *>(P.rg_plan);
+    if (R) { for (CsrPart &V : R->parts) free_part(V); delete R; }
+    P.rg_plan = nullptr; P.rg_state = 0;
+}
+
 template <class V, bool ACC, bool PUSH = false>
 static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V *x, V *y, hipStream_t s,
                          const int *done, const PushPlan &pp = PushPlan())
@@ -973,6 +1135,26 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
     const int n = P.n_rows;
     const unsigned xb = PUSH ? (unsigned)pp.nblocks : 0u;       // pushing blocks in front of the grid
     if constexpr (sizeof(V) == 8 && !ACC && !PUSH) {
+        if (n > 0 && (variant == 0 || variant == -1) && ranges_chosen(P, s)) {
+            RangePlan *R = static_cast<RangePlan *>(P.rg_plan);
+            bool changed = false;
+            for (size_t i = 0; i < R->parts.size(); i++) {
+                const CsrPart &Q = R->parts[i];
+                int rc = spmv_dispatch<V, false, false>(Q, variant, Q.n_rows ? (double)Q.nnz / Q.n_rows : 0.0, x, y + R->r0[i], s, done);
+                if (rc) return rc;
+                if (Q.last_kernel != R->seen[i]) { R->seen[i] = Q.last_kernel; changed = true; }
+            }
+            if (changed) {
+                R->desc.clear();
+                for (size_t i = 0; i < R->parts.size(); i++) {
+                    char buf[64];
+                    std::snprintf(buf, sizeof buf, "%srows [%d, %d): ", i ? " | " : "", R->r0[i], R->r0[i] + R->parts[i].n_rows);
+                    R->desc += buf; R->desc += R->parts[i].last_kernel;
+                }
+            }
+            P.last_kernel = R->desc.c_str();
+            return 0;
+        }
         if (n > 0 && (variant == 0 || variant == -1) && binned_chosen(P, s)) {
             P.last_kernel = "k_bin_expand + k_bin_reduce (two-pass binned product, x and row sums in LDS)";
             return binned_launch(P, reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), s, done);
@@ -1052,10 +1234,10 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
     case RR:                                                                                           \
         if (onewin)                                                                                    \
             hipLaunchKernelGGL((k_spmv_lds1<V, RR, ACC, PUSH>), dim3((n + RR - 1) / RR + xb), dim3(VB), 0, s, n, \
-                               (long)P.nnz, P.rowptr, P.col, val, x, y, done, pp);                     \
+                               (long)(P.end_abs >= 0 ? P.end_abs : P.nnz), P.rowptr, P.col, val, x, y, done, pp); \
         else                                                                                           \
             hipLaunchKernelGGL((k_spmv_ldsw<V, RR, ACC, PUSH>), dim3((n + RR - 1) / RR + xb), dim3(VB), 0, s, n, \
-                               (long)P.nnz, P.rowptr, P.col, val, x, y, done, pp);                     \
+                               (long)(P.end_abs >= 0 ? P.end_abs : P.nnz), P.rowptr, P.col, val, x, y, done, pp); \
         break;
         switch (R) {
             LDS_CASE(256) LDS_CASE(128) LDS_CASE(64) LDS_CASE(32) LDS_CASE(16)
@@ -1109,8 +1291,10 @@ int spmv_launch_push(const CsrPart &P, bool is_complex, int variant, double mean
 // part does not take the packed kernel (nothing was launched), < 0 failure.
 // nofold != nullptr: the second stage is left to the caller (comm.hip folds the per-block sums in the kernel that finishes the
 // shard's product anyway): *nofold = number of per-block sums waiting in P.dot_part, nothing is written to `part`.
+// fp != nullptr with fp->fin set (and the fold made here, y.u only): the fold's last block also closes the iteration body
+// (devcommon.hpp: finish_body); fp->pc.ax_n is completed here.  The caller learns it from *slots as always.
 int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double *x, double *y, const double *u, int yy, double *part,
-                    int *slots, hipStream_t s, const int *done, const PushPlan *pp, int *nofold)
+                    int *slots, hipStream_t s, const int *done, const PushPlan *pp, int *nofold, const FinishPlan *fp)
 {
     const int n = P.n_rows;
     if (n <= 0 || (variant != 0 && variant != -1)) return 0;
@@ -1145,7 +1329,9 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
     if (nofold) { *nofold = nblk; *slots = 0; return 1; }
     const int g2 = std::min(512, (nblk + VB - 1) / VB);
     const int per = (nblk + g2 - 1) / g2;
-    hipLaunchKernelGGL(k_axp_fold, dim3((nblk + per - 1) / per), dim3(VB), 0, s, P.dot_part, nblk, nblk, per, yy, part, done);
+    FinishPlan fin;
+    if (fp && fp->fin && !yy) { fin = *fp; fin.pc.axp = part; fin.pc.ax_n = (nblk + per - 1) / per; }
+    hipLaunchKernelGGL(k_axp_fold, dim3((nblk + per - 1) / per), dim3(VB), 0, s, P.dot_part, nblk, nblk, per, yy, part, done, fin);
     HIPCHK(hipGetLastError());
     P.last_kernel = P.pk_runs > 0 ? "k_spmv_ldsp (LDS-staged, run blocks + packed columns) carrying the dot that follows the product"
                                   : "k_spmv_ldsp (LDS-staged, packed columns) carrying the dot that follows the product";
@@ -1155,22 +1341,23 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
 
 // A.x with the dot(s) that follow it in the Krylov loops carried in the product (k_spmv_lds1d / k_spmv_ldsp<DOT> / k_spmv_run1d): real
 // matrices, the LDS-staged one-window family.  Everything else answers 0 and the caller multiplies and reduces in two launches as before.
-int dist_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots);     // comm.hip
 int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots, hipStream_t s,
-               const int *done)
+               const int *done, FinishPlan *fp)
 {
     static const bool off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT"); return e && atoi(e) == 0; }();
     if (off || !A || A->is_complex || A->n_rows <= 0) return 0;
-    if (A->distributed) return dist_ax_dot(A, x, y, u, yy, part, slots);
+    if (A->distributed) return dist_ax_dot(A, x, y, u, yy, part, slots, fp);
+    if (fp) fp->fin = FIN_NONE;        // (one GPU: the step rides in the NEXT pass instead -- driver.hpp, vecf)
     const CsrPart &P = A->main;
     const int n = P.n_rows;
     if (A->variant != 0 && A->variant != -1) return 0;
+    if (ranges_chosen(P, s)) return 0;  // multiplied range by range: the dot keeps its own pass
     if (A->mean_row > 160.0 || ((((uintptr_t)P.val | (uintptr_t)P.col) & 15) != 0)) return 0;
     if (binned_chosen(P, s) || tiled_chosen(P, s)) return 0;
     int R = 0; bool onewin = false;
     { int rc = lds_shape<double>(P, -1, A->mean_row, s, &R, &onewin); if (rc) return rc; }
     if (!onewin) return 0;
-    if (R == PK_R && packed_ready(P, s)) return csr_part_ax_dot(P, A->variant, A->mean_row, x, y, u, yy, part, slots, s, done, nullptr, nullptr);
+    if (R == PK_R && packed_ready(P, s)) return csr_part_ax_dot(P, A->variant, A->mean_row, x, y, u, yy, part, slots, s, done, nullptr, nullptr, nullptr);
     const int nblk = (n + R - 1) / R;
     static const bool run1_off = [] { const char *e = std::getenv("LCG_HIP_RUN1"); return e && atoi(e) == 0; }();
     if (!run1_off && (R == 256 || R == 128) && packed_build(P, s, true) && P.pk_maxrow <= 15) {
@@ -1597,6 +1784,7 @@ static int alloc_part(CsrPart &P, int n_rows, long nnz, bool cplx)
 
 void free_part(CsrPart &P)
 {
+    ranges_free(P);
     binned_free(P);
     tiled_free(P);
     if (P.owned) { hipFree(P.rowptr); hipFree(P.col); hipFree(P.val); }
@@ -1872,6 +2060,7 @@ int lcg_hip_csr_set_packed(lcg_hip_csr_t A, int mode)
     if (!A || mode < -1 || mode > 1) return LCG_HIP_E_ARG;
     for (CsrPart *P : {&A->main, &A->loc}) {
         P->pk_mode = mode;
+        ranges_free(*P);                    // the ranges inherit the modes: cut again at the next product
         if (P->pk_state > 0 && mode == 0) {         // give the memory back
             if (ctx().inited) (void)hipDeviceSynchronize();
             hipFree(P->pk_base); hipFree(P->pk_ofs); hipFree(P->pk_data);
@@ -1887,6 +2076,7 @@ int lcg_hip_csr_set_binned(lcg_hip_csr_t A, int mode)
     if (!A || mode < -1 || mode > 1) return LCG_HIP_E_ARG;
     for (CsrPart *P : {&A->main, &A->loc}) {
         P->bn_mode = mode;
+        ranges_free(*P);                    // the ranges inherit the modes: cut again at the next product
         if (mode == 0) binned_free(*P);     // gives the plan's memory back
         else P->bn_state = 0;               // decide again at the next product (a plan that exists is kept and reused)
     }
@@ -1898,10 +2088,29 @@ int lcg_hip_csr_set_tiled(lcg_hip_csr_t A, int mode)
     if (!A || mode < -1 || mode > 1) return LCG_HIP_E_ARG;
     for (CsrPart *P : {&A->main, &A->loc}) {
         P->tl_mode = mode;
+        ranges_free(*P);                    // the ranges inherit the modes: cut again at the next product
         if (mode == 0) tiled_free(*P);
         else P->tl_state = 0;               // decide again at the next product (a plan that exists is kept and reused)
     }
     return 0;
+}
+
+int lcg_hip_csr_set_ranges(lcg_hip_csr_t A, int mode)
+{
+    if (!A || mode < -1 || mode > 1) return LCG_HIP_E_ARG;
+    if (ctx().inited) (void)hipDeviceSynchronize();
+    for (CsrPart *P : {&A->main, &A->loc}) { ranges_free(*P); P->rg_mode = mode; }
+    return 0;
+}
+
+int lcg_hip_csr_ranges(lcg_hip_csr_t A, int cap, int *first_row)
+{
+    if (!A) return 0;
+    const CsrPart &P = A->distributed ? A->loc : A->main;
+    const RangePlan *R = static_cast<const RangePlan *>(P.rg_plan);
+    if (!R || P.rg_state <= 0) return 0;
+    for (int i = 0; i < cap && i < (int)R->r0.size() && first_row; i++) first_row[i] = R->r0[i];
+    return (int)R->r0.size();
 }
 
 const char *lcg_hip_csr_tiled_status(lcg_hip_csr_t A)
@@ -1930,12 +2139,17 @@ int64_t lcg_hip_csr_packed_runs(lcg_hip_csr_t A, int64_t *blocks_out)
     return P.pk_state > 0 ? P.pk_runs : 0;
 }
 
-int64_t lcg_hip_csr_last_traffic_model(lcg_hip_csr_t A)
+static int64_t part_traffic_model(const CsrPart &P)
 {
-    if (!A || A->is_complex) return 0;
-    const CsrPart &P = A->distributed ? A->loc : A->main;
     const char *k = P.last_kernel;
     if (!k || !*k) return 0;
+    if (P.rg_state > 0 && P.rg_plan) {      // range by range; x is counted once
+        const RangePlan *R = static_cast<const RangePlan *>(P.rg_plan);
+        int64_t b = 0;
+        const int64_t xbytes = 8 * (P.n_cols > 0 ? P.n_cols : (int64_t)P.n_rows);
+        for (const CsrPart &Q : R->parts) b += part_traffic_model(Q) - xbytes;
+        return b + xbytes;
+    }
     const int64_t n = P.n_rows, ncols = P.n_cols > 0 ? P.n_cols : P.n_rows;
     const int64_t vectors = 4 * (n + 1) + 8 * ncols + 8 * n;       // row pointers, x once, y
     const int64_t nb = (n + PK_R - 1) / PK_R;
@@ -1950,18 +2164,28 @@ int64_t lcg_hip_csr_last_traffic_model(lcg_hip_csr_t A)
     return 12 * P.nnz + vectors;                        // the CSR arrays as they are
 }
 
+int64_t lcg_hip_csr_last_traffic_model(lcg_hip_csr_t A)
+{
+    if (!A || A->is_complex) return 0;
+    return part_traffic_model(A->distributed ? A->loc : A->main);
+}
+
 int lcg_hip_csr_plan_info(lcg_hip_csr_t A, double *build_ms, int64_t *extra_bytes)
 {
     if (!A) return LCG_HIP_E_ARG;
     const CsrPart &P = A->distributed ? A->loc : A->main;
-    if (build_ms) *build_ms = P.plan_ms;
-    if (extra_bytes) {
-        int64_t b = 0;
-        if (P.pk_state > 0) b += 16 * ((int64_t)P.pk_groups + 4) + 8 * (((int64_t)P.n_rows + PK_R - 1) / PK_R + 1);
-        if (P.bn_plan) b += (int64_t)binned_plan_bytes(P);
-        if (P.tl_plan) b += (int64_t)tiled_plan_bytes(P);
-        *extra_bytes = b;
-    }
+    double ms = P.plan_ms;
+    int64_t b = 0;
+    auto add = [&](const CsrPart &Q) {
+        if (Q.pk_state > 0) b += 16 * ((int64_t)Q.pk_groups + 4) + 8 * (((int64_t)Q.n_rows + PK_R - 1) / PK_R + 1);
+        if (Q.bn_plan) b += (int64_t)binned_plan_bytes(Q);
+        if (Q.tl_plan) b += (int64_t)tiled_plan_bytes(Q);
+    };
+    add(P);
+    if (P.rg_state > 0 && P.rg_plan)
+        for (const CsrPart &Q : static_cast<const RangePlan *>(P.rg_plan)->parts) { add(Q); ms += Q.plan_ms; }
+    if (build_ms) *build_ms = ms;
+    if (extra_bytes) *extra_bytes = b;
     return 0;
 }
 

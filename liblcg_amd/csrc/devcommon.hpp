@@ -194,11 +194,17 @@ __device__ __forceinline__ bool xg_exchange(const XgBox &xb, const double *sums,
         double *dst = xb.peers[q] + (size_t)(par * xb.P + xb.me) * XG_SLOT;
 #pragma unroll
         for (int r = 0; r < NR; r++) __hip_atomic_store(dst + r, sums[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + MAXR), k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // The sums are write-through stores at system scope into uncached memory: once they are acknowledged (vmcnt) they are
+        // visible over there, and the sequence word may follow.  A release fence would do the same and ALSO write back every
+        // dirty line of this XCD's L2 -- which, when this runs in the last block of a product (finish_body), is the product's y.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + MAXR), k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         double *src = xb.mine + (size_t)(par * xb.P + q) * XG_SLOT;
         const long long t0 = wall_clock64();
         bool ok = true;
-        while (__hip_atomic_load(reinterpret_cast<unsigned long long *>(src + MAXR), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != k) {
+        // (relaxed polls; the sums below are system-scope loads of uncached memory issued behind the matching poll: no acquire,
+        //  whose cache invalidation per poll would cost 2-3x per hop)
+        while (__hip_atomic_load(reinterpret_cast<unsigned long long *>(src + MAXR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != k) {
             __builtin_amdgcn_s_sleep(2);
             if (wall_clock64() - t0 > xb.timeout_ticks) { ok = false; break; }
         }
@@ -401,6 +407,72 @@ __global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, Pa
         }
     }
     if (mode != SC_REDUCE && threadIdx.x == 0) fin(st, sums);
+}
+
+// ---- the body-closing step of plain CG's one-reduction schedule (solvers_real.hip), here because a sharded product's last
+// block may run it (finish_body below) ----------------------------------------------------------------------------------
+enum { S_AK = 0, S_BK, S_WK, S_RHO /* g.g | z.r | r.r0 */, S_M2, S_G2 /* residual numerator */ };   // DevState::s slots of the real solvers
+__device__ __forceinline__ double clamp1(double v) { return v < 1.0 ? 1.0 : v; }
+struct FinCg1Close {    // the only scalar step of a body: counts it, closes it, prepares the next
+    static constexpr int NR = 4;
+    __device__ void operator()(DevState *st, const double *sum) const
+    {
+        st->it++;
+        if (!st->done) {
+            st->s[S_M2] = clamp1(sum[0]);
+            if (sum[3] > 0.0 || sum[0] != sum[0]) {         // lcg.cpp:247-253
+                st->t++;
+                st->done = 1; st->status = ST_NAN;
+            } else {
+                const double rho_new = sum[1];
+                const double bk = rho_new / st->s[S_RHO];                       // lcg.cpp:256
+                st->s[S_AK] = rho_new / (sum[2] - bk * rho_new / st->s[S_AK]);  // lcg.cpp:235 with d.Ad as above
+                st->s[S_BK] = bk;
+                st->s[S_RHO] = rho_new;
+                st->s[S_G2] = rho_new;
+                st->t++;
+                stop_rule(st, rho_new, st->s[S_M2]);
+            }
+        }
+        publish(st);
+    }
+};
+
+// Called by EVERY thread of EVERY block of a kernel whose blocks each leave one partial sum (thread 0 holds the block's: v, to be
+// stored at *slot), at a point all threads of the block reach.  The block that takes the last ticket closes the iteration body:
+// it adds up everything that waits (reduce_partials, fixed order: the bits of k_scal), lets the sums meet the other ranks'
+// (xg_allreduce) and runs the step -- the launch of k_scal and the kernel boundary in front of it are gone.
+// Hand-off between blocks (any XCD): the partial is stored write-through at agent scope and acknowledged (vmcnt) before the
+// ticket is taken; the last block invalidates its caches (agent acquire) behind its own ticket and a workgroup barrier before
+// it reads the others' sums (MI355X_MICROARCH.md, cross-workgroup hand-offs: "Consumer, always").
+__device__ __forceinline__ void finish_body(const FinishPlan &fp, double *slot, double v)
+{
+    __shared__ int last_s;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(fp.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = t + 1u == gridDim.x ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(fp.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the next launch starts from zero
+    constexpr int NRA = 4;
+    __shared__ double fsums[NRA];
+    reduce_partials<NRA>(fp.partials, fp.pc, fsums);
+    if (fp.xg && !xg_allreduce<NRA>(fp.xb, fsums)) {
+        if (threadIdx.x == 0) { fp.st->done = 1; fp.st->status = ST_COMM; }
+        return;
+    }
+    if (threadIdx.x == 0) {
+        switch (fp.fin) {
+        case FIN_CG1_CLOSE: FinCg1Close{}(fp.st, fsums); break;
+        default: break;
+        }
+    }
 }
 
 // ---- scalar step fused into the pass that consumes it (single GPU) ------------------------------------------------

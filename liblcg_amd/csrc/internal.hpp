@@ -75,6 +75,22 @@ struct DotPlan {
     int stride = AXP_CAP;   // distance of the y.y sums from the y.u sums in `part`
 };
 
+// The scalar step that closes an iteration body, run by the LAST block of the kernel that completes the body's last sum (the
+// finisher of a sharded product: k_remote / k_scatter_add_dot / k_axp_fold) instead of by a kernel of its own: the block whose
+// ticket is the last one reduces every pending partial sum in the usual fixed order (reduce_partials: the same bits as k_scal),
+// exchanges the sums with the other ranks over the mailboxes and runs the step (devcommon.hpp: finish_body).
+enum { FIN_NONE = 0, FIN_CG1_CLOSE = 1 };
+struct DevState;
+struct FinishPlan {
+    int fin = FIN_NONE;
+    int xg = 0;                         // 1: the sums meet the other ranks' over the mailboxes first (xb)
+    unsigned int *ticket = nullptr;     // blocks of the finishing kernel that have left their sum (the last one resets it)
+    const double *partials = nullptr;   // the table of the latest reducing pass
+    PartCount pc;                       // what waits where: the pass's rows, and the product's sums (axp, ax_n, ax_row)
+    DevState *st = nullptr;
+    XgBox xb;
+};
+
 // Mirror of the stop state in host-mapped pinned memory; written by the scalar kernels,
 // polled by the host without touching the stream.
 struct HostStatus {
@@ -115,6 +131,7 @@ struct Ctx {
     DevState *state = nullptr;         // the state the next kernel is handed (one of state_pair: driver.hpp, vecf)
     double *partials_pair[2] = {nullptr, nullptr};
     double *ax_partials = nullptr;     // [2][AXP_CAP]: the sums an A.x kernel carried (csr.hip: k_spmv_lds1d), see PartCount
+    unsigned int *fin_ticket = nullptr; // FinishPlan::ticket (zero between launches)
     DevState *state_pair[2] = {nullptr, nullptr};
     HostStatus *hstat = nullptr;       // pinned, mapped
     HostStatus *hstat_dev = nullptr;   // device alias of hstat
@@ -189,6 +206,12 @@ struct CsrPart {
     mutable int tl_state = 0;      // 0 not tried, 1 plan ready, -1 not eligible / not chosen
     mutable void *tl_plan = nullptr;
     mutable const char *tl_why = "not tried";
+    // row ranges (csr.hip, "row ranges"): a matrix whose row blocks fall into different column-pattern classes is multiplied range by
+    // range, each range -- a view of this part's arrays -- choosing its own kernel family
+    int64_t end_abs = -1;          // a view only: offset one past its last entry in the shared col / val (-1: this part owns offsets 0 .. nnz)
+    mutable int rg_mode = -1;      // -1 auto (>= 4M entries), 0 never, 1 whenever two classes are found
+    mutable int rg_state = 0;      // 0 not tried, 1 split, -1 one range
+    mutable void *rg_plan = nullptr;
     mutable const char *last_kernel = "";   // name of the kernel family the latest product used
     mutable double plan_ms = 0.0;           // host time spent choosing a kernel family and building its copy of the matrix (first product)
 };
@@ -232,11 +255,13 @@ int spmv_launch_push(const CsrPart &P, bool is_complex, int variant, double mean
 int jacobi_launch(const lcg_hip_csr *A, const double *x, double *z, int n, hipStream_t s);
 // y = A.x with the sums y.u (and y.y) riding in the product: 1 = done, *slots partial sums wait in part[0 .. *slots) (and
 // part[AXP_CAP ..)); 0 = this matrix / kernel family cannot (nothing was launched: the caller multiplies and reduces as before); < 0 failure
+// fp (may be null): a step the product's last block should run once its sums are complete (sharded rows with the mailboxes);
+// on return fp->fin is still set if it will, FIN_NONE if the caller has to launch the step itself
 int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots, hipStream_t s,
-               const int *done_flag);
+               const int *done_flag, FinishPlan *fp);
 // the packed kernel of one part carrying y.u (and y.y), optionally with a shard's pushing blocks in front: 1 launched, 0 not this part
 int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double *x, double *y, const double *u, int yy, double *part,
-                    int *slots, hipStream_t s, const int *done_flag, const PushPlan *pp, int *nofold);
+                    int *slots, hipStream_t s, const int *done_flag, const PushPlan *pp, int *nofold, const FinishPlan *fp);
 // csr_binned.hip
 int binned_ready(const CsrPart &P, hipStream_t s);      // 1 plan ready, 0 not eligible, < 0 failure
 int binned_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done_flag);
@@ -259,7 +284,7 @@ bool xg_box(XgBox *out);        // true when the direct all-reduce is connected 
 int dist_spmv(lcg_hip_csr *A, const double *x, double *y);
 // the sharded product, carrying y.u where it can: the local product's partial sums (folded) followed by the remote-column finisher's, in
 // part[0 .. *slots).  The product is ALWAYS made: 1 = with the sum, 2 = without it (the caller reduces in its own pass), < 0 failure
-int dist_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots);
+int dist_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots, FinishPlan *fp);
 int dist_spmv_op(lcg_hip_csr *A, const CsrPart &T, const double *x, double *y);     // y = this rank's rows of A^T.x / A^H.x (T = (A_r)^T, csr.hip: op_part)
 
 } // namespace lcgh

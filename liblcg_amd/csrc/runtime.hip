@@ -53,6 +53,8 @@ int ensure_init()
     }
     c.partials = c.partials_pair[0];
     HIPCHK(hipMalloc(&c.ax_partials, sizeof(double) * 2 * AXP_CAP));
+    HIPCHK(hipMalloc(&c.fin_ticket, sizeof(unsigned int)));
+    HIPCHK(hipMemset(c.fin_ticket, 0, sizeof(unsigned int)));
     c.state = c.state_pair[0];
     HIPCHK(hipHostMalloc((void **)&c.hstat, sizeof(HostStatus), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void **)&c.hstat_dev, c.hstat, 0));
@@ -291,7 +293,7 @@ int lcg_hip_spmv_dot(lcg_hip_csr_t A, const double *x, double *y, const double *
     int rc = ensure_init(); if (rc) return rc;
     Ctx &c = ctx();
     int slots = 0;
-    const int f = csr_ax_dot(A, x, y, u, 1, c.ax_partials, &slots, c.stream, nullptr);
+    const int f = csr_ax_dot(A, x, y, u, 1, c.ax_partials, &slots, c.stream, nullptr, nullptr);
     if (f < 0) return f;
     if (f == 0) {       // this matrix / kernel family keeps product and reduction apart
         rc = lcg_hip_spmv(A, x, y); if (rc) return rc;

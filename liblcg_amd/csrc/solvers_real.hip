@@ -20,9 +20,8 @@
 namespace lcgh {
 
 // DevState::s slots shared by the real solvers
-enum { S_AK = 0, S_BK, S_WK, S_RHO /* g.g | z.r | r.r0 */, S_M2, S_G2 /* residual numerator */ };
+// (S_AK .. S_G2, clamp1: devcommon.hpp)
 
-__device__ __forceinline__ double clamp1(double v) { return v < 1.0 ? 1.0 : v; }
 
 // ---- generic passes -------------------------------------------------------------------------
 struct OpDot1 {     // acc0 = a.b
@@ -181,30 +180,7 @@ struct FinCg1Start {    // a_0 = g.g / g.A.g, b_0 = 0 (d_0 = -g, lcg.cpp:171-176
         st->s[S_BK] = 0.0;
     }
 };
-struct FinCg1Close {    // the only scalar step of a body: counts it, closes it, prepares the next
-    static constexpr int NR = 4;
-    __device__ void operator()(DevState *st, const double *sum) const
-    {
-        st->it++;
-        if (!st->done) {
-            st->s[S_M2] = clamp1(sum[0]);
-            if (sum[3] > 0.0 || sum[0] != sum[0]) {         // lcg.cpp:247-253
-                st->t++;
-                st->done = 1; st->status = ST_NAN;
-            } else {
-                const double rho_new = sum[1];
-                const double bk = rho_new / st->s[S_RHO];                       // lcg.cpp:256
-                st->s[S_AK] = rho_new / (sum[2] - bk * rho_new / st->s[S_AK]);  // lcg.cpp:235 with d.Ad as above
-                st->s[S_BK] = bk;
-                st->s[S_RHO] = rho_new;
-                st->s[S_G2] = rho_new;
-                st->t++;
-                stop_rule(st, rho_new, st->s[S_M2]);
-            }
-        }
-        publish(st);
-    }
-};
+// (FinCg1Close -- the only scalar step of a body -- lives in devcommon.hpp: a sharded product's last block may run it)
 
 // ---- PCG ------------------------------------------------------------------------------------
 struct OpResidual { // r = B - Ax   (also the start of CGS/BiCGStab with extra copies)
@@ -358,17 +334,27 @@ struct RealCommon {
     // y = A.x followed by the sums y.u (and y.y): with the built-in product on a handle this process holds whole, the sums ride
     // in the product's epilogue (csr.hip: k_spmv_lds1d) and reach the next scalar step as its sum `row` (y.y: row + 1) -- *fused
     // says so; otherwise the product is made as always and the caller runs its own reducing pass
-    int ax_dot(const double *x, double *y, const double *u, bool yy, int row, bool *fused)
+    // fin_id / stepped: with sharded rows and the mailboxes the product's last block can also run the step that closes the body
+    // (FIN_*: devcommon.hpp, finish_body) -- *stepped says it will, and the caller then launches no scalar kernel.
+    int ax_dot(const double *x, double *y, const double *u, bool yy, int row, bool *fused, int fin_id = FIN_NONE, bool *stepped = nullptr)
     {
         int f = 0, slots = 0;
+        FinishPlan fp;
+        if (stepped) *stepped = false;
+        if (fin_id != FIN_NONE && stepped && !yy && comm_active() && xg_box(&fp.xb)) {
+            fp.fin = fin_id; fp.xg = 1; fp.ticket = c.fin_ticket; fp.partials = c.partials; fp.st = c.state;
+            fp.pc = drv.pcnt; fp.pc.axp = c.ax_partials; fp.pc.ax_n = 0; fp.pc.ax_row = row; fp.pc.ax_yy = 0; fp.pc.g[row] = 0;
+        }
         // (sharded rows: csr_ax_dot hands over to comm.hip, which always makes the product and answers 1 when it carried the sum, 2 when not)
         const bool builtin = Afp == lcg_hip_csr_ax && inst != nullptr;
         int rc = drv.timed_ax([&] {
-            if (builtin) f = csr_ax_dot(static_cast<lcg_hip_csr *>(inst), x, y, u, yy ? 1 : 0, c.ax_partials, &slots, c.stream, &c.state->done);
+            if (builtin) f = csr_ax_dot(static_cast<lcg_hip_csr *>(inst), x, y, u, yy ? 1 : 0, c.ax_partials, &slots, c.stream, &c.state->done,
+                                        fp.fin ? &fp : nullptr);
             if (f == 0) Afp(inst, x, y, n);
             else if (f < 0 && !c.ax_rc) c.ax_rc = f;
         });
         *fused = f == 1;
+        if (stepped) *stepped = f == 1 && builtin && fp.fin != FIN_NONE;
         if (f == 1) {
             PartCount &pc = drv.pcnt;
             pc.axp = c.ax_partials; pc.ax_n = slots; pc.ax_row = row; pc.ax_yy = yy ? 1 : 0;
@@ -448,11 +434,13 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
             TRY(k.drv.scal(FinCg1Start{}));
             rc = k.run_loop([&]() -> int {
                 TRY(k.drv.vec(OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
+                bool stepped = false;
                 if (!last_body()) {
-                    bool f; TRY(k.ax_dot(g, w, g, false, 2, &f));
+                    // (sharded rows with the mailboxes: the last block of the kernel that completes g.w reduces, exchanges and steps)
+                    bool f; TRY(k.ax_dot(g, w, g, false, 2, &f, FIN_CG1_CLOSE, &stepped));
                     if (!f) { c.err = "A.x stopped carrying its dot in the middle of a solve"; return LCG_HIP_E_ARG; }
                 }
-                TRY(k.drv.scal(FinCg1Close{}));
+                if (!stepped) TRY(k.drv.scal(FinCg1Close{}));
                 return 0;
             });
         } else if (Pfp == nullptr && !comm_active()) {

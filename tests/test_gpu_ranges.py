@@ -1,0 +1,222 @@
+"""-m gpu: row ranges (csr.hip, "row ranges"; lcg_hip_csr_set_ranges) -- matrices whose rows fall into different column-pattern
+classes: a 27-point stencil in 90 % of the rows, long-range random couplings in the rest.
+
+  * <= 60,000 rows, built on the host, ranges forced: A.x row by row against the oracle's product (1e-13 |A||x|), the cut where
+    the generator put it, CG (block-diagonal SPD mix) and BiCGStab / CGS (non-symmetric mix, couplings anywhere) against the
+    oracle with the bands of tests/test_gpu_fuzz_solvers.py and six capped iterations to 1e-13;
+  * 10M rows, composed on the device (8M rows of constant diagonals + 2M rows of scrambled columns, block diagonal), automatic
+    mode: two ranges, the run-block kernel on the first and the binned product on the second -- asserted --, and y BIT-EQUAL to
+    the products of the two blocks as matrices of their own (a range is multiplied by the kernel it would get alone).
+The A.x contract is the user's callback of the reference (lcg.h:37-38): any CSR must be multiplied correctly whatever mix of
+patterns it holds."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def stencil27(nx, ny, nz):
+    """CSR of a 27-point stencil on an nx x ny x nz grid (row-major, x fastest): -1 off the diagonal, 27 on it (SPD)."""
+    n = nx * ny * nz
+    idx = np.arange(n).reshape(nz, ny, nx)
+    rows, cols, vals = [], [], []
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                src = idx[max(0, -dz):nz - max(0, dz), max(0, -dy):ny - max(0, dy), max(0, -dx):nx - max(0, dx)]
+                dst = idx[max(0, dz):nz - max(0, -dz), max(0, dy):ny - max(0, -dy), max(0, dx):nx - max(0, -dx)]
+                rows.append(src.ravel()); cols.append(dst.ravel())
+                vals.append(np.full(src.size, 27.0 if (dx, dy, dz) == (0, 0, 0) else -1.0))
+    return n, np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+
+
+def to_csr(n, r, c, v):
+    order = np.lexsort((c, r))
+    r, c, v = r[order], c[order], v[order]
+    rp = np.zeros(n + 1, np.int64); np.add.at(rp, r + 1, 1)
+    return np.cumsum(rp).astype(np.int32), c.astype(np.int32), v.astype(np.float64)
+
+
+def mixed_system(rng, symmetric, dims=None):
+    """90 % stencil rows followed by 10 % rows with 24 long-range couplings each.  symmetric: the couplings stay inside the
+    last block and are mirrored (block-diagonal SPD); otherwise they go anywhere in the matrix (A != A^T)."""
+    nx, ny, nz = dims or (int(rng.integers(24, 40)), int(rng.integers(24, 40)), int(rng.integers(20, 34)))
+    n1, r, c, v = stencil27(nx, ny, nz)
+    n2 = max(2048, (n1 // 9) // 2048 * 2048 + 2048)
+    n1p = (n1 + 2047) // 2048 * 2048          # the stencil block padded with diagonal-only rows up to a chunk boundary
+    pad = np.arange(n1, n1p)
+    n = n1p + n2
+    rr = np.repeat(np.arange(n1p, n), 24)
+    if symmetric:
+        cc = rng.integers(n1p, n, rr.size)
+        keep = cc != rr
+        rr, cc = rr[keep], cc[keep]
+        w = -rng.random(rr.size)
+        R = np.concatenate([rr, cc]); Cc = np.concatenate([cc, rr]); W = np.concatenate([w, w])
+    else:
+        cc = rng.integers(0, n, rr.size)
+        keep = cc != rr
+        R, Cc, W = rr[keep], cc[keep], -rng.random(int(keep.sum()))
+    # duplicates are summed into one entry; the diagonal of the coupled rows dominates their row
+    key = R.astype(np.int64) * n + Cc
+    uk, inv = np.unique(key, return_inverse=True)
+    Wk = np.zeros(uk.size); np.add.at(Wk, inv, W)
+    R, Cc = (uk // n).astype(np.int64), (uk % n).astype(np.int64)
+    dsum = np.zeros(n); np.add.at(dsum, R, np.abs(Wk))
+    drows = np.concatenate([pad, np.arange(n1p, n)])
+    r = np.concatenate([r, R, drows]); c = np.concatenate([c, Cc, drows])
+    v = np.concatenate([v, Wk, np.concatenate([np.full(pad.size, 1.0), dsum[n1p:] + 0.5])])
+    return n, n1p, to_csr(n, r, c, v)
+
+
+def test_mixed_rows_against_the_oracle(port):
+    from liblcg_amd import _lib, api
+    from oracle import pyoracle as po
+    lib = _lib.load()
+    rng = np.random.default_rng(2026)
+    for case in range(4):
+        symmetric = case % 2 == 0
+        n, cut, (rp, ci, v) = mixed_system(rng, symmetric)
+        assert n <= 60000
+        A = api.CsrMatrix.from_csr(rp, ci, v)
+        assert lib.lcg_hip_csr_set_ranges(A.h, 1) == 0
+        xh = rng.standard_normal(n)
+        x = torch.from_numpy(xh).cuda(); y = torch.empty_like(x)
+        A.spmv(x, y); api.synchronize()
+        first = (C.c_int * 8)()
+        nr = lib.lcg_hip_csr_ranges(A.h, 8, first)
+        name = lib.lcg_hip_csr_last_kernel(A.h).decode()
+        assert nr == 2 and list(first[:2]) == [0, cut], (case, nr, list(first[:nr]), cut, name)
+        assert name.startswith("rows [0, %d): " % cut) and (" | rows [%d, %d): " % (cut, n)) in name, name
+        ref = port.csr_matvec(rp, ci, v, xh)
+        bound = port.csr_matvec(rp, ci, np.abs(v), np.abs(xh))
+        assert float(np.max(np.abs(y.cpu().numpy() - ref) / bound)) <= 1e-13, (case, name)
+        # one kernel family for all rows gives the same product to rounding
+        assert lib.lcg_hip_csr_set_ranges(A.h, 0) == 0
+        y0 = torch.empty_like(x); A.spmv(x, y0); api.synchronize()
+        assert lib.lcg_hip_csr_ranges(A.h, 8, first) == 0
+        assert float(np.max(np.abs(y0.cpu().numpy() - ref) / bound)) <= 1e-13, case
+        assert lib.lcg_hip_csr_set_ranges(A.h, 1) == 0
+        # solvers through the split product
+        xt = torch.from_numpy(rng.standard_normal(n)).cuda()
+        b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
+        bh = b.cpu().numpy()
+        eps, abs_diff = 1e-12, case // 2
+        for sid, nm in (((api.LCG_CG, "cg"),) if symmetric else ((api.LCG_BICGSTAB, "bicgstab"), (api.LCG_CGS, "cgs"))):
+            opara = po.default_para(epsilon=eps, abs_diff=abs_diff)
+            ref = port.solve(sid, rp, ci, v, bh, para=opara)
+            sens, dit = 0.0, 0
+            for k in range(2):
+                alt = port.solve(sid, rp, ci, v, bh * (1.0 + 1e-16 * np.random.default_rng(10 * case + k).standard_normal(n)), para=opara)
+                sens = max(sens, np.linalg.norm(alt["x"] - ref["x"]) / np.linalg.norm(ref["x"]))
+                dit = max(dit, abs(alt["iters"] - ref["iters"]))
+            m = torch.zeros(n, dtype=torch.float64, device="cuda")
+            info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=eps, abs_diff=abs_diff), A, sid)
+            assert lib.lcg_hip_csr_ranges(A.h, 8, first) == 2
+            tag = (case, n, nm, info.iterations, ref["iters"], sens, dit)
+            assert info.ret == ref["ret"] == 0, tag
+            assert abs(info.iterations - ref["iters"]) <= max(3, 3 * dit, 0.05 * ref["iters"]), tag
+            assert np.linalg.norm(m.cpu().numpy() - ref["x"]) <= max(1e-9, 20 * sens) * np.linalg.norm(ref["x"]), tag
+            m.zero_()
+            i6 = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=eps, abs_diff=abs_diff, max_iterations=6), A, sid)
+            r6 = port.solve(sid, rp, ci, v, bh, para=po.default_para(epsilon=eps, abs_diff=abs_diff, max_iterations=6))
+            assert i6.ret == r6["ret"] == -1019 and i6.iterations == 6, tag
+            assert np.linalg.norm(m.cpu().numpy() - r6["x"]) <= 1e-13 * np.linalg.norm(r6["x"]), tag
+        A.destroy()
+
+
+def test_seven_million_entries_automatic(port):
+    """64^3 stencil rows + 10 % coupled rows (7.8M entries): the automatic mode cuts by itself; A.x against the oracle's product."""
+    from liblcg_amd import _lib, api
+    lib = _lib.load()
+    rng = np.random.default_rng(64)
+    n, cut, (rp, ci, v) = mixed_system(rng, False, (64, 64, 64))
+    assert len(ci) >= 4_000_000
+    A = api.CsrMatrix.from_csr(rp, ci, v)
+    xh = rng.standard_normal(n)
+    x = torch.from_numpy(xh).cuda(); y = torch.empty_like(x)
+    A.spmv(x, y); api.synchronize()
+    first = (C.c_int * 8)()
+    nr = lib.lcg_hip_csr_ranges(A.h, 8, first)
+    name = lib.lcg_hip_csr_last_kernel(A.h).decode()
+    assert nr == 2 and list(first[:2]) == [0, cut], (nr, list(first[:nr]), cut, name)
+    # (a 64-row block of this grid is one x-line with its two boundary rows: packed columns, no run blocks)
+    assert "rows [0, %d): k_spmv_ldsp (LDS-staged" % cut in name, name
+    ref = port.csr_matvec(rp, ci, v, xh)
+    bound = port.csr_matvec(rp, ci, np.abs(v), np.abs(xh))
+    assert float(np.max(np.abs(y.cpu().numpy() - ref) / bound)) <= 1e-13, name
+    A.destroy()
+
+
+def device_arrays(A):
+    """(rowptr, col, val) of a handle as torch tensors on the device (copies)."""
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    pr, pc, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert lib.lcg_hip_csr_arrays(A.h, C.byref(pr), C.byref(pc), C.byref(pv)) == 0
+    nnz = A.nnz
+    rp = torch.empty(A.n + 1, dtype=torch.int32, device="cuda"); ci = torch.empty(nnz, dtype=torch.int32, device="cuda")
+    v = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    for dst, src in ((rp, pr), (ci, pc), (v, pv)):
+        assert lib.lcg_hip_memcpy(dst.data_ptr(), src, dst.numel() * dst.element_size(), 3) == 0
+    return rp, ci, v
+
+
+def test_ten_million_rows_two_classes():
+    from liblcg_amd import _lib, api
+    lib = _lib.load()
+    n1, n2 = 8_000_000, 2_000_000
+    n = n1 + n2
+    G1 = api.CsrMatrix.generate(n1, 16, 131072, True, 3, 0.01, pattern=api.GEN_DIAGONALS)
+    G2 = api.CsrMatrix.generate(n2, 16, 0, True, 5, 0.01, pattern=api.GEN_SCRAMBLED)
+    rp1, c1, v1 = device_arrays(G1)
+    rp2, c2, v2 = device_arrays(G2)
+    nnz1 = int(rp1[-1].item())
+    rp = torch.cat([rp1, rp2[1:] + nnz1]); ci = torch.cat([c1, c2 + n1]); v = torch.cat([v1, v2])
+    # the scattered block as a matrix of its own WITH the columns it has in the mix (2M x 10M): the binned product sums a row in
+    # an order that depends on where its columns fall in the 8192-column tiles
+    G2.destroy()
+    G2 = api.CsrMatrix.from_csr(rp2, c2 + n1, v2, n_cols=n)
+    del rp1, c1, v1, rp2, c2, v2
+    A = api.CsrMatrix.from_csr(rp, ci, v, n_cols=n)
+    x = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 11, 0, n, x)
+    y = torch.empty_like(x)
+    A.spmv(x, y); api.synchronize()
+    first = (C.c_int * 8)()
+    nr = lib.lcg_hip_csr_ranges(A.h, 8, first)
+    name = lib.lcg_hip_csr_last_kernel(A.h).decode()
+    assert nr == 2 and list(first[:2]) == [0, n1], (nr, list(first[:nr]), name)
+    a, b = name.split(" | ")
+    assert a.startswith("rows [0, %d): k_spmv_ldsp (LDS-staged, run blocks" % n1), name
+    assert b.startswith("rows [%d, %d): k_bin_expand + k_bin_reduce" % (n1, n)), name
+    # each block as a matrix of its own: the same kernels, the same bits
+    y1 = torch.empty(n1, dtype=torch.float64, device="cuda"); y2 = torch.empty(n2, dtype=torch.float64, device="cuda")
+    G1.spmv(x[:n1].contiguous(), y1); G2.spmv(x, y2); api.synchronize()
+    assert lib.lcg_hip_csr_last_kernel(G1.h).decode().startswith("k_spmv_ldsp (LDS-staged, run blocks")
+    assert lib.lcg_hip_csr_last_kernel(G2.h).decode().startswith("k_bin_expand")
+    assert torch.equal(y[:n1], y1) and torch.equal(y[n1:], y2)
+    # and against one kernel family for all rows (what the library did before): rounding apart, and slower
+    import time
+
+    def timed(out, reps=10):
+        A.spmv(x, out); api.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            A.spmv(x, out)
+        api.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e6
+    t_split = timed(y)
+    assert lib.lcg_hip_csr_set_ranges(A.h, 0) == 0
+    y0 = torch.empty_like(x)
+    t_whole = timed(y0)
+    whole = lib.lcg_hip_csr_last_kernel(A.h).decode()
+    assert lib.lcg_hip_csr_ranges(A.h, 8, first) == 0
+    print(f"\n10M mixed rows: ranges {t_split:.0f} us ({name}) vs one family {t_whole:.0f} us ({whole})")
+    scale = float(torch.max(torch.abs(y)).item())
+    assert float(torch.max(torch.abs(y0 - y)).item()) <= 1e-11 * scale
+    assert t_split < t_whole
+    for M in (A, G1, G2):
+        M.destroy()
