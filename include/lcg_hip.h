@@ -116,6 +116,9 @@ double lcg_hip_last_residual(void);
 int    lcg_hip_set_profiling(int on);
 double lcg_hip_last_ax_mean_us(void);
 int    lcg_hip_last_ax_calls(void);
+/* Scalar steps of the latest solve that ran in the last block of a sharded product instead of in a kernel of their own
+ * (opt-in: LCG_HIP_FINISHER=1, plain CG's one-reduction schedule over the mailboxes; 0 otherwise).  No reference counterpart. */
+int    lcg_hip_last_finisher_steps(void);
 /* The solvers keep their temporaries (the reference allocates and frees them per call, lcg.cpp:158-166,266-271) for the
  * next solve; this gives the idle ones back to the device. */
 int    lcg_hip_trim(void);

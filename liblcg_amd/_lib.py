@@ -50,6 +50,7 @@ SIGNATURES = {
     "lcg_hip_set_cg_schedule": (C.c_int, [C.c_int]),
     "lcg_hip_last_ax_mean_us": (C.c_double, []),
     "lcg_hip_last_ax_calls": (C.c_int, []),
+    "lcg_hip_last_finisher_steps": (C.c_int, []),
     "lcg_hip_trim": (C.c_int, []),
     "lcg_hip_solver": (C.c_int, [vp, vp, vp, vp, C.c_int, C.POINTER(LcgPara), vp, C.c_int, C.c_int]),
     "lcg_hip_solver_preconditioned": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.POINTER(LcgPara), vp, C.c_int, C.c_int]),

@@ -139,6 +139,7 @@ struct Driver {
         // every body where a body is long and only 6 are kept in flight
         h.pub_mask = comm_active() ? 0x3fffffff : ((cplx ? 2 * n : n) >= (1 << 20) ? 0 : 3);
         if (const char *e = std::getenv("LCG_HIP_PUBLISH_EVERY")) h.pub_mask = std::max(1, atoi(e)) - 1;
+        c.fin_steps = 0;
         c.hstat->it = 0; c.hstat->done = 0; c.hstat->status = 0; c.hstat->t = 0; c.hstat->residual = 0.0;
         (void)lcg_hip_last_ax_mean_us();        // a previous solve's events, if nobody asked yet: they are about to be reused
         // from a pinned staging slot, in stream order in front of the solve's first kernel: no synchronisation here (the

@@ -132,6 +132,7 @@ struct Ctx {
     double *partials_pair[2] = {nullptr, nullptr};
     double *ax_partials = nullptr;     // [2][AXP_CAP]: the sums an A.x kernel carried (csr.hip: k_spmv_lds1d), see PartCount
     unsigned int *fin_ticket = nullptr; // FinishPlan::ticket (zero between launches)
+    int fin_steps = 0;                  // scalar steps of the latest solve that a product's last block ran (finish_body)
     DevState *state_pair[2] = {nullptr, nullptr};
     HostStatus *hstat = nullptr;       // pinned, mapped
     HostStatus *hstat_dev = nullptr;   // device alias of hstat

@@ -248,6 +248,7 @@ int lcg_hip_trim(void)
     return 0;
 }
 int lcg_hip_last_ax_calls(void) { return ctx().last_ax_calls; }
+int lcg_hip_last_finisher_steps(void) { return ctx().fin_steps; }
 
 int lcg_hip_set_cg_schedule(int schedule)
 {

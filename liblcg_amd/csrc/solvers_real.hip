@@ -354,7 +354,7 @@ struct RealCommon {
             else if (f < 0 && !c.ax_rc) c.ax_rc = f;
         });
         *fused = f == 1;
-        if (stepped) *stepped = f == 1 && builtin && fp.fin != FIN_NONE;
+        if (stepped) { *stepped = f == 1 && builtin && fp.fin != FIN_NONE; if (*stepped) c.fin_steps++; }
         if (f == 1) {
             PartCount &pc = drv.pcnt;
             pc.axp = c.ax_partials; pc.ax_n = slots; pc.ax_row = row; pc.ax_yy = yy ? 1 : 0;
