@@ -356,7 +356,10 @@ static int plan_build(const CsrPart &P, hipStream_t s, BinnedPlan **out, const c
     BCHK(hipGetLastError());
     rc = device_exclusive_scan(nt, tileg, tileofs, s, &total1);
     if (rc) return cleanup(rc);
-    if (total2 <= 0 || total1 <= 0 || total2 > 0x7fffffffL / BN_G || total1 > total2) { *why = "stream length out of range"; return cleanup(0); }
+    // (granule offsets are int32, entry positions 64-bit everywhere: up to 2^31 granules = 1.7e10 padded entries.  At 6e7 rows of 33
+    //  scattered entries a (chunk, tile) group holds 9 entries on average and the padding to whole granules adds ~40 %: 2.8e9 entries,
+    //  3.5e8 granules -- round 2's limit of 2^31 / 8 granules refused that system)
+    if (total2 <= 0 || total1 <= 0 || total2 > 0x7fffffffL - BN_STEP || total1 > total2) { *why = "stream length out of range"; return cleanup(0); }
     B->gran2 = total2; B->gran1 = total1;
     const size_t e2 = (size_t)BN_G * total2 + BN_STEP;      // one step of slack: the last wavefront may load past its bin
     const size_t e1 = (size_t)BN_G * total1 + BN_G;

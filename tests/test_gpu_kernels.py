@@ -549,7 +549,7 @@ def test_full_size_properties(api):
     assert ((Ax - b).norm().item() / n) <= 1.01e-10                       # the monitored quantity, recomputed
 
 
-@pytest.mark.parametrize("pattern", ["constant_diagonals", "row_random_band"])
+@pytest.mark.parametrize("pattern", ["constant_diagonals", "row_random_band", "scrambled"])
 def test_near_the_int32_limit(api, pattern):
     """The largest system the int32 CSR of the reference's interface can hold at this density: 60M rows, 1.98e9 entries
     (92 % of 2^31), 24 GB of matrix -- entry offsets, the packed / tiled copies and the per-block tables all near their
@@ -558,14 +558,17 @@ def test_near_the_int32_limit(api, pattern):
     from liblcg_amd import _lib
     lib = _lib.load()
     n = 60_000_000
-    A = api.CsrMatrix.generate(n, 16, 131072, True, 1, 0.01, pattern=api.GEN_DIAGONALS if pattern == "constant_diagonals" else api.GEN_ROW_RANDOM_BAND)
+    pat = {"constant_diagonals": api.GEN_DIAGONALS, "row_random_band": api.GEN_ROW_RANDOM_BAND, "scrambled": api.GEN_SCRAMBLED}[pattern]
+    A = api.CsrMatrix.generate(n, 16, 131072 if pattern != "scrambled" else 0, True, 1, 0.01, pattern=pat)
     assert 0.9 * 2**31 < A.nnz < 2**31
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
     y = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
     Ax, Ay, Az = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
     A.spmv(x, Ax); A.spmv(y, Ay); api.synchronize()
-    assert ("run blocks" if pattern == "constant_diagonals" else "k_tile_spmv") in lib.lcg_hip_csr_last_kernel(A.h).decode()
+    # (scrambled: 2.1e8 (chunk, tile) groups of 9 entries -- the binned plan's granule offsets near THEIR limit too)
+    want = {"constant_diagonals": "run blocks", "row_random_band": "k_tile_spmv", "scrambled": "k_bin_expand + k_bin_reduce"}[pattern]
+    assert want in lib.lcg_hip_csr_last_kernel(A.h).decode(), (lib.lcg_hip_csr_last_kernel(A.h).decode(), lib.lcg_hip_csr_binned_status(A.h))
     z = x + 2.0 * y
     A.spmv(z, Az); api.synchronize()
     assert (Az - (Ax + 2.0 * Ay)).abs().max().item() <= 1e-12 * Az.abs().max().item()
