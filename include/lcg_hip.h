@@ -128,7 +128,10 @@ int    lcg_hip_trim(void);
  * A.d follows from Ad = beta Ad - w, and g.g, g.w, m.m share ONE reduction (one RCCL all-reduce
  * per iteration instead of two); same iterates in exact arithmetic, same stop rule and counts.
  * LCG_HIP_CG_AUTO (default): one-reduction when the rows are sharded and, on one GPU, for systems of fewer than 2^17 rows
- * (an iteration is then a chain of kernel latencies: three launches instead of four); classic otherwise. */
+ * (an iteration is then a chain of kernel latencies: two launches instead of three) unless A.x or M is a callback of the
+ * caller's own -- such a callback sees the reference's sequence of calls (the rearrangement makes one product more before the first
+ * stop test); classic otherwise.  tests/test_gpu_solvers.py::test_cg_schedules_on_an_ill_conditioned_system holds both schedules
+ * to the oracle's classic loop on a system of condition number 3.6e6 (iteration count, true residual, monitored = true). */
 enum { LCG_HIP_CG_AUTO = 0, LCG_HIP_CG_CLASSIC = 1, LCG_HIP_CG_ONE_REDUCTION = 2 };
 int    lcg_hip_set_cg_schedule(int schedule);
 

@@ -27,6 +27,9 @@ struct Driver {
     int max_it, abs_diff;
     double eps;
     int enq = 0;       // iteration bodies enqueued
+    // a callback of the caller's own (not the built-in product / Jacobi) is in the loop: such a callback cannot honour the stop
+    // flag, so nothing is enqueued ahead of a verdict the reference would have returned on first (lcg.cpp:186-203)
+    bool user_cb = false;
 
     Driver(Ctx &c_, long n_, bool cplx_, int max_it_, double eps_, int abs_diff_)
         : c(c_), n(n_), cplx(cplx_), max_it(max_it_), abs_diff(abs_diff_), eps(eps_) { c.in_solve = true; c.ax_rc = 0; }
@@ -185,17 +188,19 @@ struct Driver {
     {
         DevState h;
         int rc = 0;
-        if (has_pfp) {
+        if (has_pfp || user_cb) {
             rc = read_state(h);
             if (rc) return rc;
             if (h.status == ST_ALREADY) {                   // lcg.cpp:186-203
-                pfp(h.residual, 0);
+                if (has_pfp) pfp(h.residual, 0);
                 finish(h);
                 return LCG_ALREADY_OPTIMIZIED;
             }
         }
-        // (without a progress callback nobody needs the setup's verdict yet: "already optimised" has set the stop flag, the
-        //  bodies enqueued below fall through, and the verdict is read with the final state -- one stream drain less per solve)
+        // (without a progress callback and with the built-in callbacks nobody needs the setup's verdict yet: "already optimised" has
+        //  set the stop flag, the bodies enqueued below fall through -- the built-in products honour the flag --, and the verdict is
+        //  read with the final state: one stream drain less per solve.  A user's A.x / M callback would be CALLED for every body
+        //  enqueued ahead, which the reference never does after this verdict: there the verdict is read first.)
         if (has_pfp) {
             for (;;) {                                      // lcg.cpp:206-230, one sync per iteration
                 if (pfp(h.residual, h.t)) { finish(h); return LCG_STOP; }

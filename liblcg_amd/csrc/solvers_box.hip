@@ -159,6 +159,7 @@ static int solve_pg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
         low = dlow; hig = dhig;
     }
     Driver drv(c, n, false, p.max_iterations, p.epsilon, p.abs_diff);
+    drv.user_cb = Afp != lcg_hip_csr_ax;
     TRY(drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
     const uintptr_t a_all = al(m) | al(B) | al(g) | al(Ad) | al(mn) | al(low) | al(hig);
@@ -206,6 +207,7 @@ static int solve_spg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const 
         low = dlow; hig = dhig;
     }
     Driver drv(c, n, false, p.max_iterations, p.epsilon, p.abs_diff);
+    drv.user_cb = Afp != lcg_hip_csr_ax;
     TRY(drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
     const uintptr_t a_all = al(m) | al(B) | al(g) | al(Ad) | al(mn) | al(d) | al(low) | al(hig);

@@ -542,7 +542,8 @@ struct CplxCommon {
     Ctx &c; Driver drv; clcg_para para; void *inst; clcg_hip_axfunc_ptr Afp; clcg_hip_progress_ptr Pfp;
     double *m; int n;
     CplxCommon(Ctx &c_, int n_, const clcg_para &p, void *inst_, clcg_hip_axfunc_ptr A, clcg_hip_progress_ptr P, double *m_)
-        : c(c_), drv(c_, n_, true, p.max_iterations, p.epsilon, p.abs_diff), para(p), inst(inst_), Afp(A), Pfp(P), m(m_), n(n_) {}
+        : c(c_), drv(c_, n_, true, p.max_iterations, p.epsilon, p.abs_diff), para(p), inst(inst_), Afp(A), Pfp(P), m(m_), n(n_)
+    { drv.user_cb = A != clcg_hip_csr_ax; }
     int ax(const double *x, double *y) { return drv.timed_ax([&] { Afp(inst, x, y, n, 0, 0); }); }
     int axop(const double *x, double *y, int layout, int conj) { return drv.timed_ax([&] { Afp(inst, x, y, n, layout, conj); }); }
     int run_loop(const std::function<int()> &body)
@@ -618,6 +619,7 @@ static int solve_cpcg(clcg_hip_axfunc_ptr Afp, clcg_hip_axfunc_ptr Mfp, clcg_hip
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
     const double *inv = nullptr;        // built-in Jacobi on a complex handle: fold M^-1 into the update
+    if (Mfp != clcg_hip_jacobi_mx) k.drv.user_cb = true;
     if (Mfp == clcg_hip_jacobi_mx && inst) {
         const lcg_hip_csr *A = static_cast<const lcg_hip_csr *>(inst);
         if (A->is_complex && A->n_rows == n) inv = A->invdiag;
@@ -662,6 +664,7 @@ static int solve_cpbicg(clcg_hip_axfunc_ptr Afp, clcg_hip_axfunc_ptr Mfp, clcg_h
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
     const double *inv = nullptr;        // built-in Jacobi on a complex handle: fold M^-1 into the update
+    if (Mfp != clcg_hip_jacobi_mx) k.drv.user_cb = true;
     if (Mfp == clcg_hip_jacobi_mx && inst) {
         const lcg_hip_csr *A = static_cast<const lcg_hip_csr *>(inst);
         if (A->is_complex && A->n_rows == n) inv = A->invdiag;

@@ -329,7 +329,7 @@ struct RealCommon {
     double *m; int n;
     RealCommon(Ctx &c_, int n_, const lcg_para &p, void *inst_, lcg_axfunc_ptr A, lcg_progress_ptr P, double *m_)
         : c(c_), drv(c_, n_, false, p.max_iterations, p.epsilon, p.abs_diff), para(p), inst(inst_),
-          Afp(A), Pfp(P), m(m_), n(n_) {}
+          Afp(A), Pfp(P), m(m_), n(n_) { drv.user_cb = A != lcg_hip_csr_ax; }
     int ax(const double *x, double *y) { return drv.timed_ax([&] { Afp(inst, x, y, n); }); }
     // y = A.x followed by the sums y.u (and y.y): with the built-in product on a handle this process holds whole, the sums ride
     // in the product's epilogue (csr.hip: k_spmv_lds1d) and reach the next scalar step as its sum `row` (y.y: row + 1) -- *fused
@@ -403,8 +403,10 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
     const uintptr_t a_upd = al(m) | al(g) | al(d) | al(Ad);
     // AUTO: the one-reduction schedule when the rows are sharded (one all-reduce per iteration) and on one GPU for systems so
     // small that an iteration is a chain of kernel latencies (< 2^17 rows): three launches per iteration instead of four
+    // (a callback of the caller's own keeps the reference's recurrence and with it the reference's sequence of callback calls:
+    //  the one-reduction arrangement makes one product more before the first stop test)
     const bool one_reduction = c.cg_schedule == LCG_HIP_CG_ONE_REDUCTION ||
-                               (c.cg_schedule == LCG_HIP_CG_AUTO && (comm_active() || n < (1 << 17)));
+                               (c.cg_schedule == LCG_HIP_CG_AUTO && (comm_active() || (n < (1 << 17) && !k.drv.user_cb)));
     if (one_reduction) {
         double *w; TRY(ws.get(w, nullptr, sizeof(double) * n));
         bool fused; TRY(k.ax_dot(g, w, g, false, 0, &fused));
@@ -503,6 +505,7 @@ static int solve_pcg(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pf
     DevState *st = c.state;
     // built-in Jacobi on a handle that owns its reciprocal diagonal: fold M^-1 into the update
     const double *invdiag = nullptr;
+    if (Mfp != lcg_hip_jacobi_mx) k.drv.user_cb = true;
     if (Mfp == lcg_hip_jacobi_mx && inst) {
         const lcg_hip_csr *A = static_cast<const lcg_hip_csr *>(inst);
         if (!A->is_complex && A->n_rows == n) invdiag = A->invdiag;

@@ -98,3 +98,28 @@ def test_product_never_touches_the_oracle():
                 assert "/root/reference" not in text, f
     ldd = subprocess.check_output(["ldd", os.path.join(pkg, "lib", "liblcg_hip.so")], text=True)
     assert "oracle" not in ldd and "liblcg_ref" not in ldd
+
+
+def test_lds_fp64_adds_are_the_hardware_instruction(tmp_path):
+    """The tiled and binned products promise the same bits from call to call: a row is summed by one wavefront in stream order
+    with the LDS's own fp64 add.  That holds only if the relaxed workgroup-scope atomic add on LDS lowers to ds_add_f64 and not
+    to a compare-and-swap loop (whose retry order would depend on timing): checked on the gfx950 code the library is built
+    from.  The order of same-address lanes inside one ds_add_f64 is verified on the GPU (tests/test_gpu_binned.py)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "liblcg_amd", "csrc")
+    for name, kernels in (("csr_tiled.hip", ("k_tile_spmv2",)), ("csr_binned.hip", ("k_bin_reduce",))):
+        out = str(tmp_path / (name + ".s"))
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + src,
+                        "--cuda-device-only", "-S", "-o", out, os.path.join(src, name)], check=True, capture_output=True, timeout=600)
+        asm = open(out).read()
+        for k in kernels:
+            bodies = [b for b in asm.split(".globl")[1:] if k in b.split("\n", 1)[0]]
+            assert bodies, (name, k)
+            for b in bodies:
+                code = b.split("s_endpgm")[0]
+                assert "ds_add_f64" in code, (name, k)
+                assert "ds_cmpst" not in code and "ds_cmpswap" not in code, (name, k)

@@ -193,6 +193,72 @@ def test_python_callback_as_afp(api, case10k, A10k):
     assert np.linalg.norm(m.cpu().numpy() - xs) <= 1e-7
 
 
+def test_already_optimised_with_a_user_callback_calls_it_as_the_reference_does(api, case10k, A10k):
+    """lcg.cpp:168-203: with a start that already meets the tolerance the reference calls Afp ONCE (the set-up product) and
+    returns LCG_ALREADY_OPTIMIZIED.  A user's callback cannot honour the device's stop flag, so nothing may be enqueued ahead of
+    that verdict (up to 24 bodies used to be)."""
+    n, rp, ci, v, b, xs = case10k
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    for sid, per_setup in ((api.LCG_CG, 1), (api.LCG_CGS, 1), (api.LCG_BICGSTAB, 1)):
+        calls = [0]
+
+        def my_ax(inst, x, y, nn):
+            calls[0] += 1
+            lib.lcg_hip_spmv(A10k.h, x, y)
+        m = torch.from_numpy(xs.copy()).cuda()
+        info = api.lcg_solver(my_ax, None, m, torch.from_numpy(b).cuda(), n, api.lcg_default_parameters(epsilon=1e-6), None, sid)
+        assert info.ret == 2 and info.iterations == 0 and calls[0] == per_setup, (sid, info.ret, calls[0])
+        assert np.array_equal(m.cpu().numpy(), xs)
+
+
+def test_cg_schedules_on_an_ill_conditioned_system(api, port):
+    """Below 2^17 rows one GPU runs CG in the one-reduction (Chronopoulos-Gear) arrangement (two launches per iteration); the
+    reference's loop (lcg.cpp:206-264) is the classic two-reduction recurrence.  Same iterates in exact arithmetic -- here on
+    a system where rounding has room to show: the 1D Laplacian of 3000 rows (condition number 3.6e6; 2981 iterations to 1e-16).
+    Both schedules against the oracle's classic loop: iteration counts in the band the oracle's own 1-ulp sensitivity gives,
+    the TRUE residual of the answer within the stop rule, and the monitored residual equal to the true one."""
+    from oracle import pyoracle as po
+    n = 3000
+    rp = np.zeros(n + 1, np.int32); ci = []; v = []
+    for i in range(n):
+        for j, a in ((i - 1, -1.0), (i, 2.0), (i + 1, -1.0)):
+            if 0 <= j < n:
+                ci.append(j); v.append(a)
+        rp[i + 1] = len(ci)
+    ci = np.array(ci, np.int32); v = np.array(v)
+    rng = np.random.default_rng(5)
+    xt = rng.standard_normal(n)
+    b = port.csr_matvec(rp, ci, v, xt)
+    eps = 1e-16
+    opara = po.default_para(epsilon=eps, abs_diff=0, max_iterations=20000)
+    ref = port.solve(po.LCG_CG, rp, ci, v, b, para=opara)
+    assert ref["ret"] == 0 and ref["iters"] > 1000
+    dit = 0
+    for k in range(3):
+        alt = port.solve(po.LCG_CG, rp, ci, v, b * (1.0 + 1e-16 * np.random.default_rng(k).standard_normal(n)), para=opara)
+        dit = max(dit, abs(alt["iters"] - ref["iters"]))
+    A = api.CsrMatrix.from_csr(rp, ci, v)
+    bd = torch.from_numpy(b).cuda()
+    try:
+        for sched in (api.CG_AUTO, api.CG_CLASSIC, api.CG_ONE_REDUCTION):
+            api.set_cg_schedule(sched)
+            m = torch.zeros(n, dtype=torch.float64, device="cuda")
+            info = api.lcg_solver("lcg_hip_csr_ax", None, m, bd, n, api.lcg_default_parameters(epsilon=eps, abs_diff=0, max_iterations=20000), A, api.LCG_CG)
+            x = m.cpu().numpy()
+            tag = (sched, info.ret, info.iterations, ref["iters"], dit)
+            assert info.ret == 0, tag
+            assert abs(info.iterations - ref["iters"]) <= max(5, 3 * dit, 0.03 * ref["iters"]), tag
+            r = port.csr_matvec(rp, ci, v, x) - b
+            true_res = float(r @ r) / max(float(x @ x), 1.0)               # lcg.cpp:208-222 (relative form)
+            # the recurred g.g is what the stop rule sees; it may not flatter the answer
+            assert true_res <= 4.0 * eps and abs(true_res - info.residual) <= 0.5 * info.residual + 1e-14, tag + (true_res, info.residual)
+            assert np.linalg.norm(x - xt) <= 3.0 * np.linalg.norm(ref["x"] - xt), tag
+    finally:
+        api.set_cg_schedule(api.CG_AUTO)
+    A.destroy()
+
+
 # ------------------------------------------------------------------------------- complex
 def _solve_cplx(api, A, sid, b, n, para, shadow=None):
     m = torch.zeros(n, dtype=torch.complex128, device="cuda")
