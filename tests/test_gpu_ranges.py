@@ -220,3 +220,67 @@ def test_ten_million_rows_two_classes():
     assert t_split < t_whole
     for M in (A, G1, G2):
         M.destroy()
+
+
+def test_random_class_layouts(port):
+    """Fuzz: 2-5 stretches of rows, each of a random class -- tridiagonal / 9-point / 27-point stencil pieces (structured), columns
+    drawn per row inside a band (banded random), columns anywhere (scattered), empty rows in between, stretch heights that are
+    NOT multiples of the 64-row block or the 2048-row chunk -- forced ranges: the product row by row against the oracle's
+    (1e-13 |A||x|), wherever the cuts fall, and equal to rounding with the split switched off.  The cuts themselves are a
+    matter of speed, not of correctness: only their sanity is asserted (ascending, inside the matrix)."""
+    from liblcg_amd import _lib, api
+    lib = _lib.load()
+    rng = np.random.default_rng(777)
+    seen_ranges = 0
+    for case in range(12):
+        nstretch = int(rng.integers(2, 6))
+        heights = [int(rng.integers(1500, 30000)) for _ in range(nstretch)]
+        n = sum(heights)
+        rows, cols, vals = [], [], []
+        r0 = 0
+        for h in heights:
+            kind = int(rng.integers(0, 4))
+            rr = np.arange(r0, r0 + h)
+            if kind == 0:       # structured: a few constant diagonals
+                offs = np.unique(np.concatenate([[0], rng.integers(-min(2000, n - 1), min(2000, n - 1), int(rng.integers(3, 12)))]))
+                for o in offs:
+                    cc = rr + o
+                    ok = (cc >= 0) & (cc < n)
+                    rows.append(rr[ok]); cols.append(cc[ok]); vals.append(rng.standard_normal(int(ok.sum())))
+            elif kind == 1:     # banded random: every row draws its own columns within +-W
+                W = int(rng.integers(200, 5000)); k = int(rng.integers(4, 20))
+                cc = np.clip(rr[:, None] + rng.integers(-W, W + 1, (h, k)), 0, n - 1)
+                rows.append(np.repeat(rr, k)); cols.append(cc.ravel()); vals.append(rng.standard_normal(h * k))
+            elif kind == 2:     # scattered
+                k = int(rng.integers(2, 16))
+                rows.append(np.repeat(rr, k)); cols.append(rng.integers(0, n, h * k)); vals.append(rng.standard_normal(h * k))
+            else:               # mostly empty rows
+                keep = rr[rng.random(h) < 0.05]
+                rows.append(keep); cols.append(rng.integers(0, n, keep.size)); vals.append(rng.standard_normal(keep.size))
+            r0 += h
+        r = np.concatenate(rows); c = np.concatenate(cols); v = np.concatenate(vals)
+        key = r.astype(np.int64) * n + c
+        uk, inv = np.unique(key, return_inverse=True)
+        vk = np.zeros(uk.size); np.add.at(vk, inv, v)
+        rp, ci, vv = to_csr(n, (uk // n), (uk % n), vk)
+        A = api.CsrMatrix.from_csr(rp, ci, vv)
+        xh = rng.standard_normal(n)
+        x = torch.from_numpy(xh).cuda(); y = torch.empty_like(x)
+        ref = port.csr_matvec(rp, ci, vv, xh)
+        bound = port.csr_matvec(rp, ci, np.abs(vv), np.abs(xh)) + 1e-300
+        for mode in (1, 0, -1):
+            assert lib.lcg_hip_csr_set_ranges(A.h, mode) == 0
+            y.fill_(float("nan"))
+            A.spmv(x, y); api.synchronize()
+            first = (C.c_int * 8)()
+            nr = lib.lcg_hip_csr_ranges(A.h, 8, first)
+            name = lib.lcg_hip_csr_last_kernel(A.h).decode()
+            assert float(np.max(np.abs(y.cpu().numpy() - ref) / bound)) <= 1e-13, (case, mode, name)
+            if mode == 1:
+                seen_ranges += nr
+                cuts = list(first[:nr])
+                assert nr == 0 or (2 <= nr <= 8 and cuts[0] == 0 and cuts == sorted(set(cuts)) and cuts[-1] < n), (case, cuts)
+            else:
+                assert nr == 0 or mode == -1
+        A.destroy()
+    assert seen_ranges >= 12        # the split really was exercised
