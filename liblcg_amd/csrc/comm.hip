@@ -132,7 +132,7 @@ __global__ __launch_bounds__(VB) void k_xg_allreduce(double *v, int count, XgBox
     __shared__ double sums[MAXR];
     if ((int)threadIdx.x < MAXR) sums[threadIdx.x] = (int)threadIdx.x < count ? v[threadIdx.x] : 0.0;
     __syncthreads();
-    const bool ok = xg_allreduce<MAXR>(xb, sums);
+    const bool ok = xg_allreduce<MAXR>(xb, sums, xg_begin(xb));
     if ((int)threadIdx.x < count && ok) v[threadIdx.x] = sums[threadIdx.x];
     if (threadIdx.x == 0 && ok_out) *ok_out = ok ? 1 : 0;
 }
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(VB) void k_xg_allgather(const double *in, double *o
     __shared__ double got[MAXR][XG_MAXP];
     if ((int)threadIdx.x < MAXR) mine[threadIdx.x] = in[threadIdx.x];
     __syncthreads();
-    const bool ok = xg_exchange<MAXR>(xb, mine, got);
+    const bool ok = xg_exchange<MAXR>(xb, mine, got, xg_begin(xb));
     if (ok)
         for (int i = threadIdx.x; i < MAXR * xb.P; i += VB) out[i] = got[i % MAXR][i / MAXR];
     if (threadIdx.x == 0) *ok_out = ok ? 1 : 0;

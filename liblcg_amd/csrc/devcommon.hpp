@@ -179,12 +179,43 @@ enum { SC_FUSED = 0, SC_REDUCE = 1, SC_FIN = 2, SC_XGMI = 3 };
 // obtains the same bits -- which the lock-step loop (driver.hpp) relies on.  Two parities suffice:
 // a rank can finish call k+1 only after every peer has entered k+1, i.e. finished reading call k.
 // A contribution that does not arrive within timeout_ticks raises *fail; the call returns false.
-template <int NR>
-__device__ __forceinline__ bool xg_exchange(const XgBox &xb, const double *sums, double (*got)[XG_MAXP])
+// 16-byte packets {value, sequence number}: one global_store_dwordx4 / global_load_dwordx4 each, system scope, uncached memory.
+// A packet is written and read whole (an aligned 16-byte access is one transaction on gfx950 -- observed untorn, the connect-time
+// self-test of 32 known-answer all-reduces and tests/test_gpu_p2p.py check it on the node; not an architectural promise), so the
+// value needs no flag behind it: the sender fires its packets and goes on, the receiver polls the packets themselves.
+typedef unsigned int xg_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void xg_store_packet(double *slot, double v, unsigned long long k)
 {
+    const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
+    xg_v4u w; w.x = (unsigned)vb; w.y = (unsigned)(vb >> 32); w.z = (unsigned)k; w.w = (unsigned)(k >> 32);
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(slot), "v"(w) : "memory");
+}
+__device__ __forceinline__ void xg_load_packet(const double *slot, double *v, unsigned long long *k)
+{
+    xg_v4u w;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(slot) : "memory");
+    *v = __longlong_as_double((long long)((unsigned long long)w.x | ((unsigned long long)w.y << 32)));
+    *k = (unsigned long long)w.z | ((unsigned long long)w.w << 32);
+}
+
+// The sequence number of the exchange a one-block kernel is about to make and the failure flag, requested by thread 0 at the
+// kernel's START (beside the partial sums the kernel loads first) instead of in front of the exchange: one memory round trip less
+// on the chain of a scalar step.
+struct XgTicket { unsigned long long k = 0; int bad = 0; };
+__device__ __forceinline__ XgTicket xg_begin(const XgBox &xb)
+{
+    XgTicket t;
+    if (threadIdx.x == 0) { t.k = *xb.seq + 1; t.bad = *xb.fail; }
+    return t;
+}
+
+template <int NR>
+__device__ __forceinline__ bool xg_exchange(const XgBox &xb, const double *sums, double (*got)[XG_MAXP], XgTicket tk)
+{
+    static_assert(2 * NR <= XG_SLOT, "a slot holds one 16-byte packet per sum");
     __shared__ unsigned long long sq;
     __shared__ int bad;
-    if (threadIdx.x == 0) { sq = *xb.seq + 1; *xb.seq = sq; bad = *xb.fail; }
+    if (threadIdx.x == 0) { sq = tk.k; *xb.seq = tk.k; bad = tk.bad; }
     __syncthreads();
     if (bad) return false;      // an earlier exchange failed: the peers are gone, do not wait again
     const unsigned long long k = sq;
@@ -193,25 +224,24 @@ __device__ __forceinline__ bool xg_exchange(const XgBox &xb, const double *sums,
         const int q = threadIdx.x;
         double *dst = xb.peers[q] + (size_t)(par * xb.P + xb.me) * XG_SLOT;
 #pragma unroll
-        for (int r = 0; r < NR; r++) __hip_atomic_store(dst + r, sums[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        // The sums are write-through stores at system scope into uncached memory: once they are acknowledged (vmcnt) they are
-        // visible over there, and the sequence word may follow.  A release fence would do the same and ALSO write back every
-        // dirty line of this XCD's L2 -- which, when this runs in the last block of a product (finish_body), is the product's y.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + MAXR), k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        double *src = xb.mine + (size_t)(par * xb.P + q) * XG_SLOT;
+        for (int r = 0; r < NR; r++) xg_store_packet(dst + 2 * r, sums[r], k);
+        const double *src = xb.mine + (size_t)(par * xb.P + q) * XG_SLOT;
         const long long t0 = wall_clock64();
         bool ok = true;
-        // (relaxed polls; the sums below are system-scope loads of uncached memory issued behind the matching poll: no acquire,
-        //  whose cache invalidation per poll would cost 2-3x per hop)
-        while (__hip_atomic_load(reinterpret_cast<unsigned long long *>(src + MAXR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != k) {
+        double tmp[NR];
+        for (;;) {
+            bool all = true;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                unsigned long long kk;
+                xg_load_packet(src + 2 * r, &tmp[r], &kk);
+                all = all && kk == k;
+            }
+            if (all) break;
             __builtin_amdgcn_s_sleep(2);
             if (wall_clock64() - t0 > xb.timeout_ticks) { ok = false; break; }
         }
         if (!ok) { bad = 1; *xb.fail = 1; }
-        double tmp[NR];     // all loads in flight before the first use
-#pragma unroll
-        for (int r = 0; r < NR; r++) tmp[r] = __hip_atomic_load(src + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll
         for (int r = 0; r < NR; r++) got[r][q] = tmp[r];
     }
@@ -220,10 +250,10 @@ __device__ __forceinline__ bool xg_exchange(const XgBox &xb, const double *sums,
 }
 
 template <int NR>
-__device__ __forceinline__ bool xg_allreduce(const XgBox &xb, double *sums)
+__device__ __forceinline__ bool xg_allreduce(const XgBox &xb, double *sums, XgTicket tk)
 {
     __shared__ double got[NR][XG_MAXP];
-    if (!xg_exchange<NR>(xb, sums, got)) return false;
+    if (!xg_exchange<NR>(xb, sums, got, tk)) return false;
     if ((int)threadIdx.x < NR) {
         double v = 0.0;
         for (int q = 0; q < xb.P; q++) v += got[threadIdx.x][q];
@@ -391,7 +421,15 @@ template <class Fin>
 __global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, PartCount G, DevState *st, int mode, XgBox xb)
 {
     constexpr int NRA = Fin::NR > 0 ? Fin::NR : 1;
+    constexpr int SW = (int)(sizeof(DevState) / 8);
     __shared__ double sums[NRA];
+    __shared__ DevState L;
+    XgTicket tk;
+    if (mode == SC_XGMI && Fin::NR > 0) tk = xg_begin(xb);
+    // the state the step works on is requested NOW, beside the partial sums, and the step runs on the copy in LDS: its loads would
+    // otherwise be one more dependent round trip at the end of the chain (reduce -> exchange -> step)
+    double sv = 0.0;
+    if (mode != SC_REDUCE && (int)threadIdx.x < SW) sv = reinterpret_cast<const double *>(st)[threadIdx.x];
     if (mode != SC_FIN && Fin::NR > 0) {
         reduce_partials<NRA>(partials, G, sums);
         if (mode == SC_REDUCE && threadIdx.x < NRA) st->red[threadIdx.x] = sums[threadIdx.x];
@@ -400,13 +438,18 @@ __global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, Pa
         __syncthreads();
     }
     if (mode == SC_XGMI && Fin::NR > 0) {
-        if (!xg_allreduce<NRA>(xb, sums)) {
+        if (!xg_allreduce<NRA>(xb, sums, tk)) {
             // every rank sees the failure of this or a later exchange and stops the same way
             if (threadIdx.x == 0) { st->done = 1; st->status = ST_COMM; }
             return;
         }
     }
-    if (mode != SC_REDUCE && threadIdx.x == 0) fin(st, sums);
+    if (mode == SC_REDUCE) return;
+    if ((int)threadIdx.x < SW) reinterpret_cast<double *>(&L)[threadIdx.x] = sv;
+    __syncthreads();
+    if (threadIdx.x == 0) fin(&L, sums);
+    __syncthreads();
+    if ((int)threadIdx.x < SW) reinterpret_cast<double *>(st)[threadIdx.x] = reinterpret_cast<const double *>(&L)[threadIdx.x];
 }
 
 // ---- the body-closing step of plain CG's one-reduction schedule (solvers_real.hip), here because a sharded product's last
@@ -462,8 +505,10 @@ __device__ __forceinline__ void finish_body(const FinishPlan &fp, double *slot, 
     if (threadIdx.x == 0) __hip_atomic_store(fp.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the next launch starts from zero
     constexpr int NRA = 4;
     __shared__ double fsums[NRA];
+    XgTicket tk;
+    if (fp.xg) tk = xg_begin(fp.xb);
     reduce_partials<NRA>(fp.partials, fp.pc, fsums);
-    if (fp.xg && !xg_allreduce<NRA>(fp.xb, fsums)) {
+    if (fp.xg && !xg_allreduce<NRA>(fp.xb, fsums, tk)) {
         if (threadIdx.x == 0) { fp.st->done = 1; fp.st->status = ST_COMM; }
         return;
     }
