@@ -13,8 +13,8 @@ not depend on K guards the number: the residual a 25-iteration solve monitored m
 of its iterate (recomputed with a second A.x), and 100 iterations must come within 1e-3 of x_true.
 
 N = 1 also reports `variants`: the same CG on the three column patterns of the synthetic family
-(constant diagonals -- the headline --, row-random band, scrambled), so that the headline cannot be
-mistaken for the whole family.
+(constant diagonals -- the headline --, row-random band, scrambled) and on a matrix that mixes two of them by rows,
+so that the headline cannot be mistaken for the whole family.
 N > 1: the same 10M-row system is row-partitioned over the ranks (strong scaling).  The
 north-star exchange -- RCCL all-gather of x + RCCL all-reduce of the dots -- is measured FIRST and
 always reported (`value_rccl_allgather`); cheaper exchanges are then validated against its product
@@ -133,13 +133,38 @@ def main():
             dist.all_reduce(t)
         return [float(v) for v in t.tolist()]
 
+    def mixed_rows_matrix():
+        """80 % of the rows constant diagonals, the last 20 % scrambled columns (inside their own block: block-diagonal, SPD):
+        two generated matrices joined on the device.  One GPU only.  What `row ranges` (lcg_hip_csr_set_ranges) are for."""
+        import ctypes as C
+        n1 = (n * 4 // 5) // 64 * 64
+        parts = []
+        for rows, band, pat, seed in ((n1, args.band, PATTERNS["constant_diagonals"], 3), (n - n1, 0, PATTERNS["scrambled"], 5)):
+            G = api.CsrMatrix.generate(rows, args.npairs, band, True, seed, 0.01, pattern=pat)
+            pr, pc, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            assert lib.lcg_hip_csr_arrays(G.h, C.byref(pr), C.byref(pc), C.byref(pv)) == 0
+            nz = G.nnz
+            rp = torch.empty(rows + 1, dtype=torch.int32, device="cuda"); ci = torch.empty(nz, dtype=torch.int32, device="cuda")
+            vv = torch.empty(nz, dtype=torch.float64, device="cuda")
+            for dst, src in ((rp, pr), (ci, pc), (vv, pv)):
+                assert lib.lcg_hip_memcpy(dst.data_ptr(), src, dst.numel() * dst.element_size(), 3) == 0
+            G.destroy()
+            parts.append((rp, ci, vv))
+        (rp1, c1, v1), (rp2, c2, v2) = parts
+        rp = torch.cat([rp1, rp2[1:] + int(rp1[-1].item())]); ci = torch.cat([c1, c2 + n1]); vv = torch.cat([v1, v2])
+        del parts, rp1, c1, v1, rp2, c2, v2
+        return api.CsrMatrix.from_csr(rp, ci, vv, n_cols=n)
+
     class System:
         """One generated system resident in HBM: A (this rank's rows), x_true, b = A.x_true, workspaces."""
 
         def __init__(self, pattern):
-            band = args.band if PATTERNS[pattern] else 0
             self.pattern = pattern
-            self.A = api.CsrMatrix.generate(n, args.npairs, band, symmetric, 1, 0.01, r0, r1, pattern=PATTERNS[pattern])
+            if pattern == "mixed_rows":
+                self.A = mixed_rows_matrix()
+            else:
+                band = args.band if PATTERNS[pattern] else 0
+                self.A = api.CsrMatrix.generate(n, args.npairs, band, symmetric, 1, 0.01, r0, r1, pattern=PATTERNS[pattern])
             if args.solver == "pcg":
                 self.A.build_jacobi()
             self.xt = torch.empty(nloc, dtype=torch.float64, device="cuda")
@@ -326,9 +351,10 @@ def main():
 
 def variants(args, System, S, lib, api, n, spmv_bytes, iteration_bytes):
     """The same K-step CG on each column pattern of the family (three repetitions, median): it/s, A.x time and its
-    fraction of the 8 TB/s peak on ALGORITHMIC bytes, the kernel that ran, and the same solution check."""
+    fraction of the 8 TB/s peak on ALGORITHMIC bytes, the kernel that ran, and the same solution check.  `mixed_rows`: 80 % of the
+    rows constant diagonals, 20 % scrambled -- multiplied range by range (the kernel string names the ranges)."""
     res = {}
-    for pattern in ("constant_diagonals", "row_random_band", "scrambled"):
+    for pattern in ("constant_diagonals", "row_random_band", "scrambled", "mixed_rows"):
         if pattern == S.pattern:
             V, own = S, False
         else:
