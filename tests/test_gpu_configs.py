@@ -57,10 +57,11 @@ def test_config1_laplacian_pcg_jacobi_full_size(api, port):
             assert info.residual <= 1e-10 and np.linalg.norm(x - xt.cpu().numpy()) <= 1e-4 * np.linalg.norm(x)
 
 
-def test_config4_nonsymmetric_bicgstab_full_size(api):
+def test_config4_nonsymmetric_bicgstab_full_size(api, port):
     """BASELINE configs[4](i): the 10M-row generated system with unmirrored values, BiCGStab to abs_diff = 1,
     eps = 1e-10 -- size-independent properties (no CPU reference at this size): A really is non-symmetric, the solve
     returns convergence, recovers x_true, and the residual it monitored is the residual of its answer (second A.x)."""
+    from oracle import pyoracle as po
     n = 10_000_000
     A = api.CsrMatrix.generate(n, 16, 131072, False, 1, 0.01)
     assert 32.5 * n < A.nnz <= 33 * n
@@ -87,6 +88,20 @@ def test_config4_nonsymmetric_bicgstab_full_size(api):
     m.zero_()
     info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=1e-10, abs_diff=1), A, api.LCG_CGS)
     assert info.ret == 0 and ((m - xt).norm() / xt.norm()).item() <= 5.5e-5
+    # The ARITHMETIC at full size: four capped iterations of both loops against the oracle on the very same
+    # 3.3e8 entries.  The band is rounding, not a stop: the oracle adds its 1e7-term inner products left to right, the device in
+    # blocks -- a few 1e-13 per sum -- so the iterates agree to 1e-10 where a wrong coefficient would show at 1e-1.
+    rp, ci, v = A.arrays_to_host()
+    bh = b.cpu().numpy()
+    for sid in (api.LCG_BICGSTAB, api.LCG_CGS):
+        ref = port.solve(sid, rp, ci, v, bh, para=po.default_para(epsilon=1e-300, abs_diff=1, max_iterations=4))
+        m.zero_()
+        info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=1e-300, abs_diff=1, max_iterations=4), A, sid)
+        x = m.cpu().numpy()
+        rel = float(np.linalg.norm(x - ref["x"]) / np.linalg.norm(ref["x"]))
+        assert info.ret == ref["ret"] == -1019 and info.iterations == ref["iters"] == 4 and rel <= 1e-10, (sid, info.ret, ref["ret"], rel)
+        if ref["residual"] > 0.0:
+            assert abs(info.residual - ref["residual"]) <= 1e-9 * ref["residual"], (sid, info.residual, ref["residual"])
 
 
 @pytest.mark.parametrize("pattern,n,band,seed", NONSYM_SYSTEMS)
