@@ -843,6 +843,35 @@ int dist_spmv_op(lcg_hip_csr *A, const CsrPart &T, const double *x, double *y)
     return 0;
 }
 
+// The compact sums of the remote-column rows (out[j] = sum_k val[k] * xfull[col[k]] of remc row j) with the chain-of-short-rows kernel
+// above -- the all-gather / neighbour-range exchanges put this product BEHIND the exchange, on the critical path: the row-block
+// kernels the automatic choice would take for such a part (262K rows of ~6 entries on the 8-way shard of the headline system) need
+// 41 us for it, k_remote 10.
+static int remote_sums_launch(lcg_hip_csr *A, const double *xfull, double *out, hipStream_t s, const int *done)
+{
+    const int nr = A->remc.n_rows;
+    if (nr <= 0) return 0;
+    const double mean_r = (double)A->remc.nnz / nr;
+    int T = mean_r <= 8.0 ? 1 : (mean_r <= 24.0 ? 2 : 4);
+    if (const char *e = std::getenv("LCG_HIP_REMOTE_T")) T = atoi(e);
+    if (T != 1 && T != 2 && T != 4) return fail(hipErrorInvalidValue, "bad lanes-per-row for the remote-column product", __FILE__, __LINE__);
+    const unsigned g = (unsigned)(((long)nr * T + VB - 1) / VB);
+#define RS_LAUNCH(TT)                                                                                                \
+    do {                                                                                                             \
+        if (A->is_complex)                                                                                           \
+            hipLaunchKernelGGL((k_remote<double2, TT, false>), dim3(g), dim3(VB), 0, s, nr, A->remc.rowptr, A->remc.col, \
+                               reinterpret_cast<const double2 *>(A->remc.val), A->rem_rows,                          \
+                               reinterpret_cast<const double2 *>(xfull), reinterpret_cast<double2 *>(out), done);    \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_remote<double, TT, false>), dim3(g), dim3(VB), 0, s, nr, A->remc.rowptr, A->remc.col, \
+                               A->remc.val, A->rem_rows, xfull, out, done);                                          \
+    } while (0)
+    switch (T) { case 1: RS_LAUNCH(1); break; case 2: RS_LAUNCH(2); break; default: RS_LAUNCH(4); }
+#undef RS_LAUNCH
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // u != nullptr: the product also leaves y.u as partial sums in part[0 .. *slots) -- the local product's (folded to <= 512), then one per
 // block of the remote-column finisher.  *fused says whether it did (when not, the plain product was made).
 // fp (with fp->fin set): the kernel that completes the sum also closes the iteration body with its last block (finish_body); when the
@@ -884,6 +913,18 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
         static const bool withhold = std::getenv("LCG_HIP_TEST_WITHHOLD_PUSH") != nullptr;
         static const bool one_stream_ = [] { const char *e = std::getenv("LCG_HIP_DIRECT_STREAMS"); return !(e && atoi(e) == 2); }();
         static const bool land_ = [] { const char *e = std::getenv("LCG_HIP_DIRECT_LAND"); return e && atoi(e) == 1; }();
+        // The receiving blocks ride in the tail of the product's grid (devcommon.hpp: recv_block) instead of being a kernel of their
+        // own behind it: one launch and one kernel boundary less per product, and the copies run beside the product's last blocks.
+        // They are the LAST blocks to be dispatched and few (one per 4096 doubles received), so they cannot keep the pushing
+        // blocks of a rank that shares this GPU from running.  LCG_HIP_RECV_KERNEL=1: k_recv as its own kernel again (A/B runs).
+        static const bool recv_kernel_ = [] { const char *e = std::getenv("LCG_HIP_RECV_KERNEL"); return e && atoi(e) == 1; }();
+        const bool recv_in_tail = !recv_kernel_ && !withhold && one_stream_ && !land_ && wp.n > 0;
+        if (recv_in_tail) {
+            pp.nrecv = cp.nblocks; pp.rnseg = cp.nseg; pp.wp = wp; pp.rst = c.in_solve ? c.state : nullptr;
+            for (int q = 0; q < cp.nseg; q++) { pp.rsrc[q] = cp.src[q]; pp.rdst[q] = cp.dst[q]; pp.rcount[q] = cp.count[q]; }
+            for (int q = 0; q <= cp.nseg && q <= XG_MAXSEG; q++) pp.rfirst[q] = cp.first_block[q];
+            if (pp.nrecv <= 0) pp.nrecv = 1;        // flag-only neighbours: one block awaits the flags
+        }
         // the remote part's share of the dot rides in the single-stream k_remote; its blocks must fit behind the local sums
         const long rem_blocks = A->remc.n_rows > 0 ? ((long)A->remc.n_rows * 4 + VB - 1) / VB : 0;
         dot = dot && !withhold && one_stream_ && !land_ && 512 + rem_blocks <= AXP_CAP;
@@ -923,7 +964,7 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
             std::fprintf(stderr, "[lcg_hip] direct: land=%d (env %d, sparse %d, recv %lld, n_global %lld, rows %d) one_stream=%d\n", (int)land,
                          land_env, (int)sparse_halo, D->recv_total, (long long)A->n_global, A->n_rows, (int)one_stream);
         const double *landing = D->recv + (size_t)(D->calls & 1) * D->half;
-        if (wp.n > 0 && !land) {    // flags are awaited even after a stop: the neighbours' calls stay paired with mine
+        if (wp.n > 0 && !land && !recv_in_tail) {    // flags are awaited even after a stop: the neighbours' calls stay paired with mine
             hipLaunchKernelGGL(k_recv, dim3((unsigned)cp.nblocks), dim3(VB), 0, rs, wp, cp, c.in_solve ? c.state : nullptr);
             HIPCHK(hipGetLastError());
         }
@@ -1013,8 +1054,10 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
     // ... followed there by the product of the remote columns (few rows: their sums go to rem_y) ...
     int rc = 0;
     if (A->remc.n_rows > 0) {
+        static const bool rowblocks = [] { const char *e = std::getenv("LCG_HIP_REMOTE_ROWBLOCKS"); return e && atoi(e) == 1; }();     // A/B runs
         const double mean_r = (double)A->remc.nnz / A->remc.n_rows;
-        rc = spmv_launch(A->remc, A->is_complex, 0, mean_r, A->xfull, A->rem_y, false, c.comm_stream, done);
+        rc = rowblocks ? spmv_launch(A->remc, A->is_complex, 0, mean_r, A->xfull, A->rem_y, false, c.comm_stream, done)
+                       : remote_sums_launch(A, A->xfull, A->rem_y, c.comm_stream, done);
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(c.ev_b, c.comm_stream));

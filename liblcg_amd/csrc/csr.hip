@@ -43,6 +43,7 @@ __global__ __launch_bounds__(VB) void k_spmv_wave(int n, const int *__restrict__
                                                   const int *done, PushPlan pp)
 {
     if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
+    if (PUSH && pp.nrecv > 0 && (int)blockIdx.x >= (int)gridDim.x - pp.nrecv) { recv_block(pp, (int)blockIdx.x - ((int)gridDim.x - pp.nrecv)); return; }
     const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
     if (done && *done) return;
     const int sub = threadIdx.x % T;
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(VB) void k_spmv_lds1(int n, long nnz, const int *__
                                                   const int *done, PushPlan pp)
 {
     if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
+    if (PUSH && pp.nrecv > 0 && (int)blockIdx.x >= (int)gridDim.x - pp.nrecv) { recv_block(pp, (int)blockIdx.x - ((int)gridDim.x - pp.nrecv)); return; }
     const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
     constexpr int CH = LdsCfg<V>::CH;
     __shared__ __attribute__((aligned(16))) V sval[CH];
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsw(int n, long nnz, const int *__
                                                   const int *done, PushPlan pp)
 {
     if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
+    if (PUSH && pp.nrecv > 0 && (int)blockIdx.x >= (int)gridDim.x - pp.nrecv) { recv_block(pp, (int)blockIdx.x - ((int)gridDim.x - pp.nrecv)); return; }
     const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
     constexpr int T = VB / R;
     constexpr int CH = LdsCfg<V>::CH;
@@ -414,6 +417,7 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
                                                   double *__restrict__ y, const int *done, PushPlan pp, DotPlan dp)
 {
     if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
+    if (PUSH && pp.nrecv > 0 && (int)blockIdx.x >= (int)gridDim.x - pp.nrecv) { recv_block(pp, (int)blockIdx.x - ((int)gridDim.x - pp.nrecv)); return; }
     const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
     constexpr int R = PK_R;
     constexpr int T = VB / R;
@@ -1133,7 +1137,7 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
                          const int *done, const PushPlan &pp = PushPlan())
 {
     const int n = P.n_rows;
-    const unsigned xb = PUSH ? (unsigned)pp.nblocks : 0u;       // pushing blocks in front of the grid
+    const unsigned xb = PUSH ? (unsigned)(pp.nblocks + pp.nrecv) : 0u;       // pushing blocks in front of the grid, receiving blocks behind it
     if constexpr (sizeof(V) == 8 && !ACC && !PUSH) {
         if (n > 0 && (variant == 0 || variant == -1) && ranges_chosen(P, s)) {
             RangePlan *R = static_cast<RangePlan *>(P.rg_plan);
@@ -1311,7 +1315,7 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
     const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);
     const int ns = per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
     const PushPlan ppv = pp ? *pp : PushPlan();
-    const unsigned xb = pp ? (unsigned)pp->nblocks : 0u;
+    const unsigned xb = pp ? (unsigned)(pp->nblocks + pp->nrecv) : 0u;
 #define PKD_LAUNCH(PU, NSS, BB)                                                                                     \
         hipLaunchKernelGGL((k_spmv_ldsp<PU, NSS, BB, true>), dim3(nblk + xb), dim3(VB), 0, s, n, P.rowptr,          \
                            static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, P.val, x, y, done, ppv, dp)

@@ -87,6 +87,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_tile_spmv2(int n, int nwg, co
 {
     constexpr int TC = TL_TC;
     if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
+    if (PUSH && pp.nrecv > 0 && (int)blockIdx.x >= (int)gridDim.x - pp.nrecv) { recv_block(pp, (int)blockIdx.x - ((int)gridDim.x - pp.nrecv)); return; }
     const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
     __shared__ __attribute__((aligned(16))) double sx[2][TC];
     __shared__ __attribute__((aligned(16))) double ys[NW][TL_RW];
@@ -453,7 +454,7 @@ int tiled_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, co
 {
     const TiledPlan *T = static_cast<const TiledPlan *>(P.tl_plan);
     if (!T) return fail(hipErrorInvalidValue, "tiled A.x without a plan", __FILE__, __LINE__);
-    const unsigned grid = 8u * (unsigned)((T->nwg + 7) / 8) + (push ? (unsigned)push->nblocks : 0u);
+    const unsigned grid = 8u * (unsigned)((T->nwg + 7) / 8) + (push ? (unsigned)(push->nblocks + push->nrecv) : 0u);
     const PushPlan pp = push ? *push : PushPlan();
     // ring depth and cache policy of the stream (A/B runs).  Measured on the 10M-row row-random band, same box: depth 2 / 3 / 4 / 6 / 8
     // = 690 / 649 / 657 / 682 / 699 us (eight consumers keep 8 x D x 2 KB in flight through a 32 KB L1: deeper rings evict their

@@ -333,6 +333,36 @@ __device__ __forceinline__ bool wait_flags(const WaitPlan &wp)
     return wbad == 0;
 }
 
+// A receiving block in the tail of a product's grid (PushPlan::nrecv): k_recv's work (comm.hip) without its launch.  Relaxed
+// polls and system-scope loads of the uncached landing zone, like the landing-direct product: an acquire here would invalidate
+// the XCD's L2 under the product blocks still running beside it.
+__device__ __forceinline__ void recv_block(const PushPlan &pp, int b)
+{
+    if (!wait_flags<false>(pp.wp)) {
+        if (pp.rst && b == 0 && threadIdx.x == 0) { pp.rst->done = 1; pp.rst->status = ST_COMM; }
+        return;
+    }
+    if (pp.rnseg == 0 || threadIdx.x >= VB) return;     // (workgroups wider than VB threads -- k_tile_spmv2 -- copy with their first VB)
+    int s = 0;
+    while (s + 1 < pp.rnseg && b >= pp.rfirst[s + 1]) s++;
+    const long off = (long)(b - pp.rfirst[s]) * PUSH_CHUNK;
+    const long cnt = min((long)PUSH_CHUNK, pp.rcount[s] - off);
+    const double *src = pp.rsrc[s] + off;
+    double *dst = pp.rdst[s] + off;
+    constexpr int PER = PUSH_CHUNK / VB;
+    double v[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const long i = threadIdx.x + (long)q * VB;
+        v[q] = __hip_atomic_load(const_cast<double *>(src) + (i < cnt ? i : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const long i = threadIdx.x + (long)q * VB;
+        if (i < cnt) dst[i] = v[q];
+    }
+}
+
 __device__ __forceinline__ void publish(DevState *st)
 {
     HostStatus *h = st->host;

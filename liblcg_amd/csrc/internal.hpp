@@ -36,6 +36,14 @@ struct XgBox {
 // neighbour's remote-column product waits for the flags of the call it belongs to.
 constexpr int XG_MAXSEG = 8;        // most neighbours of a rank under this mode
 constexpr int PUSH_CHUNK = 4096;    // doubles one pushing block moves
+struct DevState;
+struct WaitPlan {
+    int n = 0;
+    unsigned long long seq = 0;
+    long long timeout_ticks = 0;
+    int *fail = nullptr;
+    const unsigned long long *flag[XG_MAXSEG];  // the neighbours' flag words in MY flag array
+};
 struct PushPlan {
     int nseg = 0, nflag = 0, nblocks = 0;
     unsigned long long seq = 0;         // number of this A.x call (same on every rank)
@@ -45,14 +53,18 @@ struct PushPlan {
     long count[XG_MAXSEG];              // doubles
     int first_block[XG_MAXSEG + 1];
     unsigned long long *flag[XG_MAXSEG];        // my flag word in each neighbour's flag array
+    // RECEIVING blocks behind the product's blocks (one-stream direct exchange): block j of them waits for the neighbours' flags of
+    // this call and copies chunk j of what they wrote from the landing zone into the gather buffer -- k_recv's work without its
+    // launch, overlapped with the product's tail (devcommon.hpp: recv_block)
+    int nrecv = 0, rnseg = 0;
+    const double *rsrc[XG_MAXSEG];
+    double *rdst[XG_MAXSEG];
+    long rcount[XG_MAXSEG];
+    int rfirst[XG_MAXSEG + 1];
+    WaitPlan wp;
+    DevState *rst = nullptr;            // where a time-out is recorded (may be null)
 };
-struct WaitPlan {
-    int n = 0;
-    unsigned long long seq = 0;
-    long long timeout_ticks = 0;
-    int *fail = nullptr;
-    const unsigned long long *flag[XG_MAXSEG];  // the neighbours' flag words in MY flag array
-};
+
 
 // Partial sums per running sum: slots 0 .. g[r]-1 of table row r hold the r-th sum's partials (one per block of the reducing
 // pass).  One running sum (two with yy) may instead come from the epilogue of an A.x kernel that leaves one partial per
