@@ -914,6 +914,12 @@ __global__ __launch_bounds__(VB) void k_diag_like(int n, const int *__restrict__
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(sum, (unsigned long long)cnt);
 }
 
+static double tiled_fill_threshold()
+{
+    static const double fill = [] { const char *e = std::getenv("LCG_HIP_TILED_FILL"); return e ? atof(e) : 700.0; }();
+    return fill;
+}
+
 static bool tiled_chosen(const CsrPart &P, hipStream_t s)
 {
     if (P.tl_state != 0) return P.tl_state > 0;
@@ -938,8 +944,7 @@ static bool tiled_chosen(const CsrPart &P, hipStream_t s)
         if (P.diag_like > 0.5) { P.tl_state = -1; P.tl_why = "automatic mode: the columns run along diagonals (the row-block kernels gather contiguously)"; return false; }
         // least mean number of entries per (workgroup of 8192 rows, tile of 2048 columns) pair.  Measured at N = 1e7, 33 per row (round 3):
         // W = 524288, 1052 per pair: tiled 1.01-1.17 ms, binned 1.70; W = 1048576, 527 per pair: tiled 1.96 ms, binned 1.72
-        static const double fill = [] { const char *e = std::getenv("LCG_HIP_TILED_FILL"); return e ? atof(e) : 700.0; }();
-        min_fill = fill;
+        min_fill = tiled_fill_threshold();
     }
     const int rc = tiled_ready(P, s, min_fill);
     if (rc <= 0) { P.tl_state = -1; return false; }
@@ -1045,9 +1050,16 @@ static bool ranges_chosen(const CsrPart &P, hipStream_t s)
         if (!ok) { (void)hipGetLastError(); return false; }
     }
     // class of a stretch from its sums: 0 structured (diagonals / stencils), 1 columns drawn per row inside a band, 2 scattered; -1 empty
+    // (a stretch whose columns are drawn per row but too widely for the tiled product -- its workgroups of 8192 rows would find
+    //  fewer entries per 2048-column tile than the tiled plan asks for -- is multiplied like scattered columns: the row-block
+    //  kernels, its only other choice, pay a cache line per gather there)
     auto classify = [](double span_sum, double dl, double ent, double blocks) {
         if (ent <= 0.0 || blocks <= 0.0) return -1;
-        return dl / ent > 0.5 ? 0 : (span_sum / blocks >= span_threshold() ? 2 : 1);
+        if (dl / ent > 0.5) return 0;
+        const double span = span_sum / blocks;
+        if (span >= span_threshold()) return 2;
+        const double fill = 128.0 * (ent / blocks) / ((span + 8192.0) / 2048.0);
+        return fill < tiled_fill_threshold() && span >= (double)(1 << 19) ? 2 : 1;
     };
     auto block_class = [&](int b) { return classify((double)hb[3 * (size_t)b], (double)hb[3 * (size_t)b + 1], (double)hb[3 * (size_t)b + 2], 1.0); };
     std::vector<int> cls(nc);
@@ -1113,6 +1125,9 @@ static bool ranges_chosen(const CsrPart &P, hipStream_t s)
         V.owned = false; V.padded = r1 < n ? true : P.padded;       // (behind an inner range lies the next range)
         V.end_abs = cut[i + 1]; V.n_cols = P.n_cols;
         V.pk_mode = P.pk_mode; V.bn_mode = P.bn_mode; V.tl_mode = P.tl_mode; V.rg_mode = 0; V.rg_state = -1;
+        // a stretch classed as scattered takes the binned product where it is eligible at all (its own mean span may sit just
+        // under the whole-matrix threshold: the class was decided chunk by chunk)
+        if (runs[i].k == 2 && P.bn_mode < 0 && V.nnz >= (1 << 22)) V.bn_mode = 1;
         R->parts.push_back(V); R->r0.push_back(r0); R->seen.push_back(nullptr);
     }
     if (R->parts.size() < 2) { delete R; return false; }
