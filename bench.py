@@ -78,6 +78,7 @@ def main():
                     help="lcg_hip_set_cg_schedule: auto = classic on one GPU, one all-reduce per iteration when sharded")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not collect roofline.traffic with rocprofv3 child runs (N = 1); use the committed figure")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -291,6 +292,15 @@ def main():
         achieved = shard_bytes / (ax_us * 1e-6) / 1e9
         kernel = lib.lcg_hip_csr_last_kernel(S.A.h).decode()
         traffic, source = pmc_traffic(args.pattern, kernel, S.nnz_local) if world == 1 and not sharded else (None, "not collected for sharded runs")
+        if world == 1 and not sharded and not args.no_live_pmc:
+            # the same counters collected NOW, on this box, by two rocprofv3 child runs of the product alone (counters cannot be read
+            # from inside this process): the committed figure above is the fallback when the profiler is not available
+            live, why = live_pmc_traffic(args, kernel)
+            if live:
+                out["traffic_committed"] = {"traffic": traffic, "traffic_source": source}
+                traffic, source = live, why
+            else:
+                source = f"{source}; live collection skipped: {why}"
         out["roofline"] = {"bound": "hbm", "kernel": kernel if world == 1 else "A.x (local product + x exchange + remote columns): " + kernel,
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": source, "bytes_per_launch": shard_bytes, "avg_launch_us": ax_us,
@@ -400,6 +410,53 @@ def physical_fractions(lib, A, ax_us, traffic, sharded):
         out["plan_build_ms"] = ms.value
         out["plan_extra_bytes"] = extra.value
     return out
+
+
+def live_pmc_traffic(args, kernel_description):
+    """HBM bytes per A.x launch on THIS box: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, the program directly
+    behind `--`, no trace domain beside the counters) around scripts/ax_variants.py on the same generated matrix; FETCH_SIZE x 2 +
+    WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950 (KB per dispatch; wide coalesced reads are tallied at half their size).
+    Returns (bytes, source) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "no rocprofv3"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself being profiled"
+    family = kernel_description.split(" ")[0]       # k_spmv_ldsp, k_tile_spmv, k_bin_expand, ...
+    fams = {"k_tile_spmv": ("k_tile_spmv",), "k_bin_expand": ("k_bin_expand", "k_bin_reduce")}.get(family, (family,))
+    if not family.startswith("k_"):
+        return None, f"kernel family not recognised in '{kernel_description[:40]}'"
+    tmp = tempfile.mkdtemp(prefix="lcg_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "-o", "pmc", "--",
+                   sys.executable, os.path.join(ROOT, "scripts", "ax_variants.py"), "--rows", str(args.rows), "--band", str(args.band),
+                   "--patterns", str(PATTERNS[args.pattern]), "--modes", "auto", "--reps", "3", "--dot", "1"]
+            p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=180)
+            if p.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} ended with {p.returncode}"
+            got = {}
+            for f in glob.glob(os.path.join(tmp, counter, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in fams):
+                        got.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            if not got:
+                return None, f"no {counter} rows for {fams}"
+            # one launch of the product = one launch of each kernel of the family that ran in the steady state (the kernels seen most often)
+            most = max(len(v) for v in got.values())
+            vals[counter] = sum(sum(v) / len(v) for v in got.values() if len(v) >= most - 1) * 1024.0
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as exc:
+        return None, f"{type(exc).__name__}: {exc}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], ("live on this box: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate child runs of "
+                                                            "scripts/ax_variants.py on the same matrix), FETCH_SIZE x 2 + WRITE_SIZE")
 
 
 def pmc_traffic(pattern, kernel, nnz=None):

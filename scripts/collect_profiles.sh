@@ -17,7 +17,7 @@ tail -c 600 "$OUT/bench.json"; echo
 cd /tmp && export TMPDIR=/tmp
 # 2. kernel trace of the same command (the variants ride in it: one stats file covers all three patterns)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bench" -o prof -- \
-    python3 "$REPO/bench.py" --no-cpu-baseline > "$OUT/trace_bench.json" 2> "$OUT/trace_bench.err"
+    python3 "$REPO/bench.py" --no-cpu-baseline --no-live-pmc > "$OUT/trace_bench.json" 2> "$OUT/trace_bench.err"
 echo "bench kernel trace done"
 # 3. kernel traces of the other single-GPU configurations: configs[1] (Laplacian PCG), configs[4](i) (10M non-symmetric
 #    BiCGStab / CGS), configs[0] and the complex system (latency-bound)
@@ -35,7 +35,7 @@ done
 # 5. counters on the headline CG iteration (BLAS-1 kernels: the calibration of FETCH_SIZE on known byte counts)
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmcbench_$c" -o pmc -- \
-        python3 "$REPO/bench.py" --no-cpu-baseline --no-variants --steps 20 --warmup 2 --reps 1 > /dev/null 2> "$OUT/pmcbench_$c.err"
+        python3 "$REPO/bench.py" --no-cpu-baseline --no-live-pmc --no-variants --steps 20 --warmup 2 --reps 1 > /dev/null 2> "$OUT/pmcbench_$c.err"
     echo "pmc(bench) $c done"
 done
 cd "$REPO"

@@ -53,7 +53,7 @@ def test_need_ranges_match_oracle_rows(port):
 
 def _run_bench(extra_env, *args):
     env = dict(os.environ, **extra_env)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--rows", "400000",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-live-pmc", "--rows", "400000",
                         "--band", "5000", "--steps", "30", "--warmup", "3", *args],
                        capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
@@ -85,7 +85,7 @@ def test_sharded_products_use_the_tiled_kernel_too():
     """A row-random band shard under the all-gather exchange: the local-column part (all of it with one rank) is large
     enough for the automatic choice to take the tiled product; the bench's guard (residual recomputed with a second A.x,
     100 iterations towards x_true) passes on it."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-variants", "--rows", "1500000", "--band", "40000",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-live-pmc", "--no-variants", "--rows", "1500000", "--band", "40000",
                         "--pattern", "row_random_band", "--steps", "20", "--warmup", "3", "--reps", "2"], capture_output=True, text=True,
                        env=dict(os.environ, LCG_HIP_FORCE_COMM="1", LCG_HIP_DIST_MODE="0", MASTER_PORT="29543"), timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
@@ -160,3 +160,15 @@ def test_a_failing_product_ends_the_solve_with_its_code():
     m.zero_()
     assert lib.lcg_hip_solver(ax, None, m.data_ptr(), b.data_ptr(), n, C.byref(p), A.h, api.LCG_CG, 1) == 0
     assert ((m - xt).norm() / xt.norm()).item() < 1e-8
+
+
+def test_bench_collects_its_traffic_counters_live():
+    """bench.py at N = 1 collects roofline.traffic on the box it times on: two rocprofv3 --pmc child runs of the product alone.
+    The figure must sit between what the kernel must move by construction and twice that (x re-fetched per XCD, metadata)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-variants", "--rows", "2000000",
+                        "--steps", "10", "--warmup", "2", "--reps", "2"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    rf = json.loads(p.stdout.strip().splitlines()[-1])["roofline"]
+    assert rf["traffic_source"].startswith("live on this box"), rf["traffic_source"]
+    assert rf["must_move_bytes"] <= rf["traffic"] <= 2.0 * rf["must_move_bytes"], (rf["traffic"], rf["must_move_bytes"])
+    assert 0.0 < rf["frac_traffic"] < 1.0
