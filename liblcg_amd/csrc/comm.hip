@@ -942,7 +942,8 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
             rc = withhold ? spmv_launch(A->loc, A->is_complex, A->variant, mean_l, x, y, false, c.stream, done)
                           : spmv_launch_push(A->loc, A->is_complex, A->variant, mean_l, x, y, c.stream, done, pp);
         if (rc) return rc;
-        // One stream by default: product (+ pushing blocks) | k_recv | k_remote, no event at all.
+        // One stream by default: product (pushing blocks in front, receiving blocks behind) | k_remote, no event at all
+        // (the receiving blocks as a kernel of their own -- k_recv -- under LCG_HIP_RECV_KERNEL=1, the two-stream form and the withhold hook).
         // LCG_HIP_DIRECT_STREAMS=2 puts the receiving kernels on the second stream -- enqueued AFTER the
         // pushing product (so that, even if both streams shared a hardware queue, my push is never behind
         // my wait) and without a fork event (they depend on the neighbours' flags, not on this stream);
