@@ -72,6 +72,7 @@ SIGNATURES = {
     "lcg_hip_csr_set_kernel": (C.c_int, [vp, C.c_int]),
     "lcg_hip_csr_set_packed": (C.c_int, [vp, C.c_int]),
     "lcg_hip_csr_packed_runs": (C.c_int64, [vp, C.POINTER(C.c_int64)]),
+    "lcg_hip_csr_packed_templates": (C.c_int64, [vp]),
     "lcg_hip_csr_set_binned": (C.c_int, [vp, C.c_int]),
     "lcg_hip_csr_set_tiled": (C.c_int, [vp, C.c_int]),
     "lcg_hip_csr_set_ranges": (C.c_int, [vp, C.c_int]),

@@ -308,8 +308,89 @@ constexpr int PK_SPAN = 1 << 21;
 // one more than the entry in the same slot of the row above -- the shape of constant diagonals and stencils away from the
 // matrix edges.  Such a block needs no columns of its own beyond row 0's: column(row r, slot k) = column(row 0, slot k) + r.
 // It stores row 0's L columns as plain int32 (four per 16-byte group) and is marked by base[b] = -1 - L.
+// A TEMPLATE block (round 3): what a stencil's blocks look like where the grid's boundaries pass through them.  The rows do not
+// all hold the same entries any more, but every entry of the block lies on one of D <= 32 diagonals (column - row in block), the
+// ones of the block's longest row, and every row holds its entries in ascending column order.  Such a block stores the D offsets and one
+// 32-bit mask per row (which diagonals the row has) -- 23 groups of 16 bytes for a 27-point stencil instead of ~250 -- and is marked
+// by base[b] = -(1 << 30) - D.  Run blocks are the special case "all masks full"; they keep their own, cheaper, form.
+constexpr int TPL_MAXD = 32;
+constexpr int TPL_CODE = 1 << 30;       // base[b] = -TPL_CODE - D; ngroups[b] (before k_pk_groups) = -TPL_GRP - D
+constexpr int TPL_GRP = 1 << 20;
+
+// One wavefront, lane = row of the block: builds tpl[0 .. D) = the ascending offsets (column - row in block) the block's entries
+// lie on -- seeded with the longest row's, then completed by the rows that have others (a block that holds the last line of one
+// grid plane and the first line of the next has rows that miss DIFFERENT neighbours) -- and returns the lane's mask over them;
+// *bad when there are more than TPL_MAXD of them or a row's columns do not ascend.  tpl: TPL_MAXD + 1 ints of LDS, dcount: one.
+__device__ __forceinline__ unsigned tpl_row_mask(long row0, int r1, const int *__restrict__ rowptr, const int *__restrict__ col, int *tpl,
+                                                 int *dcount, int *D_out, bool *bad)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = row0 + lane;
+    int s = 0, len = 0;
+    if (row < r1) { s = rowptr[row]; len = rowptr[row + 1] - s; }
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    // the longest row (first of them) seeds the template
+    int best = len, who = lane;
+    for (int off = 32; off > 0; off >>= 1) {
+        const int ob = __shfl_down(best, off, 64), ow = __shfl_down(who, off, 64);
+        if (ob > best || (ob == best && ow < who)) { best = ob; who = ow; }
+    }
+    best = __shfl(best, 0, 64); who = __shfl(who, 0, 64);
+    *D_out = best;
+    *bad = true;
+    if (best < 1 || best > TPL_MAXD) return 0u;
+    bool mine_bad = false;
+    {   // columns must ascend strictly: entry e of a row is then the e-th set bit of its mask
+        int prev = -0x7fffffff - 1;
+        for (int k = 0; k < len; k++) { const int c = col[s + k]; if (c <= prev) mine_bad = true; prev = c; }
+    }
+    if (__ballot(mine_bad)) return 0u;
+    if (lane == who) { for (int k = 0; k < len; k++) tpl[k] = col[s + k] - lane; *dcount = len; }
+    wave_sync();
+    auto find = [&](int o, int D) {     // index of o in tpl[0 .. D), or -1
+        int lo = 0, hi = D - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (tpl[mid] < o) lo = mid + 1; else hi = mid; }
+        return tpl[lo] == o ? lo : -1;
+    };
+    for (int round = 0; round < 64; round++) {      // every round takes in one more row's offsets: at most 64
+        const int D = *dcount;
+        bool missing = false;
+        for (int k = 0; k < len && !missing; k++) missing = find(col[s + k] - lane, D) < 0;
+        const unsigned long long m = __ballot(missing);
+        if (!m) break;
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) {
+            int Dn = D;
+            for (int k = 0; k < len; k++) {
+                const int o = col[s + k] - lane;
+                if (find(o, Dn) >= 0) continue;
+                if (Dn >= TPL_MAXD) { Dn = TPL_MAXD + 1; break; }
+                int p = Dn;
+                while (p > 0 && tpl[p - 1] > o) { tpl[p] = tpl[p - 1]; p--; }
+                tpl[p] = o; Dn++;
+            }
+            *dcount = Dn;
+        }
+        wave_sync();
+        if (*dcount > TPL_MAXD) return 0u;
+    }
+    const int D = *dcount;
+    *D_out = D;
+    unsigned mask = 0u;
+    bool b = false;
+    for (int k = 0; k < len; k++) { const int p = find(col[s + k] - lane, D); if (p >= 0) mask |= 1u << p; else b = true; }
+    *bad = __ballot(b) != 0ull;
+    return mask;
+}
+
 __global__ __launch_bounds__(64) void k_pk_meta(int n, const int *rowptr, const int *col, int *base, int *ngroups, int *maxspan, int runs)
-{   // ngroups[b] = entries of block b for now, -L for a run block (k_pk_groups turns them into groups); maxspan[0] = widest block, [1] = longest row
+{   // ngroups[b] = entries of block b for now, -L for a run block, -TPL_GRP - D for a template block (k_pk_groups turns them into groups);
+    // maxspan[0] = widest block, [1] = longest row, [2] = run blocks, [3] = template blocks
+    __shared__ int tpl[TPL_MAXD + 1], dcount;
     const int b = blockIdx.x;
     const long row0 = (long)b * PK_R;
     const int r1 = (int)min((long)n, row0 + PK_R);
@@ -329,18 +410,31 @@ __global__ __launch_bounds__(64) void k_pk_meta(int n, const int *rowptr, const 
         for (int k = s + L + threadIdx.x; k < e; k += 64) bad |= col[k] != col[k - L] + 1;
         run = __ballot(bad) == 0;
     }
+    int D = 0;
+    bool tplb = false;
+    if (!run && runs == 1 && e > s) {       // uniform (runs == 2: run blocks only -- the short-row kernel walks the others from the CSR arrays)
+        bool bad;
+        (void)tpl_row_mask(row0, r1, rowptr, col, tpl, &dcount, &D, &bad);
+        tplb = !bad;        // (uniform)
+    }
     if (threadIdx.x == 0) {
         if (e == s) { lo = 0; hi = 0; }
-        base[b] = run ? -1 - L : lo; ngroups[b] = run ? -L : e - s;
-        atomicMax(maxspan, hi - lo); atomicMax(maxspan + 1, len);
+        base[b] = run ? -1 - L : (tplb ? -TPL_CODE - D : lo);
+        ngroups[b] = run ? -L : (tplb ? -TPL_GRP - D : e - s);
+        if (!tplb) atomicMax(maxspan, hi - lo);     // (a template block's columns are not stored relative to anything)
+        atomicMax(maxspan + 1, L);
         if (run) atomicAdd(maxspan + 2, 1);
+        if (tplb) atomicAdd(maxspan + 3, 1);
     }
 }
 
 __global__ void k_pk_groups(int nb, int per, int *ngroups)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nb) { const int g = ngroups[b]; ngroups[b] = g < 0 ? (-g + 3) / 4 : (per > 0 ? (g + per - 1) / per : 0); }
+    if (b < nb) {
+        const int g = ngroups[b];
+        ngroups[b] = g <= -TPL_GRP ? (-g - TPL_GRP + 3) / 4 + PK_R / 4 : (g < 0 ? (-g + 3) / 4 : (per > 0 ? (g + per - 1) / per : 0));
+    }
 }
 
 // Field j of a 128-bit group (lo, hi): BITS = 21 -> six fields, three per 64-bit half; BITS = 18 -> seven
@@ -367,6 +461,18 @@ __global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const 
     const int s = rowptr[row0], e = rowptr[r1];
     const int bs = base[b];
     if (BITS == 0 && bs >= 0) return;       // runs only: the other blocks keep nothing
+    if (bs <= -TPL_CODE) {   // template block: the D offsets (padded to whole groups), then the 64 row masks
+        __shared__ int tpl[TPL_MAXD + 1], dcount;
+        if (threadIdx.x < 64) {
+            int D; bool bad;
+            const unsigned m = tpl_row_mask(row0, r1, rowptr, col, tpl, &dcount, &D, &bad);
+            int *dst = reinterpret_cast<int *>(packed + pofs[b]);
+            const int Dp = (D + 3) & ~3;
+            if ((int)threadIdx.x < Dp) dst[threadIdx.x] = (int)threadIdx.x < D ? tpl[threadIdx.x] : 0;
+            reinterpret_cast<unsigned *>(dst + Dp)[threadIdx.x] = m;
+        }
+        return;
+    }
     if (bs < 0) {       // run block: row 0's columns as they are
         const int L = -1 - bs;
         int *dst = reinterpret_cast<int *>(packed + pofs[b]);
@@ -443,6 +549,74 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     double uv = 0.0;
     if (DOT) uv = dp.u[(j0 == 0 && rl < nrows) ? row0 + rl : 0];     // requested ahead of the stream: hidden behind it
 
+    if (bs <= -TPL_CODE) {
+        // TEMPLATE block (k_pk_meta): every entry lies on one of D <= 32 diagonals and every row says by a mask which of them it
+        // has.  As in a run block nothing but the values streams and the x gathers go out beside the value stream -- their
+        // addresses come from the row's mask and the D offsets (held one per lane, fetched by a wavefront shuffle), not from staged
+        // columns.  Entry e of a row is the e-th set bit of its mask (columns ascend); lane (row, j0) takes entries j0, j0 + T, ...
+        // and the partial sums meet as in the general path: the same bits.
+        static_assert(UNR * T >= TPL_MAXD, "one predicated batch covers the longest row of a template block");
+        const int D = -bs - TPL_CODE;
+        const int *tplp = reinterpret_cast<const int *>(packed + po);
+        const unsigned *mskp = reinterpret_cast<const unsigned *>(tplp + ((D + 3) & ~3));
+        const bool live = rl < nrows;
+        v2d pv[VR];
+#pragma unroll
+        for (int r = 0; r < VR; r++) {
+            const int u = 2 * (tid + r * VB);
+            pv[r] = *reinterpret_cast<const v2d *>(val + (long)bv + (u < cntv ? u : 0));
+        }
+        const unsigned mask = live ? mskp[rl] : 0u;
+        const int myoff = tplp[rl < D ? rl : 0];            // lane l < D of every wavefront holds offset l
+        const int rs = live ? rowptr[row0 + rl] - bv : 0;   // this lane's row in the staged values
+        const int len = __popc(mask);
+        const unsigned full = D >= 32 ? 0xffffffffu : ((1u << D) - 1u);
+        const bool dense = __ballot(live && mask != full) == 0ull;      // uniform: every live row has all D diagonals
+        double xv[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; q++) {
+            int e = j0 + q * T;
+            int slot = e;
+            if (!dense) {       // uniform: position of the e-th set bit of the mask (five halving steps)
+                unsigned m = mask; int pos = 0;
+#pragma unroll
+                for (int w = 16; w > 0; w >>= 1) {
+                    const int c = __popc(m & ((1u << w) - 1u));
+                    if (e >= c) { e -= c; pos += w; m >>= w; }
+                }
+                slot = pos;
+            }
+            const int off = __shfl(myoff, slot & 31, 64);
+            const bool ok = live && j0 + q * T < len;
+            xv[q] = x[ok ? rl + off : 0];       // (the offsets are row 0's columns, as in a run block: column = offset + row in block)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < VR; r++) {
+            const int u = 2 * (tid + r * VB);
+            if (u < cntv) *reinterpret_cast<v2d *>(sval + u) = pv[r];
+        }
+        __syncthreads();
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < UNR; q++) {
+            const int e = j0 + q * T;
+            acc = (live && e < len) ? fma(sval[rs + e], xv[q], acc) : acc;
+        }
+        __syncthreads();
+        sred[j0][rl] = acc;
+        __syncthreads();
+        double vfin = 0.0;
+        if (j0 == 0 && live) {
+            double v = sred[0][rl];
+#pragma unroll
+            for (int j = 1; j < T; j++) v += sred[j][rl];
+            y[row0 + rl] = v;
+            vfin = v;
+        }
+        if (DOT) ldsp_dot_tail(dp, bid, j0, vfin, uv);
+        return;
+    }
     if (bs < 0) {
         // RUN block (k_pk_meta): every row holds L entries and column(row r, slot k) = column(row 0, slot k) + r.  Nothing but
         // the values streams; the columns are row 0's L integers, read through the scalar cache (a wavefront is one slot j0 of
@@ -800,14 +974,16 @@ static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only)
     const int nb = (n + PK_R - 1) / PK_R;
     int *ngr = nullptr, *span = nullptr;
     long total = 0;
-    int hspan[3] = {0, 0, 0};
+    int hspan[4] = {0, 0, 0, 0};
     static const int runs = [] { const char *e = std::getenv("LCG_HIP_PACKED_RUNS"); return e ? atoi(e) : 1; }();    // 0: A/B runs without run blocks
     bool ok = hipMalloc(&P.pk_base, sizeof(int) * (size_t)nb) == hipSuccess && hipMalloc(&P.pk_ofs, sizeof(int) * ((size_t)nb + 1)) == hipSuccess &&
-              hipMalloc(&ngr, sizeof(int) * (size_t)nb) == hipSuccess && hipMalloc(&span, 3 * sizeof(int)) == hipSuccess &&
-              hipMemsetAsync(span, 0, 3 * sizeof(int), s) == hipSuccess;
+              hipMalloc(&ngr, sizeof(int) * (size_t)nb) == hipSuccess && hipMalloc(&span, 4 * sizeof(int)) == hipSuccess &&
+              hipMemsetAsync(span, 0, 4 * sizeof(int), s) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(k_pk_meta, dim3(nb), dim3(64), 0, s, n, P.rowptr, P.col, P.pk_base, ngr, span, runs);
-        ok = hipMemcpyAsync(hspan, span, 3 * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        // (k_pk_meta: 0 no run blocks, 1 run blocks and template blocks, 2 run blocks only)
+        static const int tpls = [] { const char *e = std::getenv("LCG_HIP_PACKED_TEMPLATES"); return e ? atoi(e) : 1; }();    // 0: A/B runs without template blocks
+        hipLaunchKernelGGL(k_pk_meta, dim3(nb), dim3(64), 0, s, n, P.rowptr, P.col, P.pk_base, ngr, span, runs ? ((runs_only || !tpls) ? 2 : 1) : 0);
+        ok = hipMemcpyAsync(hspan, span, 4 * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     }
     if (ok) ok = runs_only ? (runs && 2L * hspan[2] >= nb) : hspan[0] < PK_SPAN;     // runs only: worth it when most blocks are runs
     static const int force_bits = [] { const char *e = std::getenv("LCG_HIP_PACKED_BITS"); return e ? atoi(e) : 0; }();   // 21: A/B runs
@@ -839,6 +1015,7 @@ static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only)
     }
     P.pk_maxrow = hspan[1];
     P.pk_runs = hspan[2];
+    P.pk_tpls = hspan[3];
     P.pk_groups = total;
     P.pk_bits = bits;
     P.pk_state = runs_only ? 2 : 1;
@@ -949,6 +1126,26 @@ static bool tiled_chosen(const CsrPart &P, hipStream_t s)
     const int rc = tiled_ready(P, s, min_fill);
     if (rc <= 0) { P.tl_state = -1; return false; }
     return true;
+}
+
+// what k_spmv_ldsp multiplied with (static strings: lcg_hip_csr_last_kernel hands them out)
+static const char *ldsp_name(const CsrPart &P, bool dot)
+{
+    const int form = (P.pk_runs > 0 ? 1 : 0) + (P.pk_tpls > 0 ? 2 : 0);
+    if (dot) {
+        static const char *const d[4] = {"k_spmv_ldsp (LDS-staged, packed columns) carrying the dot that follows the product",
+                                         "k_spmv_ldsp (LDS-staged, run blocks + packed columns) carrying the dot that follows the product",
+                                         "k_spmv_ldsp (LDS-staged, template blocks + packed columns) carrying the dot that follows the product",
+                                         "k_spmv_ldsp (LDS-staged, run blocks + template blocks + packed columns) carrying the dot that follows the product"};
+        return d[form];
+    }
+    static const char *const a[2][4] = {{"k_spmv_ldsp (LDS-staged, 18-bit packed columns)", "k_spmv_ldsp (LDS-staged, run blocks + 18-bit packed columns)",
+                                         "k_spmv_ldsp (LDS-staged, template blocks + 18-bit packed columns)",
+                                         "k_spmv_ldsp (LDS-staged, run blocks + template blocks + 18-bit packed columns)"},
+                                        {"k_spmv_ldsp (LDS-staged, 21-bit packed columns)", "k_spmv_ldsp (LDS-staged, run blocks + 21-bit packed columns)",
+                                         "k_spmv_ldsp (LDS-staged, template blocks + 21-bit packed columns)",
+                                         "k_spmv_ldsp (LDS-staged, run blocks + template blocks + 21-bit packed columns)"}};
+    return a[P.pk_bits == 18 ? 0 : 1][form];
 }
 
 // rows per block of the LDS-staged kernels so that R*mean_row entries fit one LDS window, and whether EVERY block's slice
@@ -1244,8 +1441,7 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
 #undef PK_LAUNCH
 #undef PK_CASE
                 HIPCHK(hipGetLastError());
-                P.last_kernel = P.pk_runs > 0 ? (P.pk_bits == 18 ? "k_spmv_ldsp (LDS-staged, run blocks + 18-bit packed columns)" : "k_spmv_ldsp (LDS-staged, run blocks + 21-bit packed columns)")
-                                              : (P.pk_bits == 18 ? "k_spmv_ldsp (LDS-staged, 18-bit packed columns)" : "k_spmv_ldsp (LDS-staged, 21-bit packed columns)");
+                P.last_kernel = ldsp_name(P, false);
                 return 0;
             }
         }
@@ -1343,8 +1539,7 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
 #undef PKD_LAUNCH
 #undef PKD_CASE
     HIPCHK(hipGetLastError());
-    P.last_kernel = P.pk_runs > 0 ? "k_spmv_ldsp (LDS-staged, run blocks + packed columns) carrying the dot that follows the product"
-                                  : "k_spmv_ldsp (LDS-staged, packed columns) carrying the dot that follows the product";
+    P.last_kernel = ldsp_name(P, true);
     if (nofold) { *nofold = nblk; *slots = 0; return 1; }
     const int g2 = std::min(512, (nblk + VB - 1) / VB);
     const int per = (nblk + g2 - 1) / g2;
@@ -1352,8 +1547,7 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
     if (fp && fp->fin && !yy) { fin = *fp; fin.pc.axp = part; fin.pc.ax_n = (nblk + per - 1) / per; }
     hipLaunchKernelGGL(k_axp_fold, dim3((nblk + per - 1) / per), dim3(VB), 0, s, P.dot_part, nblk, nblk, per, yy, part, done, fin);
     HIPCHK(hipGetLastError());
-    P.last_kernel = P.pk_runs > 0 ? "k_spmv_ldsp (LDS-staged, run blocks + packed columns) carrying the dot that follows the product"
-                                  : "k_spmv_ldsp (LDS-staged, packed columns) carrying the dot that follows the product";
+    P.last_kernel = ldsp_name(P, true);
     *slots = (nblk + per - 1) / per;
     return 1;
 }
@@ -2181,6 +2375,13 @@ static int64_t part_traffic_model(const CsrPart &P)
         return 8 * P.nnz + (int64_t)(4.0 * other * (double)P.nnz) + 16 * (int64_t)P.pk_groups + 8 * nb + vectors;
     }
     return 12 * P.nnz + vectors;                        // the CSR arrays as they are
+}
+
+int64_t lcg_hip_csr_packed_templates(lcg_hip_csr_t A)
+{
+    if (!A) return 0;
+    const CsrPart &P = A->distributed ? A->loc : A->main;
+    return P.pk_state > 0 ? P.pk_tpls : 0;
 }
 
 int64_t lcg_hip_csr_last_traffic_model(lcg_hip_csr_t A)

@@ -204,6 +204,7 @@ struct CsrPart {
     mutable int pk_maxrow = 0;                              // longest row (chooses the gather batch of the kernel)
     mutable int pk_bits = 21;                               // width of a packed column: 18 (seven per group) or 21 (six)
     mutable int pk_runs = 0;                                // blocks stored as runs (row 0's columns only; csr.hip: k_pk_meta)
+    mutable int pk_tpls = 0;                                // blocks stored as templates (<= 32 diagonals + a mask per row)
     mutable long pk_groups = 0;                             // 16-byte groups of the packed columns
     mutable double *dot_part = nullptr;                     // [2][blocks of 64 rows]: per-block sums of a product that carries its dot (k_spmv_ldsp<DOT>)
     // two-pass "binned" product for scattered columns (csr_binned.hip), plan built on first use

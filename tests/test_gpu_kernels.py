@@ -143,6 +143,81 @@ def test_run_blocks_of_the_packed_form(api, port):
     assert lib.lcg_hip_csr_packed_runs(B2.h, None) == 0 and "run blocks" not in lib.lcg_hip_csr_last_kernel(B2.h).decode()
 
 
+def _stencil(dims, reach):
+    """CSR of the full (2 reach + 1)^d-point stencil on a grid of the given dims (last index fastest), random values."""
+    n = int(np.prod(dims))
+    idx = np.arange(n).reshape(dims)
+    rows, cols = [], []
+    rng = range(-reach, reach + 1)
+    import itertools
+    for d in itertools.product(*([rng] * len(dims))):
+        src = idx[tuple(slice(max(0, -k), m - max(0, k)) for k, m in zip(d, dims))].ravel()
+        dst = idx[tuple(slice(max(0, k), m - max(0, -k)) for k, m in zip(d, dims))].ravel()
+        rows.append(src); cols.append(dst)
+    r = np.concatenate(rows); c = np.concatenate(cols)
+    order = np.lexsort((c, r))
+    r, c = r[order], c[order]
+    rp = np.zeros(n + 1, np.int64); np.add.at(rp, r + 1, 1)
+    return n, np.cumsum(rp).astype(np.int32), c.astype(np.int32)
+
+
+def test_template_blocks_of_the_packed_form(api, port):
+    """Template blocks (csr.hip: k_pk_meta / the template path of k_spmv_ldsp): a block of 64 rows whose entries all lie on the
+    <= 32 diagonals of its longest row keeps those offsets and a mask per row -- the blocks of a stencil that grid boundaries
+    pass through.  27-point stencils on grids whose lines are shorter than, equal to, and no multiple of the 64-row block, a
+    5 x 5 stencil in 2D: every block must be a run or a template, y must equal the plain row-block kernel's bit for bit, the
+    carried dot must agree with numpy, and with one row moved off the diagonals its block must fall back alone (more than 32
+    diagonals) or take the new diagonals in (the template is the union of the block's offsets)."""
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(27)
+    nblk = C.c_int64()
+    for dims, reach in (((9, 7, 5), 1), ((20, 33, 64), 1), ((6, 10, 128), 1), ((11, 13, 100), 1), ((70, 90), 2), ((3, 257), 2)):
+        n, rp, ci = _stencil(dims, reach)
+        val = rng.standard_normal(len(ci)); x = rng.standard_normal(n)
+        for broken in (False, True):
+            c = ci.copy()
+            if broken:      # row 70: every entry one column further (still ascending): in 3D nine diagonals the block does not have -- 36 > 32
+                if n <= 71 or c[rp[71] - 1] + 1 >= n:
+                    continue
+                c[rp[70]:rp[71]] += 1
+            A = api.CsrMatrix.from_csr(rp, c, val)
+            xd = torch.from_numpy(x).cuda()
+            y0 = torch.empty(n, dtype=torch.float64, device="cuda"); y1 = torch.full_like(y0, 5.0)
+            A.set_kernel(-64)
+            assert lib.lcg_hip_csr_set_packed(A.h, 0) == 0
+            A.spmv(xd, y0); api.synchronize()
+            assert lib.lcg_hip_csr_set_packed(A.h, 1) == 0
+            A.spmv(xd, y1); api.synchronize()
+            name = lib.lcg_hip_csr_last_kernel(A.h).decode()
+            runs = lib.lcg_hip_csr_packed_runs(A.h, C.byref(nblk)); tpls = lib.lcg_hip_csr_packed_templates(A.h)
+            assert "k_spmv_ldsp" in name and "template blocks" in name, (dims, name)
+            # every block with at most 32 distinct offsets (column - row in block) is a run or a template; the others -- where the
+            # shifted row brings more diagonals than a mask has bits -- fall back to their packed columns, alone
+            lane = np.arange(n) % 64
+            offs = c - np.repeat(lane, np.diff(rp))
+            blk = np.repeat(np.arange(n) // 64, np.diff(rp))
+            distinct = np.array([len(np.unique(offs[blk == b])) for b in range((n + 63) // 64)])
+            assert runs + tpls == int((distinct <= 32).sum()) and tpls > 0, (dims, broken, runs, tpls, nblk.value, distinct[:4])
+            if broken and dims == (9, 7, 5):
+                assert distinct[1] > 32 and runs + tpls == nblk.value - 1
+            assert torch.equal(y0, y1), (dims, broken)
+            ref = port.csr_matvec(rp, c, val, x)
+            bound = port.csr_matvec(rp, c, np.abs(val), np.abs(x))
+            assert float(np.max(np.abs(y1.cpu().numpy() - ref) / bound)) <= 1e-13, (dims, broken)
+            # the product the solver loops run: the dot carried by template blocks too
+            u = torch.from_numpy(rng.standard_normal(n)).cuda()
+            sums = (C.c_double * 2)()
+            y2 = torch.empty_like(y0)
+            A.set_kernel(0)        # (the automatic choice: rows of ~27 entries take the packed kernel with the dot in its epilogue)
+            assert lib.lcg_hip_spmv_dot(A.h, xd.data_ptr(), y2.data_ptr(), u.data_ptr(), sums) == 0
+            # (another number of rows per block than the forced 64 above where the rows are short: other last bits)
+            assert float(np.max(np.abs(y2.cpu().numpy() - ref) / bound)) <= 1e-13, (dims, broken, lib.lcg_hip_csr_last_kernel(A.h))
+            yu = float(ref @ u.cpu().numpy()); yy = float(ref @ ref)
+            assert abs(sums[0] - yu) <= 1e-11 * float(np.abs(ref) @ np.abs(u.cpu().numpy())) and abs(sums[1] - yy) <= 1e-12 * yy
+            A.destroy()
+
+
 def test_short_row_runs_one_wavefront_per_block(api, port):
     """k_spmv_run1 (short rows whose 64-row blocks are mostly runs -- stencils): against the LDS-staged kernel the automatic
     choice would otherwise take (packed copy switched off), bit for bit.  L = 1 .. 17 covers one and two partial sums per row
