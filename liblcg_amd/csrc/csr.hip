@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64) void k_pk_meta(int n, const int *rowptr, const 
         if (e == s) { lo = 0; hi = 0; }
         base[b] = run ? -1 - L : (tplb ? -TPL_CODE - D : lo);
         ngroups[b] = run ? -L : (tplb ? -TPL_GRP - D : e - s);
-        if (!tplb) atomicMax(maxspan, hi - lo);     // (a template block's columns are not stored relative to anything)
+        if (!tplb && !run) atomicMax(maxspan, hi - lo);     // (only the blocks that keep packed columns store them relative to their smallest)
         atomicMax(maxspan + 1, L);
         if (run) atomicAdd(maxspan + 2, 1);
         if (tplb) atomicAdd(maxspan + 3, 1);
@@ -1042,6 +1042,8 @@ static double span_threshold()
     return v;
 }
 
+static bool diag_like_measured(const CsrPart &P, hipStream_t s);     // (below)
+
 // true when P's products go through the binned format (plan built here on first use)
 static bool binned_chosen(const CsrPart &P, hipStream_t s)
 {
@@ -1068,6 +1070,11 @@ static bool binned_chosen(const CsrPart &P, hipStream_t s)
             P.mean_span = (double)h / nb;
         }
         if (P.mean_span < span_threshold()) { P.bn_state = -1; P.bn_why = "automatic mode: the row blocks' mean column span is below the threshold"; return false; }
+        // wide, but along diagonals (a stencil on a grid with a million points per plane): every diagonal is a contiguous stream of
+        // x for the row-block kernels, whatever the distance between the diagonals
+        if (diag_like_measured(P, s) && P.diag_like > 0.5) {
+            P.bn_state = -1; P.bn_why = "automatic mode: the columns run along diagonals (the row-block kernels gather contiguously)"; return false;
+        }
     }
     const int rc = binned_ready(P, s);      // sets bn_state
     if (rc <= 0) { P.bn_state = -1; return false; }
@@ -1091,6 +1098,22 @@ __global__ __launch_bounds__(VB) void k_diag_like(int n, const int *__restrict__
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(sum, (unsigned long long)cnt);
 }
 
+// P.diag_like (measured once): false when the measurement failed
+static bool diag_like_measured(const CsrPart &P, hipStream_t s)
+{
+    if (P.diag_like >= 0.0) return true;
+    unsigned long long *d = nullptr, h = 0;
+    bool ok = hipMalloc(&d, sizeof h) == hipSuccess && hipMemsetAsync(d, 0, sizeof h, s) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_diag_like, dim3((P.n_rows + VB - 1) / VB), dim3(VB), 0, s, P.n_rows, P.rowptr, P.col, d);
+        ok = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    }
+    if (d) hipFree(d);
+    if (!ok) { (void)hipGetLastError(); return false; }
+    P.diag_like = P.nnz > 0 ? (double)h / (double)P.nnz : 0.0;
+    return true;
+}
+
 static double tiled_fill_threshold()
 {
     static const double fill = [] { const char *e = std::getenv("LCG_HIP_TILED_FILL"); return e ? atof(e) : 700.0; }();
@@ -1107,17 +1130,7 @@ static bool tiled_chosen(const CsrPart &P, hipStream_t s)
     PlanTimer timer(P, s);
     double min_fill = 0.0;
     if (mode < 0) {
-        if (P.diag_like < 0.0) {
-            unsigned long long *d = nullptr, h = 0;
-            bool ok = hipMalloc(&d, sizeof h) == hipSuccess && hipMemsetAsync(d, 0, sizeof h, s) == hipSuccess;
-            if (ok) {
-                hipLaunchKernelGGL(k_diag_like, dim3((P.n_rows + VB - 1) / VB), dim3(VB), 0, s, P.n_rows, P.rowptr, P.col, d);
-                ok = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-            }
-            if (d) hipFree(d);
-            if (!ok) { (void)hipGetLastError(); P.tl_state = -1; return false; }
-            P.diag_like = (double)h / (double)P.nnz;
-        }
+        if (!diag_like_measured(P, s)) { P.tl_state = -1; return false; }
         if (P.diag_like > 0.5) { P.tl_state = -1; P.tl_why = "automatic mode: the columns run along diagonals (the row-block kernels gather contiguously)"; return false; }
         // least mean number of entries per (workgroup of 8192 rows, tile of 2048 columns) pair.  Measured at N = 1e7, 33 per row (round 3):
         // W = 524288, 1052 per pair: tiled 1.01-1.17 ms, binned 1.70; W = 1048576, 527 per pair: tiled 1.96 ms, binned 1.72

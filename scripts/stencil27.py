@@ -3,7 +3,7 @@
 8M rows, 2.1e8 entries), built as COO on the device with torch, handed to lcg_hip_csr_from_coo through the host, multiplied by
 whatever kernel the automatic choice takes.  Prints the kernel, time per product, algorithmic GB/s and the CG rate.
 
-  python scripts/stencil27.py [nx ny nz]
+  python scripts/stencil27.py [nx ny nz [27|7]]
 """
 import sys
 import time
@@ -16,6 +16,7 @@ from liblcg_amd import _lib, api
 
 lib = _lib.load(); assert lib.lcg_hip_init(0) == 0
 nx, ny, nz = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (200, 200, 200)
+points = int(sys.argv[4]) if len(sys.argv) >= 5 else 27        # 27 (full cube) or 7 (faces only)
 n = nx * ny * nz
 dev = "cuda"
 idx = torch.arange(n, device=dev, dtype=torch.int64).reshape(nz, ny, nx)
@@ -23,10 +24,12 @@ rows, cols, vals = [], [], []
 for dz in (-1, 0, 1):
     for dy in (-1, 0, 1):
         for dx in (-1, 0, 1):
+            if points == 7 and abs(dx) + abs(dy) + abs(dz) > 1:
+                continue
             src = idx[max(0, -dz):nz - max(0, dz), max(0, -dy):ny - max(0, dy), max(0, -dx):nx - max(0, dx)].reshape(-1)
             dst = idx[max(0, dz):nz - max(0, -dz), max(0, dy):ny - max(0, -dy), max(0, dx):nx - max(0, -dx)].reshape(-1)
             rows.append(src); cols.append(dst)
-            vals.append(torch.full((src.numel(),), 27.0 if (dx, dy, dz) == (0, 0, 0) else -1.0, device=dev, dtype=torch.float64))
+            vals.append(torch.full((src.numel(),), float(points) if (dx, dy, dz) == (0, 0, 0) else -1.0, device=dev, dtype=torch.float64))
 r = torch.cat(rows); c = torch.cat(cols); v = torch.cat(vals)
 order = torch.argsort(r * n + c)
 r, c, v = r[order], c[order], v[order]
@@ -47,7 +50,7 @@ api.synchronize()
 t = (time.perf_counter() - t0) / reps
 byts = 12 * nnz + 4 * (n + 1) + 16 * n
 runs = lib.lcg_hip_csr_packed_runs(A.h, None)
-print(f"27-point stencil {nx}x{ny}x{nz}: rows {n}, entries {nnz}; kernel: {lib.lcg_hip_csr_last_kernel(A.h).decode()} ({runs} run blocks of {(n + 63) // 64})")
+print(f"{points}-point stencil {nx}x{ny}x{nz}: rows {n}, entries {nnz}; kernel: {lib.lcg_hip_csr_last_kernel(A.h).decode()} ({runs} run blocks of {(n + 63) // 64})")
 print(f"A.x {t * 1e6:.1f} us = {byts / t / 1e9:.0f} GB/s algorithmic = {byts / t / 8e12:.3f} of 8 TB/s; must move {lib.lcg_hip_csr_last_traffic_model(A.h) / t / 8e12:.3f}; first call {first * 1e3:.1f} ms")
 xt = torch.rand(n, dtype=torch.float64, device=dev); b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
 m = torch.zeros_like(xt)
