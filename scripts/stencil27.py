@@ -36,6 +36,11 @@ r, c, v = r[order], c[order], v[order]
 rp = torch.zeros(n + 1, dtype=torch.int64, device=dev); rp[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
 A = api.CsrMatrix.from_csr(rp.to(torch.int32), c.to(torch.int32), v)
 nnz = A.nnz
+import os
+if os.environ.get("KERNEL"):
+    A.set_kernel(int(os.environ["KERNEL"]))
+if os.environ.get("PACKED"):
+    assert lib.lcg_hip_csr_set_packed(A.h, int(os.environ["PACKED"])) == 0
 del r, c, v, rows, cols, vals, order
 x = torch.rand(n, dtype=torch.float64, device=dev); y = torch.empty_like(x)
 t0 = time.perf_counter(); A.spmv(x, y); api.synchronize(); first = time.perf_counter() - t0
