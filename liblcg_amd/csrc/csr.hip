@@ -412,7 +412,7 @@ __global__ __launch_bounds__(64) void k_pk_meta(int n, const int *rowptr, const 
     }
     int D = 0;
     bool tplb = false;
-    if (!run && runs == 1 && e > s) {       // uniform (runs == 2: run blocks only -- the short-row kernel walks the others from the CSR arrays)
+    if (!run && runs == 1 && e > s) {       // uniform (runs == 2: run blocks only, LCG_HIP_PACKED_TEMPLATES=0)
         bool bad;
         (void)tpl_row_mask(row0, r1, rowptr, col, tpl, &dcount, &D, &bad);
         tplb = !bad;        // (uniform)
@@ -819,7 +819,35 @@ __device__ __forceinline__ double run1_block(int b, int wv, int n, int LP, const
     double acc[T];
 #pragma unroll
     for (int j = 0; j < T; j++) acc[j] = 0.0;
-    if (bs < 0) {
+    if (bs <= -TPL_CODE) {
+        // TEMPLATE block (k_pk_meta): the block's entries lie on D <= 32 diagonals, a mask per row says which.  A uniform loop over
+        // the diagonals: the offset is a scalar, the gather x[offset + lane] one run with holes, the row's value the
+        // popcount-th of its entries -- no column is read.  Entry e goes to partial sum e mod T like everywhere: the same bits.
+        const int D = -bs - TPL_CODE;
+        const int *tplp = pcols + 4 * (long)po;
+        const unsigned mask = live ? reinterpret_cast<const unsigned *>(tplp + ((D + 3) & ~3))[lane] : 0u;
+        const int rs = live ? rowptr[row0 + lane] : 0;
+        for (int k0 = 0; k0 < D; k0 += NB) {
+            double a[NB], xv[NB]; int e[NB]; bool ok[NB];
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                const int k = k0 + q;                       // uniform
+                const int off = tplp[k < D ? k : 0];        // scalar load
+                ok[q] = k < D && ((mask >> (k & 31)) & 1u);
+                e[q] = __popc(mask & ((1u << (k & 31)) - 1u));
+                a[q] = val[ok[q] ? rs + e[q] : 0];
+                xv[q] = x[ok[q] ? off + lane : 0];
+            }
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                if (T == 1) acc[0] = ok[q] ? fma(a[q], xv[q], acc[0]) : acc[0];
+                else {
+#pragma unroll
+                    for (int j = 0; j < T; j++) acc[j] = (ok[q] && (e[q] % T) == j) ? fma(a[q], xv[q], acc[j]) : acc[j];
+                }
+            }
+        }
+    } else if (bs < 0) {
         const int L = -1 - bs;
         const int *bcol = pcols + 4 * (long)po;
         double *mine = wlds + (size_t)wv * 64 * LP;
@@ -982,10 +1010,10 @@ static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only)
     if (ok) {
         // (k_pk_meta: 0 no run blocks, 1 run blocks and template blocks, 2 run blocks only)
         static const int tpls = [] { const char *e = std::getenv("LCG_HIP_PACKED_TEMPLATES"); return e ? atoi(e) : 1; }();    // 0: A/B runs without template blocks
-        hipLaunchKernelGGL(k_pk_meta, dim3(nb), dim3(64), 0, s, n, P.rowptr, P.col, P.pk_base, ngr, span, runs ? ((runs_only || !tpls) ? 2 : 1) : 0);
+        hipLaunchKernelGGL(k_pk_meta, dim3(nb), dim3(64), 0, s, n, P.rowptr, P.col, P.pk_base, ngr, span, runs ? (tpls ? 1 : 2) : 0);
         ok = hipMemcpyAsync(hspan, span, 4 * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     }
-    if (ok) ok = runs_only ? (runs && 2L * hspan[2] >= nb) : hspan[0] < PK_SPAN;     // runs only: worth it when most blocks are runs
+    if (ok) ok = runs_only ? (runs && 2L * (hspan[2] + hspan[3]) >= nb) : hspan[0] < PK_SPAN;     // runs only: worth it when most blocks are runs or templates
     static const int force_bits = [] { const char *e = std::getenv("LCG_HIP_PACKED_BITS"); return e ? atoi(e) : 0; }();   // 21: A/B runs
     const int bits = runs_only ? 0 : ((hspan[0] < (1 << 18) && force_bits != 21) ? 18 : 21);     // seven 18-bit columns per group where the blocks are narrow enough
     if (ok) {
@@ -2384,7 +2412,7 @@ static int64_t part_traffic_model(const CsrPart &P)
     if (std::strncmp(k, "k_spmv_ldsp", 11) == 0)       // values + packed columns (run blocks: row 0's columns only) + two words per block
         return 8 * P.nnz + 16 * (int64_t)P.pk_groups + 8 * nb + vectors;
     if (std::strncmp(k, "k_spmv_run1", 11) == 0) {     // values + row 0's columns of the run blocks + the CSR columns of the other blocks
-        const double other = nb > 0 ? 1.0 - (double)P.pk_runs / (double)nb : 1.0;
+        const double other = nb > 0 ? 1.0 - (double)(P.pk_runs + P.pk_tpls) / (double)nb : 1.0;
         return 8 * P.nnz + (int64_t)(4.0 * other * (double)P.nnz) + 16 * (int64_t)P.pk_groups + 8 * nb + vectors;
     }
     return 12 * P.nnz + vectors;                        // the CSR arrays as they are

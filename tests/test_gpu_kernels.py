@@ -143,14 +143,17 @@ def test_run_blocks_of_the_packed_form(api, port):
     assert lib.lcg_hip_csr_packed_runs(B2.h, None) == 0 and "run blocks" not in lib.lcg_hip_csr_last_kernel(B2.h).decode()
 
 
-def _stencil(dims, reach):
-    """CSR of the full (2 reach + 1)^d-point stencil on a grid of the given dims (last index fastest), random values."""
+def _stencil(dims, reach, faces=False):
+    """CSR of the full (2 reach + 1)^d-point stencil on a grid of the given dims (last index fastest); faces: the 2d + 1-point
+    stencil (neighbours along one axis only)."""
     n = int(np.prod(dims))
     idx = np.arange(n).reshape(dims)
     rows, cols = [], []
     rng = range(-reach, reach + 1)
     import itertools
     for d in itertools.product(*([rng] * len(dims))):
+        if faces and sum(1 for k in d if k) > 1:
+            continue
         src = idx[tuple(slice(max(0, -k), m - max(0, k)) for k, m in zip(d, dims))].ravel()
         dst = idx[tuple(slice(max(0, k), m - max(0, -k)) for k, m in zip(d, dims))].ravel()
         rows.append(src); cols.append(dst)
@@ -266,6 +269,31 @@ def test_short_row_runs_one_wavefront_per_block(api, port):
             assert torch.equal(y0, y1), (L, n, kern)
             assert abs(res2[0] - float(ref @ u)) <= 1e-12 * float(np.abs(ref) @ np.abs(u)) and abs(res2[1] - float(ref @ ref)) <= 1e-12 * float(ref @ ref)
             A.destroy()
+    # short-row stencils whose EVERY block holds boundary rows (grid lines no longer than the block): template blocks in the
+    # one-wavefront-per-block kernel -- 7-point in 3D, 5-point and 9-point in 2D, 13-point (reach 2) in 3D
+    for dims, reach, faces in (((6, 9, 16), 1, True), ((5, 40, 64), 1, True), ((7, 5, 128), 1, True), ((40, 50), 1, True), ((33, 64), 1, False),
+                               ((9, 8, 30), 2, True)):
+        n, rp, col = _stencil(dims, reach, faces)
+        val = rng.standard_normal(len(col)); x = rng.standard_normal(n)
+        A = api.CsrMatrix.from_csr(rp, col, val)
+        xd = torch.from_numpy(x).cuda()
+        y0 = torch.empty(n, dtype=torch.float64, device="cuda"); y1 = torch.full_like(y0, 5.0)
+        assert lib.lcg_hip_csr_set_packed(A.h, 0) == 0
+        A.spmv(xd, y0); api.synchronize()
+        assert "k_spmv_lds1" in lib.lcg_hip_csr_last_kernel(A.h).decode()
+        assert lib.lcg_hip_csr_set_packed(A.h, -1) == 0
+        A.spmv(xd, y1); api.synchronize()
+        assert "k_spmv_run1" in lib.lcg_hip_csr_last_kernel(A.h).decode(), (dims, lib.lcg_hip_csr_last_kernel(A.h))
+        assert lib.lcg_hip_csr_packed_templates(A.h) > 0, dims
+        assert torch.equal(y0, y1), dims
+        ref = port.csr_matvec(rp, col, val, x)
+        assert float(np.max(np.abs(y1.cpu().numpy() - ref) / port.csr_matvec(rp, col, np.abs(val), np.abs(x)))) <= 1e-13
+        u = rng.standard_normal(n); ud = torch.from_numpy(u).cuda()
+        y1.fill_(7.0)
+        assert lib.lcg_hip_spmv_dot(A.h, xd.data_ptr(), y1.data_ptr(), ud.data_ptr(), res2) == 0
+        assert torch.equal(y0, y1), (dims, lib.lcg_hip_csr_last_kernel(A.h))
+        assert abs(res2[0] - float(ref @ u)) <= 1e-12 * float(np.abs(ref) @ np.abs(u)) and abs(res2[1] - float(ref @ ref)) <= 1e-12 * float(ref @ ref)
+        A.destroy()
     # the Laplacian of configs[1] at a tenth of the size: mostly runs; a ragged matrix of the same density: none -> staged kernel
     A = api.CsrMatrix.laplace2d(400, 250); n = 100000
     xd = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 3, 0, n, xd)
