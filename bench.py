@@ -156,20 +156,49 @@ def main():
         del parts, rp1, c1, v1, rp2, c2, v2
         return api.CsrMatrix.from_csr(rp, ci, vv, n_cols=n)
 
+    def stencil27_matrix():
+        """A REAL structured matrix beside the synthetic family: the 27-point stencil of a cubic grid with about 0.8 x --rows points
+        (200^3 = 8M rows, 2.1e8 entries at the default size), 27 on the diagonal and -1 elsewhere (SPD), built on the device."""
+        g = max(4, int(round((0.8 * n) ** (1.0 / 3.0))))
+        ns = g * g * g
+        idx = torch.arange(ns, device="cuda", dtype=torch.int64).reshape(g, g, g)
+        rows, cols, vals = [], [], []
+        for dz in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    src = idx[max(0, -dz):g - max(0, dz), max(0, -dy):g - max(0, dy), max(0, -dx):g - max(0, dx)].reshape(-1)
+                    dst = idx[max(0, dz):g - max(0, -dz), max(0, dy):g - max(0, -dy), max(0, dx):g - max(0, -dx)].reshape(-1)
+                    rows.append(src); cols.append(dst)
+                    vals.append(torch.full((src.numel(),), 27.0 if (dx, dy, dz) == (0, 0, 0) else -1.0, device="cuda", dtype=torch.float64))
+        r = torch.cat(rows); c = torch.cat(cols); v = torch.cat(vals)
+        del rows, cols, vals, idx
+        order = torch.argsort(r * ns + c)
+        r, c, v = r[order], c[order], v[order]
+        rp = torch.zeros(ns + 1, dtype=torch.int64, device="cuda"); rp[1:] = torch.cumsum(torch.bincount(r, minlength=ns), 0)
+        A = api.CsrMatrix.from_csr(rp.to(torch.int32), c.to(torch.int32), v)
+        return A, ns
+
     class System:
         """One generated system resident in HBM: A (this rank's rows), x_true, b = A.x_true, workspaces."""
 
         def __init__(self, pattern):
             self.pattern = pattern
+            self.n, self.nloc = n, nloc
             if pattern == "mixed_rows":
                 self.A = mixed_rows_matrix()
+            elif pattern == "stencil27":
+                self.A, self.n = stencil27_matrix()
+                self.nloc = self.n
             else:
                 band = args.band if PATTERNS[pattern] else 0
                 self.A = api.CsrMatrix.generate(n, args.npairs, band, symmetric, 1, 0.01, r0, r1, pattern=PATTERNS[pattern])
             if args.solver == "pcg":
                 self.A.build_jacobi()
-            self.xt = torch.empty(nloc, dtype=torch.float64, device="cuda")
-            api.gen_xtrue(n, 1, r0, r1, self.xt)
+            self.xt = torch.empty(self.nloc, dtype=torch.float64, device="cuda")
+            if pattern == "stencil27":
+                api.gen_xtrue(self.n, 1, 0, self.n, self.xt)
+            else:
+                api.gen_xtrue(n, 1, r0, r1, self.xt)
             self.b = torch.empty_like(self.xt)
             self.m = torch.zeros_like(self.xt)
             self.ws = [torch.empty_like(self.xt) for _ in range(7)]
@@ -185,12 +214,12 @@ def main():
             p = api.lcg_default_parameters(epsilon=1e-300, max_iterations=iters)
             A, m, b, ws = self.A, self.m, self.b, self.ws
             if args.solver == "cg":
-                return api.lcg("lcg_hip_csr_ax", None, m, b, nloc, p, A, ws[0], ws[1], ws[2])
+                return api.lcg("lcg_hip_csr_ax", None, m, b, self.nloc, p, A, ws[0], ws[1], ws[2])
             if args.solver == "pcg":
-                return api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, b, nloc, p, A)
+                return api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, b, self.nloc, p, A)
             if args.solver == "cgs":
-                return api.lcgs("lcg_hip_csr_ax", None, m, b, nloc, p, A, *ws)
-            return api.lcg_solver("lcg_hip_csr_ax", None, m, b, nloc, p, A, api.LCG_BICGSTAB)
+                return api.lcgs("lcg_hip_csr_ax", None, m, b, self.nloc, p, A, *ws)
+            return api.lcg_solver("lcg_hip_csr_ax", None, m, b, self.nloc, p, A, api.LCG_BICGSTAB)
 
         def timed(self, steps, reps, events):
             """`reps` timed K-step solves.  Returns (times [s, max over ranks], ax_us, ax_calls) of the median run."""
@@ -362,9 +391,10 @@ def main():
 def variants(args, System, S, lib, api, n, spmv_bytes, iteration_bytes):
     """The same K-step CG on each column pattern of the family (three repetitions, median): it/s, A.x time and its
     fraction of the 8 TB/s peak on ALGORITHMIC bytes, the kernel that ran, and the same solution check.  `mixed_rows`: 80 % of the
-    rows constant diagonals, 20 % scrambled -- multiplied range by range (the kernel string names the ranges)."""
+    rows constant diagonals, 20 % scrambled -- multiplied range by range (the kernel string names the ranges); `stencil27`: a real
+    27-point stencil on a cubic grid of ~0.8 x --rows points (run blocks + template blocks)."""
     res = {}
-    for pattern in ("constant_diagonals", "row_random_band", "scrambled", "mixed_rows"):
+    for pattern in ("constant_diagonals", "row_random_band", "scrambled", "mixed_rows", "stencil27"):
         if pattern == S.pattern:
             V, own = S, False
         else:
@@ -374,10 +404,10 @@ def variants(args, System, S, lib, api, n, spmv_bytes, iteration_bytes):
         check = V.guard() if own else None
         times, ax_us, ax_calls = V.timed(args.steps, 3, 1)
         med = sorted(times)[len(times) // 2]
-        byts = spmv_bytes(n, V.nnz)
-        entry = {"it_per_s": args.steps / med, "ax_us": ax_us, "frac": byts / (ax_us * 1e-6) / 1e9 / HBM_PEAK_GBS if ax_us > 0 else None,
+        byts = spmv_bytes(V.n, V.nnz)
+        entry = {"rows": V.n, "it_per_s": args.steps / med, "ax_us": ax_us, "frac": byts / (ax_us * 1e-6) / 1e9 / HBM_PEAK_GBS if ax_us > 0 else None,
                  "algorithmic_GBs": byts / (ax_us * 1e-6) / 1e9 if ax_us > 0 else None, "nnz": V.nnz,
-                 "whole_iteration_algorithmic_GBs": iteration_bytes(V.nnz) / (med / args.steps) / 1e9,
+                 "whole_iteration_algorithmic_GBs": (AX_PER_IT[args.solver] * byts + 8 * BLAS1_WORDS[args.solver] * V.n) / (med / args.steps) / 1e9,
                  "kernel": lib.lcg_hip_csr_last_kernel(V.A.h).decode()}
         entry.update(physical_fractions(lib, V.A, ax_us, pmc_traffic(pattern, entry["kernel"], V.nnz)[0], False))
         if check:

@@ -77,7 +77,7 @@ def test_one_rank_communicator_reproduces_unsharded_run(mode):
     assert forced["value"] > 0 and forced["timed_repetitions"] == 5 and forced["value_min"] <= forced["value"] <= forced["value_max"]
     # the unsharded line names its workload for what it is and carries the three column patterns
     assert "constant diagonals" in plain["config"]["workload"] and plain["roofline"]["traffic_source"]
-    assert set(plain["variants"]) == {"constant_diagonals", "row_random_band", "scrambled", "mixed_rows"}
+    assert set(plain["variants"]) == {"constant_diagonals", "row_random_band", "scrambled", "mixed_rows", "stencil27"}
     assert all(v["it_per_s"] > 0 and 0 < v["frac"] < 1 for v in plain["variants"].values())
 
 
