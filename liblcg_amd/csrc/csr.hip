@@ -826,7 +826,21 @@ __device__ __forceinline__ double run1_block(int b, int wv, int n, int LP, const
         const int D = -bs - TPL_CODE;
         const int *tplp = pcols + 4 * (long)po;
         const unsigned mask = live ? reinterpret_cast<const unsigned *>(tplp + ((D + 3) & ~3))[lane] : 0u;
-        const int rs = live ? rowptr[row0 + lane] : 0;
+        const int rs = live ? rowptr[row0 + lane] - s : 0;     // this lane's row in the block's values
+        // the block's values, coalesced, into the wavefront's piece of LDS as they lie in memory (64 x LP doubles hold them: LP >= the
+        // longest row); read from the rows directly -- a stride of one row per lane -- every batch re-fetched the rows' lines
+        double *mine = wlds + (size_t)wv * 64 * LP;
+        const int tot = rowptr[row0 + nrows] - s;
+        for (int i0 = 0; i0 < tot; i0 += NB * 64) {
+            double v[NB];
+#pragma unroll
+            for (int q = 0; q < NB; q++) { const int i = i0 + q * 64 + lane; v[q] = val[s + (i < tot ? i : 0)]; }
+#pragma unroll
+            for (int q = 0; q < NB; q++) { const int i = i0 + q * 64 + lane; if (i < tot) mine[i] = v[q]; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int k0 = 0; k0 < D; k0 += NB) {
             double a[NB], xv[NB]; int e[NB]; bool ok[NB];
 #pragma unroll
@@ -835,9 +849,10 @@ __device__ __forceinline__ double run1_block(int b, int wv, int n, int LP, const
                 const int off = tplp[k < D ? k : 0];        // scalar load
                 ok[q] = k < D && ((mask >> (k & 31)) & 1u);
                 e[q] = __popc(mask & ((1u << (k & 31)) - 1u));
-                a[q] = val[ok[q] ? rs + e[q] : 0];
                 xv[q] = x[ok[q] ? off + lane : 0];
             }
+#pragma unroll
+            for (int q = 0; q < NB; q++) a[q] = ok[q] ? mine[rs + e[q]] : 0.0;
 #pragma unroll
             for (int q = 0; q < NB; q++) {
                 if (T == 1) acc[0] = ok[q] ? fma(a[q], xv[q], acc[0]) : acc[0];
@@ -1071,6 +1086,8 @@ static double span_threshold()
 }
 
 static bool diag_like_measured(const CsrPart &P, hipStream_t s);     // (below)
+static bool line_ratio_measured(const CsrPart &P, hipStream_t s);
+static double line_ratio_threshold();
 
 // true when P's products go through the binned format (plan built here on first use)
 static bool binned_chosen(const CsrPart &P, hipStream_t s)
@@ -1102,6 +1119,9 @@ static bool binned_chosen(const CsrPart &P, hipStream_t s)
         // x for the row-block kernels, whatever the distance between the diagonals
         if (diag_like_measured(P, s) && P.diag_like > 0.5) {
             P.bn_state = -1; P.bn_why = "automatic mode: the columns run along diagonals (the row-block kernels gather contiguously)"; return false;
+        }
+        if (line_ratio_measured(P, s) && P.line_ratio < line_ratio_threshold()) {
+            P.bn_state = -1; P.bn_why = "automatic mode: neighbouring rows share their cache lines of x (block-structured)"; return false;
         }
     }
     const int rc = binned_ready(P, s);      // sets bn_state
@@ -1142,6 +1162,56 @@ static bool diag_like_measured(const CsrPart &P, hipStream_t s)
     return true;
 }
 
+// How many DIFFERENT 128-byte lines of x the entries of a 64-row block touch, per entry (1 = every gather a line of its own; a
+// stencil with several unknowns per grid point ~0.03: its rows share their lines).  This -- not whether the columns advance by one
+// per row -- is what decides whether the row-block kernels crawl: they fetch x by the line.  One wavefront per block marks the
+// lines in a 16384-bit table in LDS (hashed) and corrects the count for collisions (linear counting).
+__global__ __launch_bounds__(64) void k_line_ratio(int n, const int *__restrict__ rowptr, const int *__restrict__ col, double *sums)
+{
+    constexpr int M = 16384;
+    __shared__ unsigned bits[M / 32];
+    const long row0 = (long)blockIdx.x * PK_R;
+    const int r1 = (int)min((long)n, row0 + PK_R);
+    const int s = rowptr[row0], e = rowptr[r1];
+    for (int i = threadIdx.x; i < M / 32; i += 64) bits[i] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int k = s + threadIdx.x; k < e; k += 64) {
+        const unsigned h = ((unsigned)(col[k] >> 4) * 2654435761u) >> 18;       // 14 bits
+        atomicOr(&bits[h >> 5], 1u << (h & 31));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    int c = 0;
+    for (int i = threadIdx.x; i < M / 32; i += 64) c += __popc(bits[i]);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if (threadIdx.x == 0 && e > s) {
+        const double f = (double)c / M;
+        const double est = f < 0.999 ? -(double)M * log(1.0 - f) : (double)(e - s);
+        atomicAdd(sums, fmin(est, (double)(e - s)));
+        atomicAdd(sums + 1, (double)(e - s));
+    }
+}
+
+// P.line_ratio (measured once): false when the measurement failed
+static bool line_ratio_measured(const CsrPart &P, hipStream_t s)
+{
+    if (P.line_ratio >= 0.0) return true;
+    double *d = nullptr, h[2] = {0.0, 0.0};
+    bool ok = hipMalloc(&d, sizeof h) == hipSuccess && hipMemsetAsync(d, 0, sizeof h, s) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_line_ratio, dim3((P.n_rows + PK_R - 1) / PK_R), dim3(64), 0, s, P.n_rows, P.rowptr, P.col, d);
+        ok = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    }
+    if (d) hipFree(d);
+    if (!ok) { (void)hipGetLastError(); return false; }
+    P.line_ratio = h[1] > 0.0 ? h[0] / h[1] : 0.0;
+    return true;
+}
+static double line_ratio_threshold()
+{   // LCG_HIP_LINE_RATIO: least share of gathers that have a line of their own for the tiled / binned products to be considered
+    static const double v = [] { const char *e = std::getenv("LCG_HIP_LINE_RATIO"); return e ? atof(e) : 0.5; }();
+    return v;
+}
+
 static double tiled_fill_threshold()
 {
     static const double fill = [] { const char *e = std::getenv("LCG_HIP_TILED_FILL"); return e ? atof(e) : 700.0; }();
@@ -1160,6 +1230,10 @@ static bool tiled_chosen(const CsrPart &P, hipStream_t s)
     if (mode < 0) {
         if (!diag_like_measured(P, s)) { P.tl_state = -1; return false; }
         if (P.diag_like > 0.5) { P.tl_state = -1; P.tl_why = "automatic mode: the columns run along diagonals (the row-block kernels gather contiguously)"; return false; }
+        if (line_ratio_measured(P, s) && P.line_ratio < line_ratio_threshold()) {
+            P.tl_state = -1; P.tl_why = "automatic mode: neighbouring rows share their cache lines of x (block-structured: the row-block kernels fetch few lines per entry)";
+            return false;
+        }
         // least mean number of entries per (workgroup of 8192 rows, tile of 2048 columns) pair.  Measured at N = 1e7, 33 per row (round 3):
         // W = 524288, 1052 per pair: tiled 1.01-1.17 ms, binned 1.70; W = 1048576, 527 per pair: tiled 1.96 ms, binned 1.72
         min_fill = tiled_fill_threshold();

@@ -214,6 +214,7 @@ struct CsrPart {
     mutable void *bn_plan = nullptr;
     mutable const char *bn_why = "not tried";   // why the plan is (not) there
     mutable double mean_span = -1.0;    // mean column span of a 64-row block (-1 = not measured)
+    mutable double line_ratio = -1.0;   // distinct 128-byte lines of x per entry of a 64-row block (-1 = not measured; csr.hip: k_line_ratio)
     mutable double diag_like = -1.0;    // fraction of entries whose column is one more than the entry above them (-1 = not measured)
     // one-pass "tiled" product for row-random bands (csr_tiled.hip), plan built on first use
     mutable int tl_mode = -1;      // -1 auto, 0 never, 1 whenever eligible

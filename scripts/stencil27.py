@@ -17,6 +17,7 @@ from liblcg_amd import _lib, api
 lib = _lib.load(); assert lib.lcg_hip_init(0) == 0
 nx, ny, nz = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (200, 200, 200)
 points = int(sys.argv[4]) if len(sys.argv) >= 5 else 27        # 27 (full cube) or 7 (faces only)
+dof = int(sys.argv[5]) if len(sys.argv) >= 6 else 1            # unknowns per grid point (full dof x dof coupling blocks)
 n = nx * ny * nz
 dev = "cuda"
 idx = torch.arange(n, device=dev, dtype=torch.int64).reshape(nz, ny, nx)
@@ -31,6 +32,14 @@ for dz in (-1, 0, 1):
             rows.append(src); cols.append(dst)
             vals.append(torch.full((src.numel(),), float(points) if (dx, dy, dz) == (0, 0, 0) else -1.0, device=dev, dtype=torch.float64))
 r = torch.cat(rows); c = torch.cat(cols); v = torch.cat(vals)
+if dof > 1:         # every node coupling becomes a dof x dof block (values scaled so that the diagonal still dominates)
+    a = torch.arange(dof, device=dev, dtype=torch.int64)
+    r = (r[:, None, None] * dof + a[None, :, None]).expand(-1, dof, dof).reshape(-1)
+    c = (c[:, None, None] * dof + a[None, None, :]).expand(-1, dof, dof).reshape(-1)
+    v = v[:, None, None].expand(-1, dof, dof).reshape(-1).clone()
+    off = (r % dof) != (c % dof)
+    v[off] = v[off] / (2.0 * dof)
+    n = n * dof
 order = torch.argsort(r * n + c)
 r, c, v = r[order], c[order], v[order]
 rp = torch.zeros(n + 1, dtype=torch.int64, device=dev); rp[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
@@ -55,7 +64,7 @@ api.synchronize()
 t = (time.perf_counter() - t0) / reps
 byts = 12 * nnz + 4 * (n + 1) + 16 * n
 runs = lib.lcg_hip_csr_packed_runs(A.h, None)
-print(f"{points}-point stencil {nx}x{ny}x{nz}: rows {n}, entries {nnz}; kernel: {lib.lcg_hip_csr_last_kernel(A.h).decode()} ({runs} run blocks of {(n + 63) // 64})")
+print(f"{points}-point stencil {nx}x{ny}x{nz} x {dof} dof: rows {n}, entries {nnz}; kernel: {lib.lcg_hip_csr_last_kernel(A.h).decode()} ({runs} run blocks of {(n + 63) // 64})")
 print(f"A.x {t * 1e6:.1f} us = {byts / t / 1e9:.0f} GB/s algorithmic = {byts / t / 8e12:.3f} of 8 TB/s; must move {lib.lcg_hip_csr_last_traffic_model(A.h) / t / 8e12:.3f}; first call {first * 1e3:.1f} ms")
 xt = torch.rand(n, dtype=torch.float64, device=dev); b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
 m = torch.zeros_like(xt)
