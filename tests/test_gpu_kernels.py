@@ -691,3 +691,33 @@ def test_near_the_int32_limit(api, pattern):
     true_res = (Ax - b).norm().item() / n
     assert true_res <= 1.05e-10 and abs(true_res - info.residual) <= 0.05 * info.residual
     A.destroy()
+
+
+def test_block_structured_matrices_stay_with_the_row_block_kernels(api, port):
+    """A stencil with several unknowns per grid point: consecutive rows of one point share all their columns, so the columns do
+    NOT advance by one per row (diag-like share ~ 0) -- yet the rows of a 64-row block touch few different cache lines of x
+    (k_line_ratio), and that is what the row-block kernels need.  The automatic choice must not take the tiled (nor the binned)
+    product for it (1289 vs 645 us on the 27-point x 3 stencil of 3M rows), must say why, and the product must meet the oracle's."""
+    import scipy.sparse as sp
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    for dims, reach, faces, dof in (((60, 60, 60), 1, True, 3), ((52, 52, 52), 1, False, 2)):
+        n0, rp0, ci0 = _stencil(dims, reach, faces)
+        S = sp.csr_matrix((np.ones(len(ci0)), ci0, rp0), shape=(n0, n0))
+        B = sp.kron(S, np.ones((dof, dof)), format="csr")
+        B.sort_indices()
+        n = n0 * dof
+        rp, ci = B.indptr.astype(np.int32), B.indices.astype(np.int32)
+        assert len(ci) >= (1 << 22)                                 # the automatic choice considers its big-matrix families
+        val = rng.standard_normal(len(ci)); x = rng.standard_normal(n)
+        A = api.CsrMatrix.from_csr(rp, ci, val)
+        xd = torch.from_numpy(x).cuda(); y = torch.empty_like(xd)
+        A.spmv(xd, y); api.synchronize()
+        name = lib.lcg_hip_csr_last_kernel(A.h).decode()
+        assert name.startswith(("k_spmv_lds", "k_spmv_run1")) and "k_tile" not in name and "k_bin" not in name, (dims, dof, name)
+        assert "share their cache lines" in lib.lcg_hip_csr_tiled_status(A.h).decode(), lib.lcg_hip_csr_tiled_status(A.h)
+        ref = port.csr_matvec(rp, ci, val, x)
+        bound = port.csr_matvec(rp, ci, np.abs(val), np.abs(x))
+        assert float(np.max(np.abs(y.cpu().numpy() - ref) / bound)) <= 1e-13, (dims, dof, name)
+        A.destroy()
