@@ -225,7 +225,9 @@ int64_t lcg_hip_csr_packed_templates(lcg_hip_csr_t A);
  * 2048 rows, ds_add_f64) -- 28.5 streamed bytes per entry instead of 12 + a cache line per gather.  The plan
  * (re-ordered copy of the matrix: +26.5 B per entry) is built on the device at the first product.
  * mode: -1 automatic (real matrices of >= 4M entries and >= 1M columns whose 64-row blocks span on average
- * >= 2^20 columns; LCG_HIP_BINNED_SPAN changes that threshold), 0 never (frees the plan), 1 whenever eligible.
+ * >= 2^20 columns -- LCG_HIP_BINNED_SPAN changes that threshold --, whose columns do not run along diagonals and
+ * whose gathers mostly have a cache line of x of their own -- LCG_HIP_LINE_RATIO, default 0.5: block-structured
+ * matrices stay with the row-block kernels), 0 never (frees the plan), 1 whenever eligible.
  * LCG_HIP_BINNED=0/1 overrides for the whole process.  y differs from the row-block kernels' y in the last
  * bits (products are rounded before the add); on gfx950 it is bit-identical from call to call and from plan to plan
  * (lanes of one ds_add_f64 that meet in a row are serialised by the LDS in lane order: verified by test, not an ISA promise).
@@ -238,8 +240,8 @@ int lcg_hip_csr_set_binned(lcg_hip_csr_t A, int mode);
  * walks the column tiles they touch (2048 columns; a loader wavefront copies the next tile of x into LDS by LDS-DMA while
  * eight consumer wavefronts stream the rows' entries of the current one: 2 KB per step of 192 entries = values + three
  * 21-bit (row, column) pairs per 64-bit word, 10.67 B per entry where CSR has 12).  mode: -1 automatic (real matrices of
- * >= 4M entries whose columns do not run along diagonals and whose (workgroup, tile) pairs hold >= 700 entries on
- * average: LCG_HIP_TILED_FILL), 0 never (frees the plan), 1 whenever eligible; LCG_HIP_TILED=0/1 overrides for the
+ * >= 4M entries whose columns do not run along diagonals, whose gathers mostly have a cache line of x of their own
+ * (LCG_HIP_LINE_RATIO) and whose (workgroup, tile) pairs hold >= 700 entries on average: LCG_HIP_TILED_FILL), 0 never (frees the plan), 1 whenever eligible; LCG_HIP_TILED=0/1 overrides for the
  * process.  Same last-bit deviation from the row-block kernels as the binned product; y is bit-identical from call to
  * call and from plan to plan ON gfx950 (a row is summed by one wavefront in stream order; lanes of one ds_add_f64 that meet
  * in a row are serialised by the LDS in lane order -- verified by tests/test_gpu_binned.py, not promised by the ISA). */
