@@ -122,13 +122,14 @@ int    lcg_hip_last_finisher_steps(void);
 /* The solvers keep their temporaries (the reference allocates and frees them per call, lcg.cpp:158-166,266-271) for the
  * next solve; this gives the idle ones back to the device. */
 int    lcg_hip_trim(void);
-/* How plain CG (LCG_CG, lcg.cpp:143-274) is scheduled.  LCG_HIP_CG_CLASSIC: the reference's own
+/* How plain CG (LCG_CG, lcg.cpp:143-274) -- and PCG with the built-in Jacobi (lpcg, lcg.cpp:293-434: the same rearrangement
+ * with u = M^-1 r, w = A u and u.r, w.u in the one reduction) -- is scheduled.  LCG_HIP_CG_CLASSIC: the reference's own
  * recurrence, two reductions per iteration (d.Ad, then m.m/g.g).  LCG_HIP_CG_ONE_REDUCTION: the
  * Chronopoulos-Gear rearrangement of the same recurrence -- w = A.g is applied to the gradient,
  * A.d follows from Ad = beta Ad - w, and g.g, g.w, m.m share ONE reduction (one RCCL all-reduce
  * per iteration instead of two); same iterates in exact arithmetic, same stop rule and counts.
- * LCG_HIP_CG_AUTO (default): one-reduction when the rows are sharded and, on one GPU, for systems of fewer than 2^17 rows
- * (an iteration is then a chain of kernel latencies: two launches instead of three) unless A.x or M is a callback of the
+ * LCG_HIP_CG_AUTO (default): one-reduction when the rows are sharded and, on one GPU, for systems of fewer than 2^20 rows
+ * (a launch then costs more than the one word per row the rearrangement moves in addition: two launches instead of three) unless A.x or M is a callback of the
  * caller's own -- such a callback sees the reference's sequence of calls (the rearrangement makes one product more before the first
  * stop test); classic otherwise.  tests/test_gpu_solvers.py::test_cg_schedules_on_an_ill_conditioned_system holds both schedules
  * to the oracle's classic loop on a system of condition number 3.6e6 (iteration count, true residual, monitored = true). */

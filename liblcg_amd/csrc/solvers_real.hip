@@ -21,6 +21,10 @@ namespace lcgh {
 
 // DevState::s slots shared by the real solvers
 // (S_AK .. S_G2, clamp1: devcommon.hpp)
+// LCG_HIP_CG_AUTO takes the one-reduction arrangements (CG, PCG + built-in Jacobi) on one GPU below this many rows: one launch
+// less per iteration against one word per row more -- measured on the 5-point Laplacian: 11.2 vs 13.9 us at 1e5 rows, 30.0 vs 31.4
+// at 1e6, 106.9 vs 103.5 at 4e6 (scripts/cg_schedules.py)
+constexpr int CG1_AUTO_ROWS = 1 << 20;
 
 
 // ---- generic passes -------------------------------------------------------------------------
@@ -240,6 +244,54 @@ struct OpPcgDir {       // d = z + b d                                    lcg.cp
     template <class T> __device__ void apply(long i, double *) { st_(d, i, vadd(ld<T>(z, i), bk * ld<T>(d, i))); }
 };
 
+// PCG with the built-in Jacobi in the one-reduction (Chronopoulos-Gear) arrangement -- what plain CG's OpCg1UpdateSums is to
+// lcg.cpp:206-264, this is to lpcg (lcg.cpp:361-423): with u = M^-1 r and w = A u,
+//     d = u + b d;  Ad = w + b Ad;  m += a d;  r -= a Ad;  u = invdiag r          (one pass, leaving m.m, r.r, u.r and the NaN count)
+//     w = A u  carrying  w.u                                                      (the product)
+//     b' = u.r / (u.r)_old;  a' = u.r / (w.u - b' u.r / a)                         (the one scalar step)
+// Same iterates as lpcg in exact arithmetic (d.Ad = w.u - b u.r / a_old), same stop rule on r.r / m.m, one reduction per iteration
+// and two launches instead of three.  Per row 12 words, like the fused classic form.
+struct OpPcg1UpdateSums {
+    static constexpr int NR = 5, SKIP = SKIP_DONE;      // sums 0 m.m, 1 r.r, 2 u.r, 3 NaN; 4 = w.u comes with the product
+    DevState *st; double *m, *r, *z, *d, *Ad; const double *w, *invdiag; double ak, bk;
+    __device__ void prep() { ak = st->s[S_AK]; bk = st->s[S_BK]; }
+    template <class T> __device__ void apply(long i, double *acc)
+    {
+        const T dv = vadd(ld<T>(z, i), bk * ld<T>(d, i));
+        const T sv = vadd(ld<T>(w, i), bk * ld<T>(Ad, i));
+        st_(d, i, dv); st_(Ad, i, sv);
+        const T mv = vadd(ld<T>(m, i), ak * dv);
+        const T rv = vsub(ld<T>(r, i), ak * sv);
+        const T zv = vmul(ld<T>(invdiag, i), rv);
+        st_(m, i, mv); st_(r, i, rv); st_(z, i, zv);
+        acc[0] += dotp(mv, mv); acc[1] += dotp(rv, rv); acc[2] += dotp(zv, rv); acc[3] += nanflag(mv);
+    }
+};
+struct FinPcg1Close {   // the only scalar step of a body (FinCg1Close with rho = u.r and the stop rule on r.r)
+    static constexpr int NR = 5;
+    __device__ void operator()(DevState *st, const double *sum) const
+    {
+        st->it++;
+        if (!st->done) {
+            st->s[S_M2] = clamp1(sum[0]);
+            if (sum[3] > 0.0 || sum[0] != sum[0]) {         // lcg.cpp:404-410
+                st->t++;
+                st->done = 1; st->status = ST_NAN;
+            } else {
+                const double rho_new = sum[2];
+                const double bk = rho_new / st->s[S_RHO];                       // lcg.cpp:415
+                st->s[S_AK] = rho_new / (sum[4] - bk * rho_new / st->s[S_AK]);  // lcg.cpp:390 with d.Ad as above
+                st->s[S_BK] = bk;
+                st->s[S_RHO] = rho_new;
+                st->s[S_G2] = sum[1];
+                st->t++;
+                stop_rule(st, sum[1], st->s[S_M2]);
+            }
+        }
+        publish(st);
+    }
+};
+
 // ---- CGS / BiCGStab ---------------------------------------------------------------------------
 template <bool WITH_U>
 struct OpShadowInit {   // p = (u =) r0 = r = B - Ax; m.m, r.r, r.r0      lcg.cpp:480-497 / 650-667
@@ -402,11 +454,11 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
     TRY(k.drv.scal(FinInit{}));
     const uintptr_t a_upd = al(m) | al(g) | al(d) | al(Ad);
     // AUTO: the one-reduction schedule when the rows are sharded (one all-reduce per iteration) and on one GPU for systems so
-    // small that an iteration is a chain of kernel latencies (< 2^17 rows): three launches per iteration instead of four
+    // small that a launch costs more than a word per row (< 2^20 rows): two launches per iteration instead of three
     // (a callback of the caller's own keeps the reference's recurrence and with it the reference's sequence of callback calls:
     //  the one-reduction arrangement makes one product more before the first stop test)
     const bool one_reduction = c.cg_schedule == LCG_HIP_CG_ONE_REDUCTION ||
-                               (c.cg_schedule == LCG_HIP_CG_AUTO && (comm_active() || (n < (1 << 17) && !k.drv.user_cb)));
+                               (c.cg_schedule == LCG_HIP_CG_AUTO && (comm_active() || (n < CG1_AUTO_ROWS && !k.drv.user_cb)));
     if (one_reduction) {
         double *w; TRY(ws.get(w, nullptr, sizeof(double) * n));
         bool fused; TRY(k.ax_dot(g, w, g, false, 0, &fused));
@@ -517,6 +569,48 @@ static int solve_pcg(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pf
     TRY(k.drv.vec(OpPcgInit2{st, z, m, r, d}, al(z) | al(m) | al(r) | al(d)));   // :325-339
     TRY(k.drv.scal(FinInit{}));
     const uintptr_t a_all = al(m) | al(r) | al(z) | al(d) | al(Ad) | al(invdiag);
+    const bool one_reduction = invdiag != nullptr &&
+                               (c.cg_schedule == LCG_HIP_CG_ONE_REDUCTION ||
+                                (c.cg_schedule == LCG_HIP_CG_AUTO && (comm_active() || (n < CG1_AUTO_ROWS && !k.drv.user_cb))));
+    if (one_reduction) {
+        double *w; TRY(ws.get(w, nullptr, sizeof(double) * n));
+        {   // w = A u_0 and w.u_0 (sum 0): a_0 = u.r / w.u, b_0 = 0
+            bool f; TRY(k.ax_dot(z, w, z, false, 0, &f));
+            if (!f) TRY(k.drv.vec(OpDot1{st, z, w}, al(z) | al(w)));
+        }
+        auto product = [&]() -> int {       // w = A u carrying w.u as sum 4 (or a pass of its own where the product cannot)
+            bool f; TRY(k.ax_dot(z, w, z, false, 4, &f));
+            if (!f) TRY(k.drv.vec_rows(OpDot1{st, z, w}, 4, al(z) | al(w)));
+            return 0;
+        };
+        auto last_body = [&]() { return p.max_iterations > 0 && k.drv.enq + 1 >= p.max_iterations; };
+        const OpPcg1UpdateSums upd{st, m, r, z, d, Ad, w, invdiag, 0.0, 0.0};
+        int rc;
+        if (Pfp == nullptr && !comm_active()) {
+            // the step that closes body k rides in the update of body k + 1 (FinCg1Start -- a_0, b_0 -- in front of the first): TWO
+            // launches per body; the last body is closed by the tail
+            bool first = true;
+            k.drv.tail = [&]() -> int { return first ? k.drv.scal(FinCg1Start{}) : k.drv.scal(FinPcg1Close{}); };
+            rc = k.run_loop([&]() -> int {
+                if (first) { TRY(k.drv.vecf(FinCg1Start{}, upd, a_all | al(w))); first = false; }
+                else TRY(k.drv.vecf(FinPcg1Close{}, upd, a_all | al(w)));
+                if (last_body()) return 0;
+                return product();
+            });
+            k.drv.tail = nullptr;
+        } else {
+            // progress callback (the state is read after every body) or sharded rows (the step is where the ranks' sums meet)
+            TRY(k.drv.scal(FinCg1Start{}));
+            rc = k.run_loop([&]() -> int {
+                TRY(k.drv.vec(upd, a_all | al(w)));
+                if (!last_body()) TRY(product());
+                TRY(k.drv.scal(FinPcg1Close{}));
+                return 0;
+            });
+        }
+        int rc2 = hb.close(c.stream);
+        return rc <= -2000 ? rc : (rc2 ? rc2 : rc);
+    }
     int rc = k.run_loop([&]() -> int {
         bool f; TRY(k.ax_dot(d, Ad, d, false, 0, &f));                          // :387
         if (!f) TRY(k.drv.vec(OpDot1{st, d, Ad}, al(d) | al(Ad)));               // :389

@@ -254,6 +254,33 @@ def test_cg_schedules_on_an_ill_conditioned_system(api, port):
             # the recurred g.g is what the stop rule sees; it may not flatter the answer
             assert true_res <= 4.0 * eps and abs(true_res - info.residual) <= 0.5 * info.residual + 1e-14, tag + (true_res, info.residual)
             assert np.linalg.norm(x - xt) <= 3.0 * np.linalg.norm(ref["x"] - xt), tag
+        # PCG with the built-in Jacobi has the same two arrangements (lpcg, lcg.cpp:361-423, and its one-reduction form); on a
+        # diagonal that is not constant, so that the preconditioner is not a mere scaling: D A D with D = diag(1 .. 3)
+        dg = 1.0 + 2.0 * rng.random(n)
+        v2 = v * dg[np.repeat(np.arange(n), np.diff(rp))] * dg[ci]
+        b2 = port.csr_matvec(rp, ci, v2, xt)
+        ref2 = port.solve(po.LCG_PCG, rp, ci, v2, b2, para=opara, jacobi=True)
+        dit2 = 0
+        for k in range(3):
+            alt = port.solve(po.LCG_PCG, rp, ci, v2, b2 * (1.0 + 1e-16 * np.random.default_rng(k).standard_normal(n)), para=opara, jacobi=True)
+            dit2 = max(dit2, abs(alt["iters"] - ref2["iters"]))
+        assert ref2["ret"] == 0 and ref2["iters"] > 1000
+        A2 = api.CsrMatrix.from_csr(rp, ci, v2); A2.build_jacobi()
+        bd2 = torch.from_numpy(b2).cuda()
+        for sched in (api.CG_AUTO, api.CG_CLASSIC, api.CG_ONE_REDUCTION):
+            api.set_cg_schedule(sched)
+            m = torch.zeros(n, dtype=torch.float64, device="cuda")
+            info = api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, bd2, n,
+                                                 api.lcg_default_parameters(epsilon=eps, abs_diff=0, max_iterations=20000), A2)
+            x = m.cpu().numpy()
+            tag = ("pcg", sched, info.ret, info.iterations, ref2["iters"], dit2)
+            assert info.ret == 0, tag
+            assert abs(info.iterations - ref2["iters"]) <= max(5, 3 * dit2, 0.03 * ref2["iters"]), tag
+            r = port.csr_matvec(rp, ci, v2, x) - b2
+            true_res = float(r @ r) / max(float(x @ x), 1.0)
+            assert true_res <= 4.0 * eps and abs(true_res - info.residual) <= 0.5 * info.residual + 1e-14, tag + (true_res, info.residual)
+            assert np.linalg.norm(x - xt) <= 3.0 * np.linalg.norm(ref2["x"] - xt), tag
+        A2.destroy()
     finally:
         api.set_cg_schedule(api.CG_AUTO)
     A.destroy()
