@@ -215,8 +215,8 @@ int lcg_hip_csr_set_packed(lcg_hip_csr_t A, int mode);
  * (0 before the first product built it, or when there are none); *blocks_out (may be NULL) = all blocks of 64 rows.
  * LCG_HIP_PACKED_RUNS=0 stores every block with its own columns. */
 int64_t lcg_hip_csr_packed_runs(lcg_hip_csr_t A, int64_t *blocks_out);
-/* Blocks of 64 rows the packed form stores as TEMPLATE blocks: every entry on one of <= 32 diagonals (those of the block's longest
- * row) and a 32-bit mask per row saying which of them the row has -- what a stencil's blocks look like where grid boundaries pass
+/* Blocks of 64 rows the packed form stores as TEMPLATE blocks: every entry on one of <= 64 diagonals (the union of the rows'), rows of
+ * <= 32 entries, and a 64-bit mask per row saying which diagonals the row has -- what a stencil's blocks look like where grid boundaries pass
  * through them.  Like run blocks they stream values only and are bit-identical to the plain row-block kernel.
  * LCG_HIP_PACKED_TEMPLATES=0 stores such blocks with packed columns (A/B runs).  No reference counterpart. */
 int64_t lcg_hip_csr_packed_templates(lcg_hip_csr_t A);

@@ -23,6 +23,7 @@
 //
 // Algorithmic bytes: 12*nnz + 4*(N+1) + 8*N (x) + 8*N (y), real.
 #include <algorithm>
+#include <type_traits>
 #include <cstring>
 #include <functional>
 #include <numeric>
@@ -309,11 +310,12 @@ constexpr int PK_SPAN = 1 << 21;
 // matrix edges.  Such a block needs no columns of its own beyond row 0's: column(row r, slot k) = column(row 0, slot k) + r.
 // It stores row 0's L columns as plain int32 (four per 16-byte group) and is marked by base[b] = -1 - L.
 // A TEMPLATE block (round 3): what a stencil's blocks look like where the grid's boundaries pass through them.  The rows do not
-// all hold the same entries any more, but every entry of the block lies on one of D <= 32 diagonals (column - row in block), the
-// ones of the block's longest row, and every row holds its entries in ascending column order.  Such a block stores the D offsets and one
-// 32-bit mask per row (which diagonals the row has) -- 23 groups of 16 bytes for a 27-point stencil instead of ~250 -- and is marked
-// by base[b] = -(1 << 30) - D.  Run blocks are the special case "all masks full"; they keep their own, cheaper, form.
-constexpr int TPL_MAXD = 32;
+// all hold the same entries any more, but every entry of the block lies on one of D <= 64 diagonals (column - row in block) -- the
+// union of its rows' --, no row holds more than 32 entries, and every row holds them in ascending column order.  Such a block stores the D
+// offsets and one 64-bit mask per row (which diagonals the row has) -- 39 groups of 16 bytes for a 27-point stencil instead of ~250 -- and is
+// marked by base[b] = -(1 << 30) - D.  (Stencils with several unknowns per grid point need the width: 7 neighbours x 3 unknowns lie on 35.)  Run blocks are the special case "all masks full"; they keep their own, cheaper, form.
+constexpr int TPL_MAXD = 64;         // diagonals of a template block (one bit each in a row's 64-bit mask)
+constexpr int TPL_MAXROW = 32;       // longest row of a template block (the packed kernel takes a row in ONE predicated batch of UNR * T >= 32 entries)
 constexpr int TPL_CODE = 1 << 30;       // base[b] = -TPL_CODE - D; ngroups[b] (before k_pk_groups) = -TPL_GRP - D
 constexpr int TPL_GRP = 1 << 20;
 
@@ -321,7 +323,7 @@ constexpr int TPL_GRP = 1 << 20;
 // lie on -- seeded with the longest row's, then completed by the rows that have others (a block that holds the last line of one
 // grid plane and the first line of the next has rows that miss DIFFERENT neighbours) -- and returns the lane's mask over them;
 // *bad when there are more than TPL_MAXD of them or a row's columns do not ascend.  tpl: TPL_MAXD + 1 ints of LDS, dcount: one.
-__device__ __forceinline__ unsigned tpl_row_mask(long row0, int r1, const int *__restrict__ rowptr, const int *__restrict__ col, int *tpl,
+__device__ __forceinline__ unsigned long long tpl_row_mask(long row0, int r1, const int *__restrict__ rowptr, const int *__restrict__ col, int *tpl,
                                                  int *dcount, int *D_out, bool *bad)
 {
     const int lane = threadIdx.x & 63;
@@ -342,13 +344,13 @@ __device__ __forceinline__ unsigned tpl_row_mask(long row0, int r1, const int *_
     best = __shfl(best, 0, 64); who = __shfl(who, 0, 64);
     *D_out = best;
     *bad = true;
-    if (best < 1 || best > TPL_MAXD) return 0u;
+    if (best < 1 || best > TPL_MAXROW) return 0ull;
     bool mine_bad = false;
     {   // columns must ascend strictly: entry e of a row is then the e-th set bit of its mask
         int prev = -0x7fffffff - 1;
         for (int k = 0; k < len; k++) { const int c = col[s + k]; if (c <= prev) mine_bad = true; prev = c; }
     }
-    if (__ballot(mine_bad)) return 0u;
+    if (__ballot(mine_bad)) return 0ull;
     if (lane == who) { for (int k = 0; k < len; k++) tpl[k] = col[s + k] - lane; *dcount = len; }
     wave_sync();
     auto find = [&](int o, int D) {     // index of o in tpl[0 .. D), or -1
@@ -376,13 +378,13 @@ __device__ __forceinline__ unsigned tpl_row_mask(long row0, int r1, const int *_
             *dcount = Dn;
         }
         wave_sync();
-        if (*dcount > TPL_MAXD) return 0u;
+        if (*dcount > TPL_MAXD) return 0ull;
     }
     const int D = *dcount;
     *D_out = D;
-    unsigned mask = 0u;
+    unsigned long long mask = 0ull;
     bool b = false;
-    for (int k = 0; k < len; k++) { const int p = find(col[s + k] - lane, D); if (p >= 0) mask |= 1u << p; else b = true; }
+    for (int k = 0; k < len; k++) { const int p = find(col[s + k] - lane, D); if (p >= 0) mask |= 1ull << p; else b = true; }
     *bad = __ballot(b) != 0ull;
     return mask;
 }
@@ -433,7 +435,9 @@ __global__ void k_pk_groups(int nb, int per, int *ngroups)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < nb) {
         const int g = ngroups[b];
-        ngroups[b] = g <= -TPL_GRP ? (-g - TPL_GRP + 3) / 4 + PK_R / 4 : (g < 0 ? (-g + 3) / 4 : (per > 0 ? (g + per - 1) / per : 0));
+        // (a template block: its D offsets, then a mask per row -- 32 bits wide up to 32 diagonals, 64 beyond)
+        ngroups[b] = g <= -TPL_GRP ? (-g - TPL_GRP + 3) / 4 + (-g - TPL_GRP <= 32 ? PK_R / 4 : PK_R / 2)
+                                   : (g < 0 ? (-g + 3) / 4 : (per > 0 ? (g + per - 1) / per : 0));
     }
 }
 
@@ -465,11 +469,12 @@ __global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const 
         __shared__ int tpl[TPL_MAXD + 1], dcount;
         if (threadIdx.x < 64) {
             int D; bool bad;
-            const unsigned m = tpl_row_mask(row0, r1, rowptr, col, tpl, &dcount, &D, &bad);
+            const unsigned long long m = tpl_row_mask(row0, r1, rowptr, col, tpl, &dcount, &D, &bad);
             int *dst = reinterpret_cast<int *>(packed + pofs[b]);
             const int Dp = (D + 3) & ~3;
             if ((int)threadIdx.x < Dp) dst[threadIdx.x] = (int)threadIdx.x < D ? tpl[threadIdx.x] : 0;
-            reinterpret_cast<unsigned *>(dst + Dp)[threadIdx.x] = m;
+            if (D <= 32) reinterpret_cast<unsigned *>(dst + Dp)[threadIdx.x] = (unsigned)m;
+            else reinterpret_cast<unsigned long long *>(dst + Dp)[threadIdx.x] = m;      // (Dp ints = whole 16-byte groups: aligned)
         }
         return;
     }
@@ -550,70 +555,84 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     if (DOT) uv = dp.u[(j0 == 0 && rl < nrows) ? row0 + rl : 0];     // requested ahead of the stream: hidden behind it
 
     if (bs <= -TPL_CODE) {
-        // TEMPLATE block (k_pk_meta): every entry lies on one of D <= 32 diagonals and every row says by a mask which of them it
+        // TEMPLATE block (k_pk_meta): every entry lies on one of D <= 64 diagonals and every row says by a mask which of them it
         // has.  As in a run block nothing but the values streams and the x gathers go out beside the value stream -- their
         // addresses come from the row's mask and the D offsets (held one per lane, fetched by a wavefront shuffle), not from staged
         // columns.  Entry e of a row is the e-th set bit of its mask (columns ascend); lane (row, j0) takes entries j0, j0 + T, ...
         // and the partial sums meet as in the general path: the same bits.
-        static_assert(UNR * T >= TPL_MAXD, "one predicated batch covers the longest row of a template block");
+        static_assert(UNR * T >= TPL_MAXROW, "one predicated batch covers the longest row of a template block");
         const int D = -bs - TPL_CODE;
         const int *tplp = reinterpret_cast<const int *>(packed + po);
-        const unsigned *mskp = reinterpret_cast<const unsigned *>(tplp + ((D + 3) & ~3));
+        const int *mskp = tplp + ((D + 3) & ~3);           // 64 masks: 32 bits wide up to 32 diagonals, 64 beyond
         const bool live = rl < nrows;
-        v2d pv[VR];
-#pragma unroll
-        for (int r = 0; r < VR; r++) {
-            const int u = 2 * (tid + r * VB);
-            pv[r] = *reinterpret_cast<const v2d *>(val + (long)bv + (u < cntv ? u : 0));
-        }
-        const unsigned mask = live ? mskp[rl] : 0u;
-        const int myoff = tplp[rl < D ? rl : 0];            // lane l < D of every wavefront holds offset l
-        const int rs = live ? rowptr[row0 + rl] - bv : 0;   // this lane's row in the staged values
-        const int len = __popc(mask);
-        const unsigned full = D >= 32 ? 0xffffffffu : ((1u << D) - 1u);
-        const bool dense = __ballot(live && mask != full) == 0ull;      // uniform: every live row has all D diagonals
-        double xv[UNR];
-#pragma unroll
-        for (int q = 0; q < UNR; q++) {
-            int e = j0 + q * T;
-            int slot = e;
-            if (!dense) {       // uniform: position of the e-th set bit of the mask (five halving steps)
-                unsigned m = mask; int pos = 0;
-#pragma unroll
-                for (int w = 16; w > 0; w >>= 1) {
-                    const int c = __popc(m & ((1u << w) - 1u));
-                    if (e >= c) { e -= c; pos += w; m >>= w; }
-                }
-                slot = pos;
-            }
-            const int off = __shfl(myoff, slot & 31, 64);
-            const bool ok = live && j0 + q * T < len;
-            xv[q] = x[ok ? rl + off : 0];       // (the offsets are row 0's columns, as in a run block: column = offset + row in block)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < VR; r++) {
-            const int u = 2 * (tid + r * VB);
-            if (u < cntv) *reinterpret_cast<v2d *>(sval + u) = pv[r];
-        }
-        __syncthreads();
-        double acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < UNR; q++) {
-            const int e = j0 + q * T;
-            acc = (live && e < len) ? fma(sval[rs + e], xv[q], acc) : acc;
-        }
-        __syncthreads();
-        sred[j0][rl] = acc;
-        __syncthreads();
         double vfin = 0.0;
-        if (j0 == 0 && live) {
-            double v = sred[0][rl];
+        // two instances of the same code, chosen by a scalar branch: WIDE (33 .. 64 diagonals) works on 64-bit masks, the other --
+        // every plain stencil -- on 32-bit ones (the wide arithmetic costs the narrow case 4-8 %, measured)
+        auto block = [&](auto wide_tag) {
+            constexpr bool WIDE = decltype(wide_tag)::value;
+            typedef typename std::conditional<WIDE, unsigned long long, unsigned>::type M;
+            // the small loads FIRST: the gathers wait for the mask, and a wait for a load issued behind the value stream is a wait
+            // for the value stream (vmcnt counts in order) -- two memory latencies per block instead of one
+            const M mask = live ? reinterpret_cast<const M *>(mskp)[rl] : (M)0;
+            const int myoff = tplp[rl < D ? rl : 0];            // lane l < D of every wavefront holds offset l
+            const int rs = (live ? rowptr[row0 + rl] : bv) - bv;    // this lane's row in the staged values
+            v2d pv[VR];
 #pragma unroll
-            for (int j = 1; j < T; j++) v += sred[j][rl];
-            y[row0 + rl] = v;
-            vfin = v;
-        }
+            for (int r = 0; r < VR; r++) {
+                const int u = 2 * (tid + r * VB);
+                pv[r] = *reinterpret_cast<const v2d *>(val + (long)bv + (u < cntv ? u : 0));
+            }
+            const int len = WIDE ? __popcll((unsigned long long)mask) : __popc((unsigned)mask);
+            const M full = D >= (WIDE ? 64 : 32) ? ~(M)0 : (((M)1 << D) - (M)1);
+            const bool dense = __ballot(live && mask != full) == 0ull;      // uniform: every live row has all D diagonals
+            double xv[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; q++) {
+                int e = j0 + q * T;
+                int slot = e;
+                if (!dense) {       // uniform: position of the e-th set bit of the mask (five halving steps; six on a wide mask)
+                    int pos = 0;
+                    unsigned m = (unsigned)mask;
+                    if (WIDE) {
+                        const int c = __popc(m);
+                        if (e >= c) { e -= c; pos = 32; m = (unsigned)((unsigned long long)mask >> 32); }
+                    }
+#pragma unroll
+                    for (int w = 16; w > 0; w >>= 1) {
+                        const int c = __popc(m & ((1u << w) - 1u));
+                        if (e >= c) { e -= c; pos += w; m >>= w; }
+                    }
+                    slot = pos;
+                }
+                const int off = __shfl(myoff, slot & 63, 64);
+                const bool ok = live && j0 + q * T < len;
+                xv[q] = x[ok ? rl + off : 0];       // (the offsets are row 0's columns, as in a run block: column = offset + row in block)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < VR; r++) {
+                const int u = 2 * (tid + r * VB);
+                if (u < cntv) *reinterpret_cast<v2d *>(sval + u) = pv[r];
+            }
+            __syncthreads();
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < UNR; q++) {
+                const int e = j0 + q * T;
+                acc = (live && e < len) ? fma(sval[rs + e], xv[q], acc) : acc;
+            }
+            __syncthreads();
+            sred[j0][rl] = acc;
+            __syncthreads();
+            if (j0 == 0 && live) {
+                double v = sred[0][rl];
+#pragma unroll
+                for (int j = 1; j < T; j++) v += sred[j][rl];
+                y[row0 + rl] = v;
+                vfin = v;
+            }
+        };
+        if (D > 32) block(std::true_type{}); else block(std::false_type{});
         if (DOT) ldsp_dot_tail(dp, bid, j0, vfin, uv);
         return;
     }
@@ -820,12 +839,16 @@ __device__ __forceinline__ double run1_block(int b, int wv, int n, int LP, const
 #pragma unroll
     for (int j = 0; j < T; j++) acc[j] = 0.0;
     if (bs <= -TPL_CODE) {
-        // TEMPLATE block (k_pk_meta): the block's entries lie on D <= 32 diagonals, a mask per row says which.  A uniform loop over
+        // TEMPLATE block (k_pk_meta): the block's entries lie on D <= 64 diagonals, a mask per row says which.  A uniform loop over
         // the diagonals: the offset is a scalar, the gather x[offset + lane] one run with holes, the row's value the
         // popcount-th of its entries -- no column is read.  Entry e goes to partial sum e mod T like everywhere: the same bits.
         const int D = -bs - TPL_CODE;
         const int *tplp = pcols + 4 * (long)po;
-        const unsigned mask = live ? reinterpret_cast<const unsigned *>(tplp + ((D + 3) & ~3))[lane] : 0u;
+        const bool wide = D > 32;       // uniform: 64-bit masks beyond 32 diagonals
+        unsigned long long mask = 0ull;
+        if (live) mask = wide ? reinterpret_cast<const unsigned long long *>(tplp + ((D + 3) & ~3))[lane]
+                              : (unsigned long long)reinterpret_cast<const unsigned *>(tplp + ((D + 3) & ~3))[lane];
+        const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
         const int rs = live ? rowptr[row0 + lane] - s : 0;     // this lane's row in the block's values
         // the block's values, coalesced, into the wavefront's piece of LDS as they lie in memory (64 x LP doubles hold them: LP >= the
         // longest row); read from the rows directly -- a stride of one row per lane -- every batch re-fetched the rows' lines
@@ -847,8 +870,10 @@ __device__ __forceinline__ double run1_block(int b, int wv, int n, int LP, const
             for (int q = 0; q < NB; q++) {
                 const int k = k0 + q;                       // uniform
                 const int off = tplp[k < D ? k : 0];        // scalar load
-                ok[q] = k < D && ((mask >> (k & 31)) & 1u);
-                e[q] = __popc(mask & ((1u << (k & 31)) - 1u));
+                // (k uniform: the half of the mask the bit lies in is a scalar choice)
+                const unsigned half = k < 32 ? mlo : mhi;
+                ok[q] = k < D && ((half >> (k & 31)) & 1u);
+                e[q] = __popc(half & ((1u << (k & 31)) - 1u)) + (k < 32 ? 0 : __popc(mlo));
                 xv[q] = x[ok[q] ? off + lane : 0];
             }
 #pragma unroll

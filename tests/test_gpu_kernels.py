@@ -166,11 +166,12 @@ def _stencil(dims, reach, faces=False):
 
 def test_template_blocks_of_the_packed_form(api, port):
     """Template blocks (csr.hip: k_pk_meta / the template path of k_spmv_ldsp): a block of 64 rows whose entries all lie on the
-    <= 32 diagonals of its longest row keeps those offsets and a mask per row -- the blocks of a stencil that grid boundaries
+    <= 64 diagonals keeps those offsets and a 64-bit mask per row -- the blocks of a stencil that grid boundaries
     pass through.  27-point stencils on grids whose lines are shorter than, equal to, and no multiple of the 64-row block, a
     5 x 5 stencil in 2D: every block must be a run or a template, y must equal the plain row-block kernel's bit for bit, the
     carried dot must agree with numpy, and with one row moved off the diagonals its block must fall back alone (more than 32
-    diagonals) or take the new diagonals in (the template is the union of the block's offsets)."""
+    diagonals) or take the new diagonals in (the template is the union of the block's offsets).  A 7-point stencil with three unknowns
+    per point (35 diagonals) needs the masks' full width."""
     from liblcg_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(27)
@@ -180,10 +181,11 @@ def test_template_blocks_of_the_packed_form(api, port):
         val = rng.standard_normal(len(ci)); x = rng.standard_normal(n)
         for broken in (False, True):
             c = ci.copy()
-            if broken:      # row 70: every entry one column further (still ascending): in 3D nine diagonals the block does not have -- 36 > 32
-                if n <= 71 or c[rp[71] - 1] + 1 >= n:
+            if broken:      # rows 70 .. 81: every entry 2, 4, .. 24 columns further (still ascending): diagonals the block does not have
+                if n <= 82 or c[rp[82] - 1] + 24 >= n:
                     continue
-                c[rp[70]:rp[71]] += 1
+                for j in range(12):
+                    c[rp[70 + j]:rp[71 + j]] += 2 * (j + 1)
             A = api.CsrMatrix.from_csr(rp, c, val)
             xd = torch.from_numpy(x).cuda()
             y0 = torch.empty(n, dtype=torch.float64, device="cuda"); y1 = torch.full_like(y0, 5.0)
@@ -195,15 +197,15 @@ def test_template_blocks_of_the_packed_form(api, port):
             name = lib.lcg_hip_csr_last_kernel(A.h).decode()
             runs = lib.lcg_hip_csr_packed_runs(A.h, C.byref(nblk)); tpls = lib.lcg_hip_csr_packed_templates(A.h)
             assert "k_spmv_ldsp" in name and "template blocks" in name, (dims, name)
-            # every block with at most 32 distinct offsets (column - row in block) is a run or a template; the others -- where the
-            # shifted row brings more diagonals than a mask has bits -- fall back to their packed columns, alone
+            # every block with at most 64 distinct offsets (column - row in block) is a run or a template; the others -- where the
+            # shifted rows bring more diagonals than a mask has bits -- fall back to their packed columns, alone
             lane = np.arange(n) % 64
             offs = c - np.repeat(lane, np.diff(rp))
             blk = np.repeat(np.arange(n) // 64, np.diff(rp))
             distinct = np.array([len(np.unique(offs[blk == b])) for b in range((n + 63) // 64)])
-            assert runs + tpls == int((distinct <= 32).sum()) and tpls > 0, (dims, broken, runs, tpls, nblk.value, distinct[:4])
-            if broken and dims == (9, 7, 5):
-                assert distinct[1] > 32 and runs + tpls == nblk.value - 1
+            assert runs + tpls == int((distinct <= 64).sum()) and tpls > 0, (dims, broken, runs, tpls, nblk.value, distinct[:4])
+            if broken and dims == (9, 7, 5):       # (here the shifted rows bring the block past 64 diagonals: it falls back, alone)
+                assert distinct[1] > 64 and runs + tpls == nblk.value - 1, distinct[:3]
             assert torch.equal(y0, y1), (dims, broken)
             ref = port.csr_matvec(rp, c, val, x)
             bound = port.csr_matvec(rp, c, np.abs(val), np.abs(x))
@@ -219,6 +221,39 @@ def test_template_blocks_of_the_packed_form(api, port):
             yu = float(ref @ u.cpu().numpy()); yy = float(ref @ ref)
             assert abs(sums[0] - yu) <= 1e-11 * float(np.abs(ref) @ np.abs(u.cpu().numpy())) and abs(sums[1] - yy) <= 1e-12 * yy
             A.destroy()
+
+
+def test_template_blocks_with_several_unknowns_per_point(api, port):
+    """7-point stencil x 4 unknowns (28 entries per row on 43 diagonals) and 9-point 2D x 3 (27 entries on 33): template blocks
+    need more than 32 mask bits; bit-equal to the plain kernel."""
+    import scipy.sparse as sp
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    nblk = C.c_int64()
+    for dims, reach, faces, dof in (((12, 11, 20), 1, True, 4), ((40, 70), 1, False, 3)):
+        n0, rp0, ci0 = _stencil(dims, reach, faces)
+        B = sp.kron(sp.csr_matrix((np.ones(len(ci0)), ci0, rp0), shape=(n0, n0)), np.ones((dof, dof)), format="csr"); B.sort_indices()
+        n = n0 * dof
+        rp, ci = B.indptr.astype(np.int32), B.indices.astype(np.int32)
+        val = rng.standard_normal(len(ci)); x = rng.standard_normal(n)
+        A = api.CsrMatrix.from_csr(rp, ci, val)
+        xd = torch.from_numpy(x).cuda()
+        y0 = torch.empty(n, dtype=torch.float64, device="cuda"); y1 = torch.full_like(y0, 5.0)
+        A.set_kernel(-64)
+        assert lib.lcg_hip_csr_set_packed(A.h, 0) == 0
+        A.spmv(xd, y0); api.synchronize()
+        assert lib.lcg_hip_csr_set_packed(A.h, 1) == 0
+        A.spmv(xd, y1); api.synchronize()
+        runs = lib.lcg_hip_csr_packed_runs(A.h, C.byref(nblk)); tpls = lib.lcg_hip_csr_packed_templates(A.h)
+        lane = np.arange(n) % 64
+        offs = ci - np.repeat(lane, np.diff(rp)); blk = np.repeat(np.arange(n) // 64, np.diff(rp))
+        distinct = np.array([len(np.unique(offs[blk == b])) for b in range((n + 63) // 64)])
+        assert distinct.max() > 32 and runs + tpls == int((distinct <= 64).sum()) == nblk.value, (dims, runs, tpls, nblk.value, distinct.max())
+        assert torch.equal(y0, y1), dims
+        ref = port.csr_matvec(rp, ci, val, x)
+        assert float(np.max(np.abs(y1.cpu().numpy() - ref) / port.csr_matvec(rp, ci, np.abs(val), np.abs(x)))) <= 1e-13
+        A.destroy()
 
 
 def test_short_row_runs_one_wavefront_per_block(api, port):
