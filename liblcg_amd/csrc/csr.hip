@@ -111,6 +111,11 @@ __device__ __forceinline__ V lds1_block(int bid, int n, const int *__restrict__ 
     const int rl = tid % R, j0 = tid / R;
     const int base = rowptr[row0] & ~3;
     const int cnt = rowptr[row0 + nrows] - base;
+    // this lane's row bounds, requested BEFORE the block's stream: behind the fence below they would be issued when the stream has
+    // arrived and cost the gather phase a memory latency of its own (vmcnt counts in order)
+    const int rsafe = rl < nrows ? rl : 0;              // (branch-free, like the stream loads below)
+    int rs = rowptr[row0 + rsafe], re = rowptr[row0 + rsafe + 1];
+    if (rl >= nrows) { rs = 0; re = 0; }
 
     v4i pc[NRND]; v2d pv[NRND * VU];
 #pragma unroll
@@ -136,8 +141,6 @@ __device__ __forceinline__ V lds1_block(int bid, int n, const int *__restrict__ 
             for (int q = 0; q < VU; q++) reinterpret_cast<v2d *>(sval + u)[q] = pv[r * VU + q];
         }
     }
-    int rs = 0, re = 0;
-    if (rl < nrows) { rs = rowptr[row0 + rl]; re = rowptr[row0 + rl + 1]; }
     __syncthreads();
     // lane (row rl, slot j0) takes entries rs+j0, rs+j0+T, ... of its row
     V acc = vzero(V());
@@ -692,6 +695,9 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
         return;
     }
 
+    const int rsafe = rl < nrows ? rl : 0;              // (requested before the stream, branch-free: see lds1_block)
+    int rs = rowptr[row0 + rsafe], re = rowptr[row0 + rsafe + 1];
+    if (rl >= nrows) { rs = 0; re = 0; }
     v4i pg[GR]; v2d pv[VR];
 #pragma unroll
     for (int r = 0; r < GR; r++) {
@@ -728,8 +734,6 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
         const int u = 2 * (tid + r * VB);
         if (u < cntv) *reinterpret_cast<v2d *>(sval + u) = pv[r];
     }
-    int rs = 0, re = 0;
-    if (rl < nrows) { rs = rowptr[row0 + rl]; re = rowptr[row0 + rl + 1]; }
     __syncthreads();
     double acc = 0.0;
     int k = rs + j0;
