@@ -1652,20 +1652,51 @@ int spmv_launch_push(const CsrPart &P, bool is_complex, int variant, double mean
 // shard's product anyway): *nofold = number of per-block sums waiting in P.dot_part, nothing is written to `part`.
 // fp != nullptr with fp->fin set (and the fold made here, y.u only): the fold's last block also closes the iteration body
 // (devcommon.hpp: finish_body); fp->pc.ax_n is completed here.  The caller learns it from *slots as always.
+static bool ensure_dot_part(const CsrPart &P, long count)
+{   // (the packed kernel leaves a sum per 64 rows, the tiled one per 1024: a part that changes family needs the larger buffer)
+    if (P.dot_part && P.dot_cap >= count) return true;
+    if (P.dot_part) { if (ctx().inited) (void)hipDeviceSynchronize(); (void)hipFree(P.dot_part); P.dot_part = nullptr; P.dot_cap = 0; }
+    if (hipMalloc(&P.dot_part, sizeof(double) * 2 * (size_t)count) != hipSuccess) { (void)hipGetLastError(); P.dot_part = nullptr; return false; }
+    P.dot_cap = count;
+    return true;
+}
+
 int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double *x, double *y, const double *u, int yy, double *part,
                     int *slots, hipStream_t s, const int *done, const PushPlan *pp, int *nofold, const FinishPlan *fp)
 {
     const int n = P.n_rows;
     if (n <= 0 || (variant != 0 && variant != -1)) return 0;
     if (mean_row > 160.0 || ((((uintptr_t)P.val | (uintptr_t)P.col) & 15) != 0)) return 0;
-    if ((!pp && binned_chosen(P, s)) || tiled_chosen(P, s)) return 0;
+    if (!pp && binned_chosen(P, s)) return 0;
+    if (tiled_chosen(P, s)) {
+        // the tiled product: one sum per chunk of 1024 rows (per consumer wavefront), folded like the packed kernel's per-block sums
+        static const bool tl_off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_TILED"); return e && atoi(e) == 0; }();
+        if (tl_off || !tiled_dot_ok(P)) return 0;
+        const int nchunk = tiled_chunks(P);
+        if (nchunk <= 0) return 0;
+        if (!ensure_dot_part(P, nchunk)) return 0;
+        DotPlan dp; dp.u = u; dp.part = P.dot_part; dp.yy = yy; dp.stride = nchunk;
+        int rc = tiled_launch(P, x, y, s, done, pp, &dp);
+        if (rc) return rc;
+        P.last_kernel = pp ? "k_tile_spmv (one-pass tiled product: x tiles and row sums in LDS) + pushing blocks, carrying the dot that follows the product"
+                           : "k_tile_spmv (one-pass tiled product: x tiles and row sums in LDS) carrying the dot that follows the product";
+        if (nofold) { *nofold = nchunk; *slots = 0; return 1; }
+        const int g2 = std::min(512, (nchunk + VB - 1) / VB);
+        const int per = (nchunk + g2 - 1) / g2;
+        FinishPlan fin;
+        if (fp && fp->fin && !yy) { fin = *fp; fin.pc.axp = part; fin.pc.ax_n = (nchunk + per - 1) / per; }
+        hipLaunchKernelGGL(k_axp_fold, dim3((nchunk + per - 1) / per), dim3(VB), 0, s, P.dot_part, nchunk, nchunk, per, yy, part, done, fin);
+        HIPCHK(hipGetLastError());
+        *slots = (nchunk + per - 1) / per;
+        return 1;
+    }
     int R = 0; bool onewin = false;
     { int rc = lds_shape<double>(P, -1, mean_row, s, &R, &onewin); if (rc) return rc; }
     if (!onewin || R != PK_R || !packed_ready(P, s)) return 0;
     static const bool big_off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_PACKED"); return e && atoi(e) == 0; }();
     if (big_off) return 0;
     const int nblk = (n + PK_R - 1) / PK_R;
-    if (!P.dot_part && hipMalloc(&P.dot_part, sizeof(double) * 2 * (size_t)nblk) != hipSuccess) { (void)hipGetLastError(); P.dot_part = nullptr; return 0; }
+    if (!ensure_dot_part(P, nblk)) return 0;
     DotPlan dp; dp.u = u; dp.part = P.dot_part; dp.yy = yy; dp.stride = nblk;
     const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);
     const int ns = per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
@@ -1710,7 +1741,8 @@ int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int 
     if (A->variant != 0 && A->variant != -1) return 0;
     if (ranges_chosen(P, s)) return 0;  // multiplied range by range: the dot keeps its own pass
     if (A->mean_row > 160.0 || ((((uintptr_t)P.val | (uintptr_t)P.col) & 15) != 0)) return 0;
-    if (binned_chosen(P, s) || tiled_chosen(P, s)) return 0;
+    if (binned_chosen(P, s)) return 0;
+    if (tiled_chosen(P, s)) return csr_part_ax_dot(P, A->variant, A->mean_row, x, y, u, yy, part, slots, s, done, nullptr, nullptr, nullptr);
     int R = 0; bool onewin = false;
     { int rc = lds_shape<double>(P, -1, A->mean_row, s, &R, &onewin); if (rc) return rc; }
     if (!onewin) return 0;

@@ -78,12 +78,14 @@ __device__ __forceinline__ void lds_barrier()
 
 // PUSH (sharded rows, direct exchange): the first pp.nblocks blocks of the grid carry this rank's boundary entries of x to the
 // neighbours (devcommon.hpp: push_block) while the rest multiply -- as in the row-block kernels of csr.hip.
-template <int NW, int D, bool PUSH = false, bool NT = false>
+// DOT: every consumer also leaves its 1024 rows' share of y.u (and y.y) in dp.part[chunk] (dp.part[dp.stride + chunk]) -- the dot the
+// Krylov loops take right after the product (csr.hip: csr_part_ax_dot folds the per-chunk sums).
+template <int NW, int D, bool PUSH = false, bool NT = false, bool DOT = false>
 __global__ __launch_bounds__((NW + 1) * 64) void k_tile_spmv2(int n, int nwg, const int *__restrict__ ntile, const int *__restrict__ sofs,
                                                               const int *__restrict__ tl, const int *__restrict__ gstart,
                                                               const int *__restrict__ bstep, const u64t *__restrict__ stream,
                                                               const double *__restrict__ x, long n_cols, double *__restrict__ y,
-                                                              const int *done, PushPlan pp)
+                                                              const int *done, PushPlan pp, DotPlan dp = DotPlan())
 {
     constexpr int TC = TL_TC;
     if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
@@ -197,6 +199,20 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_tile_spmv2(int n, int nwg, co
         }
 #undef TL_LOAD
         while (j + 1 < nt) { j++; lds_barrier(); }              // tiles in which this wavefront has nothing left
+    }
+    if (DOT) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll 4
+        for (int i = l; i < cnt; i += 64) {
+            const double v = my[i];
+            y[row0 + i] = v;
+            a0 = fma(v, dp.u[row0 + i], a0);
+            a1 = fma(v, v, a1);
+        }
+        a0 = wave_sum(a0);
+        if (l == WSUM_LANE) dp.part[chunk] = a0;
+        if (dp.yy) { a1 = wave_sum(a1); if (l == WSUM_LANE) dp.part[dp.stride + chunk] = a1; }
+        return;
     }
 #pragma unroll 4
     for (int i = l; i < cnt; i += 64) y[row0 + i] = my[i];
@@ -450,7 +466,23 @@ int tiled_ready(const CsrPart &P, hipStream_t s, double min_fill)
     return 1;
 }
 
-int tiled_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done, const PushPlan *push)
+// dot != nullptr: the product leaves per-chunk sums of y.u (y.y) in dot->part (chunks: tiled_chunks); only the default shape carries
+// them (eight consumers, ring of three, non-temporal stream) -- tiled_dot_ok says so beforehand
+int tiled_chunks(const CsrPart &P)
+{
+    const TiledPlan *T = static_cast<const TiledPlan *>(P.tl_plan);
+    return T ? T->nwg * T->nw : 0;
+}
+static int tiled_depth() { static const int v = [] { const char *e = std::getenv("LCG_HIP_TILED_DEPTH"); return e ? atoi(e) : 3; }(); return v; }
+static int tiled_nt() { static const int v = [] { const char *e = std::getenv("LCG_HIP_TILED_NT"); return e ? atoi(e) : 1; }(); return v; }
+bool tiled_dot_ok(const CsrPart &P)
+{
+    const TiledPlan *T = static_cast<const TiledPlan *>(P.tl_plan);
+    const int d = tiled_depth();
+    return T && T->nw == 8 && tiled_nt() && d != 2 && d != 4 && d != 6;
+}
+
+int tiled_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done, const PushPlan *push, const DotPlan *dot)
 {
     const TiledPlan *T = static_cast<const TiledPlan *>(P.tl_plan);
     if (!T) return fail(hipErrorInvalidValue, "tiled A.x without a plan", __FILE__, __LINE__);
@@ -460,8 +492,17 @@ int tiled_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, co
     // = 690 / 649 / 657 / 682 / 699 us (eight consumers keep 8 x D x 2 KB in flight through a 32 KB L1: deeper rings evict their
     // own lines), and non-temporal loads on top 670 -> 598 us at depth 3 (the stream no longer pushes the tiles of x out of the
     // L2 -- the kernel then reads at the rate of a pure sum over 4 GiB on the same box, 6.0 TB/s)
-    static const int depth = [] { const char *e = std::getenv("LCG_HIP_TILED_DEPTH"); return e ? atoi(e) : 3; }();
-    static const int nt = [] { const char *e = std::getenv("LCG_HIP_TILED_NT"); return e ? atoi(e) : 1; }();
+    const int depth = tiled_depth(), nt = tiled_nt();
+    if (dot) {
+        if (!tiled_dot_ok(P)) return fail(hipErrorInvalidValue, "tiled A.x: this shape does not carry the dot", __FILE__, __LINE__);
+        const DotPlan dpv = *dot;
+        if (push) hipLaunchKernelGGL((k_tile_spmv2<8, 3, true, true, true>), dim3(grid), dim3(9 * 64), 0, s, T->n_rows, T->nwg, T->ntile, T->sofs, T->tl,
+                                     T->gstart, T->bstep, T->stream, x, T->n_cols, y, done, pp, dpv);
+        else hipLaunchKernelGGL((k_tile_spmv2<8, 3, false, true, true>), dim3(grid), dim3(9 * 64), 0, s, T->n_rows, T->nwg, T->ntile, T->sofs, T->tl,
+                                T->gstart, T->bstep, T->stream, x, T->n_cols, y, done, pp, dpv);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
 #define TL_ARGS T->n_rows, T->nwg, T->ntile, T->sofs, T->tl, T->gstart, T->bstep, T->stream, x, T->n_cols, y, done, pp
 #define TL2(NW, DD)                                                                                                          \
     do {                                                                                                                     \

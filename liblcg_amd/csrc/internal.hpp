@@ -206,7 +206,8 @@ struct CsrPart {
     mutable int pk_runs = 0;                                // blocks stored as runs (row 0's columns only; csr.hip: k_pk_meta)
     mutable int pk_tpls = 0;                                // blocks stored as templates (<= 32 diagonals + a mask per row)
     mutable long pk_groups = 0;                             // 16-byte groups of the packed columns
-    mutable double *dot_part = nullptr;                     // [2][blocks of 64 rows]: per-block sums of a product that carries its dot (k_spmv_ldsp<DOT>)
+    mutable double *dot_part = nullptr;                     // [2][dot_cap]: per-block (per-chunk) sums of a product that carries its dot (k_spmv_ldsp<DOT>, k_tile_spmv2<DOT>)
+    mutable long dot_cap = 0;
     // two-pass "binned" product for scattered columns (csr_binned.hip), plan built on first use
     int64_t n_cols = 0;            // columns the part addresses (0 = unknown: never binned)
     mutable int bn_mode = -1;      // -1 auto (large real matrices whose row blocks span more of x than the L2 holds), 0 never, 1 whenever eligible
@@ -285,7 +286,10 @@ long binned_traffic_bytes(const CsrPart &P);
 size_t binned_plan_bytes(const CsrPart &P);
 // csr_tiled.hip
 int tiled_ready(const CsrPart &P, hipStream_t s, double min_fill);      // 1 plan ready, 0 not eligible, < 0 failure
-int tiled_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done_flag, const PushPlan *push = nullptr);
+int tiled_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done_flag, const PushPlan *push = nullptr,
+                 const DotPlan *dot = nullptr);
+int tiled_chunks(const CsrPart &P);         // chunks of 1024 rows = per-chunk sums a dot-carrying tiled product leaves
+bool tiled_dot_ok(const CsrPart &P);        // the plan's shape has a dot-carrying instance
 void tiled_free(CsrPart &P);
 long tiled_traffic_bytes(const CsrPart &P);
 long tiled_tile_copy_bytes(const CsrPart &P);

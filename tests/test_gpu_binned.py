@@ -200,3 +200,42 @@ def test_automatic_choice_and_solvers(api, lib, port):
             assert abs(info.iterations - ref["iters"]) <= 3, (sym, sid, info.iterations, ref["iters"])
             assert np.linalg.norm(xs - ref["x"]) <= 1e-9 * np.linalg.norm(ref["x"]), (sym, sid)
         A.destroy()
+
+
+def test_tiled_product_carries_the_dot():
+    """k_tile_spmv2<DOT>: every consumer wavefront leaves its 1024 rows' share of y.u (and y.y); y must not change by a bit against the
+    plain tiled product, the sums must agree with numpy's on the same y, and CG through it must meet the oracle-checked plain run."""
+    import ctypes as C
+    from liblcg_amd import _lib, api
+    lib = _lib.load()
+    for n, band in ((20000, 3000), (300000, 40000), (5 * 8192 + 77, 9000)):
+        A = api.CsrMatrix.generate(n, 16, band, True, 4, 0.01, pattern=api.GEN_ROW_RANDOM_BAND)
+        assert lib.lcg_hip_csr_set_tiled(A.h, 1) == 0
+        x = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 9, 0, n, x)
+        u = torch.rand(n, dtype=torch.float64, device="cuda") - 0.5
+        y0 = torch.empty_like(x); y1 = torch.full_like(x, 3.0)
+        A.spmv(x, y0); api.synchronize()
+        assert "k_tile_spmv" in lib.lcg_hip_csr_last_kernel(A.h).decode()
+        sums = (C.c_double * 2)()
+        assert lib.lcg_hip_spmv_dot(A.h, x.data_ptr(), y1.data_ptr(), u.data_ptr(), sums) == 0
+        name = lib.lcg_hip_csr_last_kernel(A.h).decode()
+        assert "k_tile_spmv" in name and "carrying the dot" in name, name
+        assert torch.equal(y0, y1), n
+        yh, uh = y0.cpu().numpy(), u.cpu().numpy()
+        assert abs(sums[0] - float(yh @ uh)) <= 1e-12 * float(np.abs(yh) @ np.abs(uh)) and abs(sums[1] - float(yh @ yh)) <= 1e-12 * float(yh @ yh), n
+        # the same bits from call to call
+        s2 = (C.c_double * 2)()
+        assert lib.lcg_hip_spmv_dot(A.h, x.data_ptr(), y1.data_ptr(), u.data_ptr(), s2) == 0 and s2[0] == sums[0] and s2[1] == sums[1]
+        # CG with and without the carried dot: same iteration count, same answer to rounding
+        b = torch.empty_like(x); A.spmv(x, b); api.synchronize()
+        m1 = torch.zeros_like(x)
+        i1 = api.lcg_solver("lcg_hip_csr_ax", None, m1, b, n, api.lcg_default_parameters(epsilon=1e-12, abs_diff=1), A, api.LCG_CG)
+        api.set_cg_schedule(api.CG_CLASSIC)
+        try:
+            m2 = torch.zeros_like(x)
+            i2 = api.lcg_solver("lcg_hip_csr_ax", None, m2, b, n, api.lcg_default_parameters(epsilon=1e-12, abs_diff=1), A, api.LCG_CG)
+        finally:
+            api.set_cg_schedule(api.CG_AUTO)
+        assert i1.ret == i2.ret == 0 and abs(i1.iterations - i2.iterations) <= 3
+        assert ((m1 - x).norm() / x.norm()).item() <= 1e-8 and ((m2 - x).norm() / x.norm()).item() <= 1e-8
+        A.destroy()

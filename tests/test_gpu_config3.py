@@ -108,8 +108,8 @@ def test_config3_five_real_ranks_at_the_shard_size(tmp_path, finisher):
                 assert ret == 0 and err < 1e-4, (tag, name, r[f"{tag}/{name}"])        # stop rule: sqrt(g.g)/N <= 1e-10
                 if name in ("cg", "cgs"):
                     assert abs(its - int(ref[f"{tag}/{name}_its"])) <= 3, (tag, name, its, int(ref[f"{tag}/{name}_its"]))
-        # the packed product carries g.w, so its finisher can close the body; the tiled product does not (the step stays a kernel)
-        assert (r["band/cg_finisher_steps"] > 0) == (finisher == "1") and r["rrb/cg_finisher_steps"] == 0, r
+        # the packed and the tiled product both carry g.w, so their finisher can close the body
+        assert (r["band/cg_finisher_steps"] > 0) == (finisher == "1") and (r["rrb/cg_finisher_steps"] > 0) == (finisher == "1"), r
     for key in res[0]:
         if "/" in key and isinstance(res[0][key], list):
             assert len({tuple(r[key][:2]) for r in res}) == 1, key
