@@ -524,7 +524,11 @@ __device__ __forceinline__ void ldsp_dot_tail(const DotPlan &dp, int bid, int j0
 // DOT: the block also leaves its rows' share of y.u (and y.y) in dp.part[block] (dp.part[dp.stride + block]): the dot the
 // Krylov loops take right after the product, without a pass of its own over two 80 MB vectors (see k_spmv_lds1d; here one
 // partial per block of 64 rows, folded to <= 512 by k_axp_fold before the scalar step adds them up).
-template <bool PUSH, int NS, int BITS, bool DOT = false>
+// CHE: entries a block holds at most.  PK_CH_SMALL = 2176 where every block of the matrix fits (the headline's 64 x 33 do): 26.1 KB of
+// LDS per workgroup, SIX workgroups per CU instead of the five that 2240 entries (26.9 KB) leave room for -- same-box A/B on the
+// headline system 1477 -> 1498 CG iterations/s (6 of 6 runs), the 200^3 27-point stencil's product 401 -> 374 us.
+constexpr int PK_CH_SMALL = 2176;
+template <bool PUSH, int NS, int BITS, bool DOT = false, int CHE = LdsCfg<double>::CH>
 __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__ rowptr, const v4i *__restrict__ packed,
                                                   const int *__restrict__ pofs, const int *__restrict__ pbase,
                                                   const double *__restrict__ val, const double *__restrict__ x,
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     constexpr int R = PK_R;
     constexpr int T = VB / R;
     constexpr int UNR = NS;
-    constexpr int CH = LdsCfg<double>::CH;              // entries per block at most (checked by the host)
+    constexpr int CH = CHE;                             // entries per block at most (checked by the host)
     constexpr int PER = 128 / BITS;                     // columns per 16-byte group: 6 (21 bits) or 7 (18 bits)
     constexpr int NG = (CH + PER - 1) / PER;            // groups
     constexpr int GR = (NG + VB - 1) / VB;              // rounds of 16-byte group loads
@@ -588,24 +592,20 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
             const int len = WIDE ? __popcll((unsigned long long)mask) : __popc((unsigned)mask);
             const M full = D >= (WIDE ? 64 : 32) ? ~(M)0 : (((M)1 << D) - (M)1);
             const bool dense = __ballot(live && mask != full) == 0ull;      // uniform: every live row has all D diagonals
+            // Entry j0 + q T of a row is the (j0 + q T)-th set bit of its mask.  The lane walks its mask instead of searching it: drop
+            // the j0 lowest set bits once (j0 is the wavefront's number: a uniform loop), then per entry read the lowest set bit and drop
+            // T -- 9 integer instructions per entry where the halving search took about 30 (7-point x 3 unknowns: 300 -> see DESIGN)
+            M m = mask;
+            if (!dense)
+                for (int i = __builtin_amdgcn_readfirstlane(j0); i > 0; i--) m &= m - (M)1;
             double xv[UNR];
 #pragma unroll
             for (int q = 0; q < UNR; q++) {
-                int e = j0 + q * T;
-                int slot = e;
-                if (!dense) {       // uniform: position of the e-th set bit of the mask (five halving steps; six on a wide mask)
-                    int pos = 0;
-                    unsigned m = (unsigned)mask;
-                    if (WIDE) {
-                        const int c = __popc(m);
-                        if (e >= c) { e -= c; pos = 32; m = (unsigned)((unsigned long long)mask >> 32); }
-                    }
+                int slot = j0 + q * T;
+                if (!dense) {       // uniform
+                    slot = m ? (WIDE ? __builtin_ctzll((unsigned long long)m) : __builtin_ctz((unsigned)m)) : 0;
 #pragma unroll
-                    for (int w = 16; w > 0; w >>= 1) {
-                        const int c = __popc(m & ((1u << w) - 1u));
-                        if (e >= c) { e -= c; pos += w; m >>= w; }
-                    }
-                    slot = pos;
+                    for (int t = 0; t < T; t++) m &= m - (M)1;
                 }
                 const int off = __shfl(myoff, slot & 63, 64);
                 const bool ok = live && j0 + q * T < len;
@@ -858,6 +858,21 @@ __device__ __forceinline__ double run1_block(int b, int wv, int n, int LP, const
         // longest row); read from the rows directly -- a stride of one row per lane -- every batch re-fetched the rows' lines
         double *mine = wlds + (size_t)wv * 64 * LP;
         const int tot = rowptr[row0 + nrows] - s;
+        // one batch of NB diagonals: which rows have diagonal k, which of their entries it is (recomputed where it is needed: a few
+        // integer instructions are cheaper than the registers that would carry them past the staging loop), x[offset + lane]
+        auto has = [&](int k) { return k < D && (((k < 32 ? mlo : mhi) >> (k & 31)) & 1u); };             // (k uniform: a scalar choice)
+        auto entry = [&](int k) { return __popc((k < 32 ? mlo : mhi) & ((1u << (k & 31)) - 1u)) + (k < 32 ? 0 : __popc(mlo)); };
+        auto gather = [&](int k0, double (&xv)[NB]) {
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                const int k = k0 + q;                       // uniform
+                const int off = tplp[k < D ? k : 0];        // scalar load
+                xv[q] = x[has(k) ? off + lane : 0];
+            }
+        };
+        // the first batch's gathers leave with the values, as in a run block: one memory latency less per block
+        double xv[NB];
+        gather(0, xv);
         for (int i0 = 0; i0 < tot; i0 += NB * 64) {
             double v[NB];
 #pragma unroll
@@ -869,25 +884,18 @@ __device__ __forceinline__ double run1_block(int b, int wv, int n, int LP, const
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int k0 = 0; k0 < D; k0 += NB) {
-            double a[NB], xv[NB]; int e[NB]; bool ok[NB];
+            if (k0 > 0) gather(k0, xv);
+            double a[NB];
+#pragma unroll
+            for (int q = 0; q < NB; q++) a[q] = has(k0 + q) ? mine[rs + entry(k0 + q)] : 0.0;
 #pragma unroll
             for (int q = 0; q < NB; q++) {
-                const int k = k0 + q;                       // uniform
-                const int off = tplp[k < D ? k : 0];        // scalar load
-                // (k uniform: the half of the mask the bit lies in is a scalar choice)
-                const unsigned half = k < 32 ? mlo : mhi;
-                ok[q] = k < D && ((half >> (k & 31)) & 1u);
-                e[q] = __popc(half & ((1u << (k & 31)) - 1u)) + (k < 32 ? 0 : __popc(mlo));
-                xv[q] = x[ok[q] ? off + lane : 0];
-            }
-#pragma unroll
-            for (int q = 0; q < NB; q++) a[q] = ok[q] ? mine[rs + e[q]] : 0.0;
-#pragma unroll
-            for (int q = 0; q < NB; q++) {
-                if (T == 1) acc[0] = ok[q] ? fma(a[q], xv[q], acc[0]) : acc[0];
+                const bool ok = has(k0 + q);
+                if (T == 1) acc[0] = ok ? fma(a[q], xv[q], acc[0]) : acc[0];
                 else {
+                    const int e = entry(k0 + q);
 #pragma unroll
-                    for (int j = 0; j < T; j++) acc[j] = (ok[q] && (e[q] % T) == j) ? fma(a[q], xv[q], acc[j]) : acc[j];
+                    for (int j = 0; j < T; j++) acc[j] = (ok && (e % T) == j) ? fma(a[q], xv[q], acc[j]) : acc[j];
                 }
             }
         }
@@ -1241,6 +1249,14 @@ static double line_ratio_threshold()
     return v;
 }
 
+static double tiled_line_ratio_threshold()
+{   // the same for the tiled product alone.  Measured at N = 1e7, 33 per row, columns drawn per row inside a band (round 3, one box):
+    // line ratio 0.063 / 0.125 / 0.244 / 0.434 (band 2048 / 4096 / 8192 / 16384): tiled 917 / 886 / 689 / 604 us, packed row blocks
+    // 728 / 808 / 900 / 1062 us; block-structured stencils sit below 0.05
+    static const double v = [] { const char *e = std::getenv("LCG_HIP_LINE_RATIO_TILED"); return e ? atof(e) : 0.18; }();
+    return v;
+}
+
 static double tiled_fill_threshold()
 {
     static const double fill = [] { const char *e = std::getenv("LCG_HIP_TILED_FILL"); return e ? atof(e) : 700.0; }();
@@ -1259,7 +1275,9 @@ static bool tiled_chosen(const CsrPart &P, hipStream_t s)
     if (mode < 0) {
         if (!diag_like_measured(P, s)) { P.tl_state = -1; return false; }
         if (P.diag_like > 0.5) { P.tl_state = -1; P.tl_why = "automatic mode: the columns run along diagonals (the row-block kernels gather contiguously)"; return false; }
-        if (line_ratio_measured(P, s) && P.line_ratio < line_ratio_threshold()) {
+        const bool lr = line_ratio_measured(P, s);
+        if (std::getenv("LCG_HIP_DEBUG_BINNED")) std::fprintf(stderr, "[lcg_hip] tiled choice: diag_like %.3f, line_ratio %.3f\n", P.diag_like, P.line_ratio);
+        if (lr && P.line_ratio < tiled_line_ratio_threshold()) {
             P.tl_state = -1; P.tl_why = "automatic mode: neighbouring rows share their cache lines of x (block-structured: the row-block kernels fetch few lines per entry)";
             return false;
         }
@@ -1573,13 +1591,15 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
                 // gathers per lane in the first batch: enough for the longest row when that is 9..12 per lane
                 const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);
                 const int ns = per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
-#define PK_LAUNCH(NSS, BB)                                                                                          \
-        hipLaunchKernelGGL((k_spmv_ldsp<PUSH, NSS, BB>), dim3((n + PK_R - 1) / PK_R + xb), dim3(VB), 0, s, n, P.rowptr, \
+                const bool small = P.max_slice <= PK_CH_SMALL;      // every block fits the smaller LDS window: six workgroups per CU
+#define PK_LAUNCH(NSS, BB, CC)                                                                                      \
+        hipLaunchKernelGGL((k_spmv_ldsp<PUSH, NSS, BB, false, CC>), dim3((n + PK_R - 1) / PK_R + xb), dim3(VB), 0, s, n, P.rowptr, \
                            static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, reinterpret_cast<const double *>(val), \
                            reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, pp, DotPlan())
 #define PK_CASE(NSS)                                                                                                \
     case NSS:                                                                                                       \
-        if (P.pk_bits == 18) PK_LAUNCH(NSS, 18); else PK_LAUNCH(NSS, 21);                                          \
+        if (small) { if (P.pk_bits == 18) PK_LAUNCH(NSS, 18, PK_CH_SMALL); else PK_LAUNCH(NSS, 21, PK_CH_SMALL); } \
+        else { if (P.pk_bits == 18) PK_LAUNCH(NSS, 18, LdsCfg<double>::CH); else PK_LAUNCH(NSS, 21, LdsCfg<double>::CH); } \
         break;
                 switch (ns) { PK_CASE(8) PK_CASE(9) PK_CASE(10) PK_CASE(12) }
 #undef PK_LAUNCH
@@ -1702,9 +1722,16 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
     const int ns = per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
     const PushPlan ppv = pp ? *pp : PushPlan();
     const unsigned xb = pp ? (unsigned)(pp->nblocks + pp->nrecv) : 0u;
+    const bool small = P.max_slice <= PK_CH_SMALL;
 #define PKD_LAUNCH(PU, NSS, BB)                                                                                     \
-        hipLaunchKernelGGL((k_spmv_ldsp<PU, NSS, BB, true>), dim3(nblk + xb), dim3(VB), 0, s, n, P.rowptr,          \
-                           static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, P.val, x, y, done, ppv, dp)
+    do {                                                                                                            \
+        if (small)                                                                                                  \
+            hipLaunchKernelGGL((k_spmv_ldsp<PU, NSS, BB, true, PK_CH_SMALL>), dim3(nblk + xb), dim3(VB), 0, s, n, P.rowptr, \
+                               static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, P.val, x, y, done, ppv, dp); \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_spmv_ldsp<PU, NSS, BB, true>), dim3(nblk + xb), dim3(VB), 0, s, n, P.rowptr,      \
+                               static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, P.val, x, y, done, ppv, dp); \
+    } while (0)
 #define PKD_CASE(NSS)                                                                                               \
     case NSS:                                                                                                       \
         if (pp) { if (P.pk_bits == 18) PKD_LAUNCH(true, NSS, 18); else PKD_LAUNCH(true, NSS, 21); }                 \
