@@ -524,10 +524,19 @@ __device__ __forceinline__ void ldsp_dot_tail(const DotPlan &dp, int bid, int j0
 // DOT: the block also leaves its rows' share of y.u (and y.y) in dp.part[block] (dp.part[dp.stride + block]): the dot the
 // Krylov loops take right after the product, without a pass of its own over two 80 MB vectors (see k_spmv_lds1d; here one
 // partial per block of 64 rows, folded to <= 512 by k_axp_fold before the scalar step adds them up).
-// CHE: entries a block holds at most.  PK_CH_SMALL = 2176 where every block of the matrix fits (the headline's 64 x 33 do): 26.1 KB of
-// LDS per workgroup, SIX workgroups per CU instead of the five that 2240 entries (26.9 KB) leave room for -- same-box A/B on the
-// headline system 1477 -> 1498 CG iterations/s (6 of 6 runs), the 200^3 27-point stencil's product 401 -> 374 us.
-constexpr int PK_CH_SMALL = 2176;
+// CHE: entries a block holds at most -- the LDS window, about 12 bytes per entry.  With the 2240 entries the shapes are chosen for a
+// workgroup asks for 26.9 KB and FIVE fit a CU (the LDS is handed out in granules: six would need <= 26.6 KB each).  Where every
+// block of the matrix is smaller the window shrinks: 2208 entries (26.5 KB, six workgroups per CU: the headline's 64 x 33 -- same-box
+// A/B 1477 -> 1498 CG iterations/s, 6 of 6 runs), 1872 (22.5 KB, seven: a 27-point stencil's 64 x 27 -- product 401 -> 374 us with
+// six already), 1696 (20.4 KB, eight: rows of up to 26 entries).
+constexpr int PK_CH_SMALL = 2208;
+constexpr int PK_CH_7 = 1872, PK_CH_8 = 1696;
+static int pk_window(int max_slice)
+{
+    static const int env = [] { const char *e = std::getenv("LCG_HIP_PACKED_WINDOW"); return e ? atoi(e) : 0; }();     // A/B runs: least window
+    const int need = std::max(max_slice, env);
+    return need <= PK_CH_8 ? PK_CH_8 : need <= PK_CH_7 ? PK_CH_7 : need <= PK_CH_SMALL ? PK_CH_SMALL : LdsCfg<double>::CH;
+}
 template <bool PUSH, int NS, int BITS, bool DOT = false, int CHE = LdsCfg<double>::CH>
 __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__ rowptr, const v4i *__restrict__ packed,
                                                   const int *__restrict__ pofs, const int *__restrict__ pbase,
@@ -1591,14 +1600,16 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
                 // gathers per lane in the first batch: enough for the longest row when that is 9..12 per lane
                 const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);
                 const int ns = per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
-                const bool small = P.max_slice <= PK_CH_SMALL;      // every block fits the smaller LDS window: six workgroups per CU
+                const int win = pk_window(P.max_slice);             // the smallest LDS window every block fits: more workgroups per CU
 #define PK_LAUNCH(NSS, BB, CC)                                                                                      \
         hipLaunchKernelGGL((k_spmv_ldsp<PUSH, NSS, BB, false, CC>), dim3((n + PK_R - 1) / PK_R + xb), dim3(VB), 0, s, n, P.rowptr, \
                            static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, reinterpret_cast<const double *>(val), \
                            reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, pp, DotPlan())
 #define PK_CASE(NSS)                                                                                                \
     case NSS:                                                                                                       \
-        if (small) { if (P.pk_bits == 18) PK_LAUNCH(NSS, 18, PK_CH_SMALL); else PK_LAUNCH(NSS, 21, PK_CH_SMALL); } \
+        if (win == PK_CH_8) { if (P.pk_bits == 18) PK_LAUNCH(NSS, 18, PK_CH_8); else PK_LAUNCH(NSS, 21, PK_CH_8); } \
+        else if (win == PK_CH_7) { if (P.pk_bits == 18) PK_LAUNCH(NSS, 18, PK_CH_7); else PK_LAUNCH(NSS, 21, PK_CH_7); } \
+        else if (win == PK_CH_SMALL) { if (P.pk_bits == 18) PK_LAUNCH(NSS, 18, PK_CH_SMALL); else PK_LAUNCH(NSS, 21, PK_CH_SMALL); } \
         else { if (P.pk_bits == 18) PK_LAUNCH(NSS, 18, LdsCfg<double>::CH); else PK_LAUNCH(NSS, 21, LdsCfg<double>::CH); } \
         break;
                 switch (ns) { PK_CASE(8) PK_CASE(9) PK_CASE(10) PK_CASE(12) }
@@ -1722,15 +1733,16 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
     const int ns = per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
     const PushPlan ppv = pp ? *pp : PushPlan();
     const unsigned xb = pp ? (unsigned)(pp->nblocks + pp->nrecv) : 0u;
-    const bool small = P.max_slice <= PK_CH_SMALL;
+    const int win = pk_window(P.max_slice);
+#define PKD_LAUNCH1(PU, NSS, BB, CC)                                                                                \
+            hipLaunchKernelGGL((k_spmv_ldsp<PU, NSS, BB, true, CC>), dim3(nblk + xb), dim3(VB), 0, s, n, P.rowptr,  \
+                               static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, P.val, x, y, done, ppv, dp)
 #define PKD_LAUNCH(PU, NSS, BB)                                                                                     \
     do {                                                                                                            \
-        if (small)                                                                                                  \
-            hipLaunchKernelGGL((k_spmv_ldsp<PU, NSS, BB, true, PK_CH_SMALL>), dim3(nblk + xb), dim3(VB), 0, s, n, P.rowptr, \
-                               static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, P.val, x, y, done, ppv, dp); \
-        else                                                                                                        \
-            hipLaunchKernelGGL((k_spmv_ldsp<PU, NSS, BB, true>), dim3(nblk + xb), dim3(VB), 0, s, n, P.rowptr,      \
-                               static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, P.val, x, y, done, ppv, dp); \
+        if (win == PK_CH_8) PKD_LAUNCH1(PU, NSS, BB, PK_CH_8);                                                      \
+        else if (win == PK_CH_7) PKD_LAUNCH1(PU, NSS, BB, PK_CH_7);                                                 \
+        else if (win == PK_CH_SMALL) PKD_LAUNCH1(PU, NSS, BB, PK_CH_SMALL);                                         \
+        else PKD_LAUNCH1(PU, NSS, BB, LdsCfg<double>::CH);                                                          \
     } while (0)
 #define PKD_CASE(NSS)                                                                                               \
     case NSS:                                                                                                       \
@@ -1739,6 +1751,7 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
         break;
     switch (ns) { PKD_CASE(8) PKD_CASE(9) PKD_CASE(10) PKD_CASE(12) }
 #undef PKD_LAUNCH
+#undef PKD_LAUNCH1
 #undef PKD_CASE
     HIPCHK(hipGetLastError());
     P.last_kernel = ldsp_name(P, true);
