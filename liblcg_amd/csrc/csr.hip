@@ -92,13 +92,13 @@ __global__ void k_max_slice(int n, int R, const int *rowptr, int *out)
 // lane per access (~25 KB in flight per block); then every lane keeps UNR gathers of x in flight.
 // The work of one row block, shared by the plain kernel and the one that carries a dot (below).  Returns the finished y
 // of row row0 + tid % R on the lanes that wrote it (`mine`).
-template <class V, int R, bool ACC>
+template <class V, int R, bool ACC, int CHE = LdsCfg<V>::CH>
 __device__ __forceinline__ V lds1_block(int bid, int n, const int *__restrict__ rowptr, const int *__restrict__ col,
                                         const V *__restrict__ val, const V *__restrict__ x, V *__restrict__ y, V *sval, int *scol,
                                         bool &mine)
 {
     constexpr int T = VB / R;
-    constexpr int CH = LdsCfg<V>::CH;                       // entries per LDS window (multiple of 4)
+    constexpr int CH = CHE;                                 // entries per LDS window (multiple of 4)
     constexpr int NRND = (CH + VB * 4 - 1) / (VB * 4);      // 4-entry units per lane
     constexpr int VU = sizeof(V) / 4;                       // 16-byte pieces of val per 4 entries
     constexpr int UNR = 4;                                  // x gathers in flight per lane
@@ -175,7 +175,9 @@ __device__ __forceinline__ V lds1_block(int bid, int n, const int *__restrict__ 
     return acc;
 }
 
-template <class V, int R, bool ACC, bool PUSH = false>
+// CHE: the LDS window in entries (12 bytes each for real matrices); smaller where every block of the matrix fits -- more workgroups
+// per CU (pk_window below: the ladder of k_spmv_ldsp)
+template <class V, int R, bool ACC, bool PUSH = false, int CHE = LdsCfg<V>::CH>
 __global__ __launch_bounds__(VB) void k_spmv_lds1(int n, long nnz, const int *__restrict__ rowptr,
                                                   const int *__restrict__ col, const V *__restrict__ val,
                                                   const V *__restrict__ x, V *__restrict__ y,
@@ -184,12 +186,12 @@ __global__ __launch_bounds__(VB) void k_spmv_lds1(int n, long nnz, const int *__
     if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
     if (PUSH && pp.nrecv > 0 && (int)blockIdx.x >= (int)gridDim.x - pp.nrecv) { recv_block(pp, (int)blockIdx.x - ((int)gridDim.x - pp.nrecv)); return; }
     const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
-    constexpr int CH = LdsCfg<V>::CH;
+    constexpr int CH = CHE;
     __shared__ __attribute__((aligned(16))) V sval[CH];
     __shared__ __attribute__((aligned(16))) int scol[CH];
     if (done && *done) return;
     bool mine;
-    (void)lds1_block<V, R, ACC>(bid, n, rowptr, col, val, x, y, sval, scol, mine);
+    (void)lds1_block<V, R, ACC, CHE>(bid, n, rowptr, col, val, x, y, sval, scol, mine);
 }
 
 // ---- the same product carrying a dot: the Krylov loops follow every A.x with y.u (CG / PCG: d.Ad, CGS / BiCGStab: Ap.r0,
@@ -1620,12 +1622,23 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
                 return 0;
             }
         }
+        // (real matrices, large enough for the memory system to matter: the smallest LDS window every block fits -- 27-point stencil
+        //  x 3 unknowns, 16 rows of 81 entries per block: 625 us with five workgroups per CU -> see DESIGN 3.1)
+        int win = 0;
+        if constexpr (sizeof(V) == 8 && !ACC) { if (onewin && P.nnz >= (1 << 22)) win = pk_window(P.max_slice); }
+#define LDS1_LAUNCH(RR, CC)                                                                            \
+            hipLaunchKernelGGL((k_spmv_lds1<V, RR, ACC, PUSH, CC>), dim3((n + RR - 1) / RR + xb), dim3(VB), 0, s, n, \
+                               (long)(P.end_abs >= 0 ? P.end_abs : P.nnz), P.rowptr, P.col, val, x, y, done, pp)
 #define LDS_CASE(RR)                                                                                   \
     case RR:                                                                                           \
-        if (onewin)                                                                                    \
-            hipLaunchKernelGGL((k_spmv_lds1<V, RR, ACC, PUSH>), dim3((n + RR - 1) / RR + xb), dim3(VB), 0, s, n, \
-                               (long)(P.end_abs >= 0 ? P.end_abs : P.nnz), P.rowptr, P.col, val, x, y, done, pp); \
-        else                                                                                           \
+        if (onewin) {                                                                                  \
+            if constexpr (sizeof(V) == 8 && !ACC) {                                                    \
+                if (win == PK_CH_8) LDS1_LAUNCH(RR, PK_CH_8);                                          \
+                else if (win == PK_CH_7) LDS1_LAUNCH(RR, PK_CH_7);                                     \
+                else if (win == PK_CH_SMALL) LDS1_LAUNCH(RR, PK_CH_SMALL);                             \
+                else LDS1_LAUNCH(RR, LdsCfg<V>::CH);                                                   \
+            } else LDS1_LAUNCH(RR, LdsCfg<V>::CH);                                                     \
+        } else                                                                                          \
             hipLaunchKernelGGL((k_spmv_ldsw<V, RR, ACC, PUSH>), dim3((n + RR - 1) / RR + xb), dim3(VB), 0, s, n, \
                                (long)(P.end_abs >= 0 ? P.end_abs : P.nnz), P.rowptr, P.col, val, x, y, done, pp); \
         break;
@@ -1634,6 +1647,7 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
         default: return fail(hipErrorInvalidValue, "bad LDS A.x rows-per-block", __FILE__, __LINE__);
         }
 #undef LDS_CASE
+#undef LDS1_LAUNCH
         P.last_kernel = onewin ? "k_spmv_lds1 (LDS-staged CSR)" : "k_spmv_ldsw (LDS-staged CSR, windowed)";
     } else {
 #define WAVE_CASE(TT)                                                                                  \
