@@ -2,6 +2,7 @@
 BLAS-1, Jacobi, COO ingest, generators, the sharded product, and size-independent properties
 at the full 10M-row benchmark size."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -756,3 +757,26 @@ def test_block_structured_matrices_stay_with_the_row_block_kernels(api, port):
         bound = port.csr_matvec(rp, ci, np.abs(val), np.abs(x))
         assert float(np.max(np.abs(y.cpu().numpy() - ref) / bound)) <= 1e-13, (dims, dof, name)
         A.destroy()
+
+
+def test_lds_window_does_not_change_a_bit():
+    """The row-block kernels size their LDS window to the matrix's largest block (1696 / 1872 / 2208 / 2240 entries: eight / seven / six /
+    five workgroups per CU).  The window is read once per process, so the same menu of matrices is multiplied in three processes --
+    automatic, the full window forced, the 2208 window as the least -- and y and the carried sums must agree to the last bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for win in ("", "2240", "2208"):
+        env = dict(os.environ)
+        env.pop("LCG_HIP_PACKED_WINDOW", None)
+        if win:
+            env["LCG_HIP_PACKED_WINDOW"] = win
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_window_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l and l.split()[0] in ("stencil27", "stencil7x3", "stencil27x2", "diagonals33", "band")]
+        assert len(lines) == 5, r.stdout
+        outs.append(lines)
+    assert outs[0] == outs[1] == outs[2], outs
+    kernels = {l.split()[0]: l.split()[1] for l in outs[0]}
+    assert kernels["stencil27"] == kernels["diagonals33"] == kernels["band"] == "k_spmv_ldsp" and kernels["stencil27x2"] == "k_spmv_lds1", kernels
