@@ -117,6 +117,26 @@ template <> __device__ __forceinline__ double2 ld<double2>(const double *p, long
 }
 __device__ __forceinline__ void st_(double *p, long i, double v) { p[i] = v; }
 __device__ __forceinline__ void st_(double *p, long i, double2 v) { reinterpret_cast<double2 *>(p)[i] = v; }
+// non-temporal twins: vectors an iteration touches once (the iterate m, the product A.d after the update) should not push the vectors
+// the NEXT kernels need (d = the product's x, g) out of the L2 / Infinity Cache
+typedef double v2d_nt __attribute__((ext_vector_type(2)));
+template <class T> __device__ __forceinline__ T ldnt(const double *p, long i);
+template <> __device__ __forceinline__ double ldnt<double>(const double *p, long i) { return __builtin_nontemporal_load(p + i); }
+template <> __device__ __forceinline__ double2 ldnt<double2>(const double *p, long i)
+{
+    const v2d_nt v = __builtin_nontemporal_load(reinterpret_cast<const v2d_nt *>(p) + i);
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void stnt(double *p, long i, double v) { __builtin_nontemporal_store(v, p + i); }
+__device__ __forceinline__ void stnt(double *p, long i, double2 v)
+{
+    v2d_nt w; w.x = v.x; w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<v2d_nt *>(p) + i);
+}
+// (nt is uniform per launch: the host sets it for systems whose vectors cannot stay in the caches anyway -- solvers_real.hip: stream_vectors)
+template <class T> __device__ __forceinline__ T ldp(const double *p, long i, bool nt) { return nt ? ldnt<T>(p, i) : ld<T>(p, i); }
+__device__ __forceinline__ void stp(double *p, long i, double v, bool nt) { if (nt) stnt(p, i, v); else st_(p, i, v); }
+__device__ __forceinline__ void stp(double *p, long i, double2 v, bool nt) { if (nt) stnt(p, i, v); else st_(p, i, v); }
 
 // real helpers on 1 or 2 packed values
 __device__ __forceinline__ double dotp(double a, double b) { return a * b; }

@@ -127,13 +127,15 @@ struct OpCgInit {   // g = Ad - B; d = -g; m.m, g.g (x2: rho = g.g)      lcg.cpp
 };
 struct OpCgUpdate { // m += a d; g += a Ad; m.m, g.g (x2), NaN           lcg.cpp:237-255
     static constexpr int NR = 4, SKIP = SKIP_DONE;
-    DevState *st; double *m, *g; const double *d, *Ad; double ak;
+    DevState *st; double *m, *g; const double *d, *Ad; double ak; bool nt = false;
     __device__ void prep() { ak = st->s[S_AK]; }
     template <class T> __device__ void apply(long i, double *acc)
     {
-        const T mv = vadd(ld<T>(m, i), ak * ld<T>(d, i));
-        const T gv = vadd(ld<T>(g, i), ak * ld<T>(Ad, i));
-        st_(m, i, mv); st_(g, i, gv);
+        // (nt: the iterate and A.d are touched once per iteration -- streamed past the caches, so that d and g, which the next two
+        //  kernels read, stay: stream_vectors below)
+        const T mv = vadd(ldp<T>(m, i, nt), ak * ld<T>(d, i));
+        const T gv = vadd(ld<T>(g, i), ak * ldp<T>(Ad, i, nt));
+        stp(m, i, mv, nt); st_(g, i, gv);
         acc[0] += dotp(mv, mv);
         const double gg = dotp(gv, gv);
         acc[1] += gg; acc[2] += gg;
@@ -142,11 +144,11 @@ struct OpCgUpdate { // m += a d; g += a Ad; m.m, g.g (x2), NaN           lcg.cpp
 };
 struct OpCgDir {    // d = b d - g                                         lcg.cpp:259-263
     static constexpr int NR = 0, SKIP = SKIP_DIR;
-    DevState *st; double *d; const double *g; double bk;
+    DevState *st; double *d; const double *g; double bk; bool nt = false;
     __device__ void prep() { bk = st->s[S_BK]; }
     template <class T> __device__ void apply(long i, double *)
     {
-        st_(d, i, vsub(bk * ld<T>(d, i), ld<T>(g, i)));
+        st_(d, i, vsub(bk * ld<T>(d, i), ldp<T>(g, i, nt)));      // (g: its last use before the product; d: the product's x)
     }
 };
 
@@ -159,17 +161,18 @@ struct OpCgDir {    // d = b d - g                                         lcg.c
 struct OpCg1UpdateSums { // d = b d - g; Ad = b Ad - w; m += a d; g += a Ad (lcg.cpp:259-263, 237-243), leaving m.m, g.g and the NaN
                          // count behind (lcg.cpp:244-255: sums 0, 1, 3); g.w -- sum 2 -- comes with the product or from the pass after it
     static constexpr int NR = 4, SKIP = SKIP_DONE;
-    DevState *st; double *m, *g, *d, *Ad; const double *w; double ak, bk;
+    DevState *st; double *m, *g, *d, *Ad; const double *w; double ak, bk; bool nt = false;
     __device__ void prep() { ak = st->s[S_AK]; bk = st->s[S_BK]; }
     template <class T> __device__ void apply(long i, double *acc)
     {
+        // (nt: everything but g -- the product's x -- is next touched by this pass one product later)
         const T g0 = ld<T>(g, i);
-        const T dv = vsub(bk * ld<T>(d, i), g0);
-        const T sv = vsub(bk * ld<T>(Ad, i), ld<T>(w, i));
-        st_(d, i, dv); st_(Ad, i, sv);
-        const T mv = vadd(ld<T>(m, i), ak * dv);
+        const T dv = vsub(bk * ldp<T>(d, i, nt), g0);
+        const T sv = vsub(bk * ldp<T>(Ad, i, nt), ldp<T>(w, i, nt));
+        stp(d, i, dv, nt); stp(Ad, i, sv, nt);
+        const T mv = vadd(ldp<T>(m, i, nt), ak * dv);
         const T gv = vadd(g0, ak * sv);
-        st_(m, i, mv); st_(g, i, gv);
+        stp(m, i, mv, nt); st_(g, i, gv);
         acc[0] += dotp(mv, mv);
         acc[1] += dotp(gv, gv);
         acc[3] += nanflag(mv);
@@ -226,22 +229,23 @@ struct OpPcgDots {      // m.m, r.r, z.r, NaN                             lcg.cp
 };
 struct OpPcgUpdateJacobi {  // built-in Jacobi: update, z = r .* invdiag and all dots in one pass
     static constexpr int NR = 4, SKIP = SKIP_DONE;
-    DevState *st; double *m, *r, *z; const double *d, *Ad, *invdiag; double ak;
+    DevState *st; double *m, *r, *z; const double *d, *Ad, *invdiag; double ak; bool nt = false;
     __device__ void prep() { ak = st->s[S_AK]; }
     template <class T> __device__ void apply(long i, double *acc)
     {
-        const T mv = vadd(ld<T>(m, i), ak * ld<T>(d, i));
-        const T rv = vsub(ld<T>(r, i), ak * ld<T>(Ad, i));
-        const T zv = vmul(ld<T>(invdiag, i), rv);
-        st_(m, i, mv); st_(r, i, rv); st_(z, i, zv);
+        // (nt: as in OpCgUpdate -- the iterate, A.d and the diagonal are touched once per iteration; z and d are read by the next kernel)
+        const T mv = vadd(ldp<T>(m, i, nt), ak * ld<T>(d, i));
+        const T rv = vsub(ld<T>(r, i), ak * ldp<T>(Ad, i, nt));
+        const T zv = vmul(ldp<T>(invdiag, i, nt), rv);
+        stp(m, i, mv, nt); st_(r, i, rv); st_(z, i, zv);
         acc[0] += dotp(mv, mv); acc[1] += dotp(rv, rv); acc[2] += dotp(zv, rv); acc[3] += nanflag(mv);
     }
 };
 struct OpPcgDir {       // d = z + b d                                    lcg.cpp:418-422
     static constexpr int NR = 0, SKIP = SKIP_DIR;
-    DevState *st; double *d; const double *z; double bk;
+    DevState *st; double *d; const double *z; double bk; bool nt = false;
     __device__ void prep() { bk = st->s[S_BK]; }
-    template <class T> __device__ void apply(long i, double *) { st_(d, i, vadd(ld<T>(z, i), bk * ld<T>(d, i))); }
+    template <class T> __device__ void apply(long i, double *) { st_(d, i, vadd(ldp<T>(z, i, nt), bk * ld<T>(d, i))); }
 };
 
 // PCG with the built-in Jacobi in the one-reduction (Chronopoulos-Gear) arrangement -- what plain CG's OpCg1UpdateSums is to
@@ -311,7 +315,7 @@ struct OpShadowInit {   // p = (u =) r0 = r = B - Ax; m.m, r.r, r.r0      lcg.cp
 };
 struct OpCgsQW {        // q = u - a Ax; w = u + q                        lcg.cpp:556-560
     static constexpr int NR = 0, SKIP = SKIP_DONE;
-    DevState *st; const double *u, *Ax; double *q, *w; double ak;
+    DevState *st; const double *u, *Ax; double *q, *w; double ak; bool nt = false;
     __device__ void prep() { ak = st->s[S_AK]; }
     template <class T> __device__ void apply(long i, double *)
     {
@@ -322,19 +326,19 @@ struct OpCgsQW {        // q = u - a Ax; w = u + q                        lcg.cp
 };
 struct OpCgsUpdate {    // m += a w; r -= a Ax; m.m, r.r, r.r0, NaN       lcg.cpp:565-588
     static constexpr int NR = 4, SKIP = SKIP_DONE;
-    DevState *st; double *m, *r; const double *w, *Ax, *r0; double ak;
+    DevState *st; double *m, *r; const double *w, *Ax, *r0; double ak; bool nt = false;
     __device__ void prep() { ak = st->s[S_AK]; }
     template <class T> __device__ void apply(long i, double *acc)
     {
-        const T mv = vadd(ld<T>(m, i), ak * ld<T>(w, i));
+        const T mv = vadd(ldp<T>(m, i, nt), ak * ld<T>(w, i));       // (nt: the iterate only -- see stream_vectors)
         const T rv = vsub(ld<T>(r, i), ak * ld<T>(Ax, i));
-        st_(m, i, mv); st_(r, i, rv);
+        stp(m, i, mv, nt); st_(r, i, rv);
         acc[0] += dotp(mv, mv); acc[1] += dotp(rv, rv); acc[2] += dotp(rv, ld<T>(r0, i)); acc[3] += nanflag(mv);
     }
 };
 struct OpCgsDir {       // u = r + b q; p = u + b (q + b p)               lcg.cpp:593-597
     static constexpr int NR = 0, SKIP = SKIP_DIR;
-    DevState *st; double *u, *p; const double *r, *q; double bk;
+    DevState *st; double *u, *p; const double *r, *q; double bk; bool nt = false;
     __device__ void prep() { bk = st->s[S_BK]; }
     template <class T> __device__ void apply(long i, double *)
     {
@@ -346,26 +350,26 @@ struct OpCgsDir {       // u = r + b q; p = u + b (q + b p)               lcg.cp
 };
 struct OpBicgS {        // s = r - a Ap                                   lcg.cpp:727-731
     static constexpr int NR = 0, SKIP = SKIP_DONE;
-    DevState *st; const double *r, *Ap; double *s; double ak;
+    DevState *st; const double *r, *Ap; double *s; double ak; bool nt = false;
     __device__ void prep() { ak = st->s[S_AK]; }
     template <class T> __device__ void apply(long i, double *) { st_(s, i, vsub(ld<T>(r, i), ak * ld<T>(Ap, i))); }
 };
 struct OpBicgUpdate {   // m += a p + w s; r = s - w Ax; m.m, r.r, r.r0, NaN   lcg.cpp:743-772
     static constexpr int NR = 4, SKIP = SKIP_DONE;
-    DevState *st; double *m, *r; const double *p, *s, *Ax, *r0; double ak, wk;
+    DevState *st; double *m, *r; const double *p, *s, *Ax, *r0; double ak, wk; bool nt = false;
     __device__ void prep() { ak = st->s[S_AK]; wk = st->s[S_WK]; }
     template <class T> __device__ void apply(long i, double *acc)
     {
         const T sv = ld<T>(s, i);
-        const T mv = vadd(ld<T>(m, i), vadd(ak * ld<T>(p, i), wk * sv));
+        const T mv = vadd(ldp<T>(m, i, nt), vadd(ak * ld<T>(p, i), wk * sv));       // (nt: the iterate only -- see stream_vectors)
         const T rv = vsub(sv, wk * ld<T>(Ax, i));
-        st_(m, i, mv); st_(r, i, rv);
+        stp(m, i, mv, nt); st_(r, i, rv);
         acc[0] += dotp(mv, mv); acc[1] += dotp(rv, rv); acc[2] += dotp(rv, ld<T>(r0, i)); acc[3] += nanflag(mv);
     }
 };
 struct OpBicgDir {      // p = r + b (p - w Ap)                           lcg.cpp:776-780
     static constexpr int NR = 0, SKIP = SKIP_DIR;
-    DevState *st; double *p; const double *r, *Ap; double bk, wk;
+    DevState *st; double *p; const double *r, *Ap; double bk, wk; bool nt = false;
     __device__ void prep() { bk = st->s[S_BK]; wk = st->s[S_WK]; }
     template <class T> __device__ void apply(long i, double *)
     {
@@ -375,6 +379,27 @@ struct OpBicgDir {      // p = r + b (p - w Ap)                           lcg.cp
 
 // ---- host drivers -------------------------------------------------------------------------------
 static inline uintptr_t al(const void *p) { return (uintptr_t)p; }
+
+// Cache policy of the vector passes.  On a system whose product streams far more than the 256 MB Infinity Cache holds, the passes
+// read and write what the NEXT kernels do not need (the iterate, A.d after the update, g in the direction pass, the Jacobi diagonal)
+// with non-temporal accesses, so that what they do need -- the product's x above all -- is still cached when they run.  Same-box A/B
+// (LCG_HIP_NT_VECTORS=0 / 1 forces either; 10M rows): headline CG +1.4..3 % (six pairs, two boxes), row-random band +2 %, 27-point
+// stencil +1.5 %, BiCGStab / CGS (iterate only: with more the passes got slower) +1 %, 5-point Laplacian CG +1..2 %, PCG + Jacobi +3..5 %.
+// The effect is NOT monotonic in the size (5-point Laplacians: 1M..3M rows -2..-5 %, 4M +6..13 % -- the matrix then fits the cache
+// beside two vectors --, 6M classic CG -4 %), so the automatic rule only takes the regime that was measured to be safe: vectors that
+// cannot stay cached (five of them > 128 MB) AND a product that streams >= 512 MB.
+static bool stream_vectors(long n, lcg_axfunc_ptr Afp, void *inst)
+{
+    static const int env = [] { const char *e = std::getenv("LCG_HIP_NT_VECTORS"); return e ? atoi(e) : -1; }();
+    if (env >= 0) return env != 0;
+    if (n * 40L <= (128L << 20)) return false;
+    if (Afp == lcg_hip_csr_ax && inst != nullptr) {
+        const lcg_hip_csr *A = static_cast<const lcg_hip_csr *>(inst);
+        const long nnz = A->distributed ? (long)A->loc.nnz + (long)A->rem.nnz : (long)A->main.nnz;
+        return nnz * 12L >= (512L << 20);
+    }
+    return n * 40L > (256L << 20);       // a product of the caller's own: nothing is known about its stream
+}
 
 struct RealCommon {
     Ctx &c; Driver drv; lcg_para para; void *inst; lcg_axfunc_ptr Afp; lcg_progress_ptr Pfp;
@@ -448,6 +473,7 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
+    const bool nt = stream_vectors(n, Afp, inst);      // (n: the rows THIS process holds)
 
     TRY(k.ax(m, Ad));                                                            // lcg.cpp:168
     TRY(k.drv.vec(OpCgInit{st, Ad, B, m, g, d}, al(Ad) | al(B) | al(m) | al(g) | al(d)));
@@ -473,8 +499,8 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
             bool first = true;
             k.drv.tail = [&]() -> int { return first ? k.drv.scal(FinCg1Start{}) : k.drv.scal(FinCg1Close{}); };
             rc = k.run_loop([&]() -> int {
-                if (first) { TRY(k.drv.vecf(FinCg1Start{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w))); first = false; }
-                else TRY(k.drv.vecf(FinCg1Close{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
+                if (first) { TRY(k.drv.vecf(FinCg1Start{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0, nt}, a_upd | al(w))); first = false; }
+                else TRY(k.drv.vecf(FinCg1Close{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0, nt}, a_upd | al(w)));
                 if (last_body()) return 0;
                 bool f; TRY(k.ax_dot(g, w, g, false, 2, &f));
                 if (!f) { c.err = "A.x stopped carrying its dot in the middle of a solve"; return LCG_HIP_E_ARG; }
@@ -487,7 +513,7 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
             // is where the ranks' sums meet (update + m.m, g.g, NaN | product, pushes, remote part + g.w | reduce, exchange, step)
             TRY(k.drv.scal(FinCg1Start{}));
             rc = k.run_loop([&]() -> int {
-                TRY(k.drv.vec(OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
+                TRY(k.drv.vec(OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0, nt}, a_upd | al(w)));
                 bool stepped = false;
                 if (!last_body()) {
                     // (sharded rows with the mailboxes: the last block of the kernel that completes g.w reduces, exchanges and steps)
@@ -504,8 +530,8 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
             bool first = true;
             k.drv.tail = [&]() -> int { return first ? k.drv.scal(FinCg1Start{}) : k.drv.scal(FinCg1Close{}); };
             rc = k.run_loop([&]() -> int {
-                if (first) { TRY(k.drv.vecf(FinCg1Start{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w))); first = false; }
-                else TRY(k.drv.vecf(FinCg1Close{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
+                if (first) { TRY(k.drv.vecf(FinCg1Start{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0, nt}, a_upd | al(w))); first = false; }
+                else TRY(k.drv.vecf(FinCg1Close{}, OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0, nt}, a_upd | al(w)));
                 if (last_body()) return 0;
                 TRY(k.ax(g, w));
                 TRY(k.drv.vec_rows(OpDot1{st, g, w}, 2, al(g) | al(w)));
@@ -517,7 +543,7 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
             // which has m and g in registers anyway; the pass after the product only takes g.w (two words per row instead of three)
             TRY(k.drv.scal(FinCg1Start{}));
             rc = k.run_loop([&]() -> int {
-                TRY(k.drv.vec(OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0}, a_upd | al(w)));
+                TRY(k.drv.vec(OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0, nt}, a_upd | al(w)));
                 if (!last_body()) {
                     bool f; TRY(k.ax_dot(g, w, g, false, 2, &f));   // (a product that cannot carry the sum is made all the same)
                     if (!f) TRY(k.drv.vec_rows(OpDot1{st, g, w}, 2, al(g) | al(w)));
@@ -532,8 +558,8 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
     int rc = k.run_loop([&]() -> int {
         bool f; TRY(k.ax_dot(d, Ad, d, false, 0, &f));                          // :232
         if (!f) TRY(k.drv.vec(OpDot1{st, d, Ad}, al(d) | al(Ad)));               // :234
-        TRY(k.drv.vecf(FinAlpha{}, OpCgUpdate{st, m, g, d, Ad, 0.0}, a_upd));    // :235, :237-255
-        TRY(k.drv.vecf(FinClose<false>{}, OpCgDir{st, d, g, 0.0}, al(d) | al(g)));   // :244-257, :259-263
+        TRY(k.drv.vecf(FinAlpha{}, OpCgUpdate{st, m, g, d, Ad, 0.0, nt}, a_upd));    // :235, :237-255
+        TRY(k.drv.vecf(FinClose<false>{}, OpCgDir{st, d, g, 0.0, nt}, al(d) | al(g)));   // :244-257, :259-263
         return 0;
     });
     int rc2 = hb.close(c.stream);
@@ -555,6 +581,7 @@ static int solve_pcg(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pf
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
+    const bool nt = stream_vectors(n, Afp, inst);      // (n: the rows THIS process holds)
     // built-in Jacobi on a handle that owns its reciprocal diagonal: fold M^-1 into the update
     const double *invdiag = nullptr;
     if (Mfp != lcg_hip_jacobi_mx) k.drv.user_cb = true;
@@ -615,13 +642,13 @@ static int solve_pcg(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pf
         bool f; TRY(k.ax_dot(d, Ad, d, false, 0, &f));                          // :387
         if (!f) TRY(k.drv.vec(OpDot1{st, d, Ad}, al(d) | al(Ad)));               // :389
         if (invdiag) {
-            TRY(k.drv.vecf(FinAlpha{}, OpPcgUpdateJacobi{st, m, r, z, d, Ad, invdiag, 0.0}, a_all));   // :390, :392-414
+            TRY(k.drv.vecf(FinAlpha{}, OpPcgUpdateJacobi{st, m, r, z, d, Ad, invdiag, 0.0, nt}, a_all));   // :390, :392-414
         } else {
             TRY(k.drv.vecf(FinAlpha{}, OpPcgUpdate{st, m, r, d, Ad, 0.0}, a_all));   // :390, :392-397
             TRY(k.drv.checked_mx([&] { Mfp(inst, r, z, n); }));                  // :399
             TRY(k.drv.vec(OpPcgDots{st, m, r, z}, a_all));                       // :401-414
         }
-        TRY(k.drv.vecf(FinClose<false>{}, OpPcgDir{st, d, z, 0.0}, al(d) | al(z)));  // :415-416, :418-422
+        TRY(k.drv.vecf(FinClose<false>{}, OpPcgDir{st, d, z, 0.0, nt && invdiag != nullptr}, al(d) | al(z)));  // :415-416, :418-422
         return 0;
     });
     int rc2 = hb.close(c.stream);
@@ -644,6 +671,7 @@ static int solve_cgs(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const 
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
+    const bool nt = stream_vectors(n, Afp, inst);      // (n: the rows THIS process holds)
     const uintptr_t a_all = al(m) | al(B) | al(r) | al(r0) | al(pk) | al(Ax) | al(u) | al(q) | al(w);
 
     TRY(k.ax(m, Ax));                                                            // lcg.cpp:476
@@ -652,10 +680,10 @@ static int solve_cgs(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const 
     int rc = k.run_loop([&]() -> int {
         bool f; TRY(k.ax_dot(pk, Ax, r0, false, 0, &f));                        // :546
         if (!f) TRY(k.drv.vec(OpDot1{st, Ax, r0}, a_all));                       // :548-552
-        TRY(k.drv.vecf(FinAlpha{}, OpCgsQW{st, u, Ax, q, w, 0.0}, a_all));       // :553, :556-560
+        TRY(k.drv.vecf(FinAlpha{}, OpCgsQW{st, u, Ax, q, w, 0.0, nt}, a_all));       // :553, :556-560
         TRY(k.ax(w, Ax));                                                        // :562
-        TRY(k.drv.vec(OpCgsUpdate{st, m, r, w, Ax, r0, 0.0}, a_all));            // :565-588
-        TRY(k.drv.vecf(FinClose<false>{}, OpCgsDir{st, u, pk, r, q, 0.0}, a_all));   // :589-590, :593-597
+        TRY(k.drv.vec(OpCgsUpdate{st, m, r, w, Ax, r0, 0.0, nt}, a_all));            // :565-588
+        TRY(k.drv.vecf(FinClose<false>{}, OpCgsDir{st, u, pk, r, q, 0.0, nt}, a_all));   // :589-590, :593-597
         return 0;
     });
     int rc2 = hb.close(c.stream);
@@ -677,6 +705,7 @@ static int solve_bicgstab(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, c
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
+    const bool nt = stream_vectors(n, Afp, inst);      // (n: the rows THIS process holds)
     const uintptr_t a_all = al(m) | al(B) | al(r) | al(r0) | al(pk) | al(Ax) | al(s) | al(Ap);
 
     TRY(k.ax(m, Ax));                                                            // lcg.cpp:648
@@ -685,11 +714,11 @@ static int solve_bicgstab(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, c
     int rc = k.run_loop([&]() -> int {
         bool f; TRY(k.ax_dot(pk, Ap, r0, false, 0, &f));                        // :718
         if (!f) TRY(k.drv.vec(OpDot1{st, Ap, r0}, a_all));                       // :720-724
-        TRY(k.drv.vecf(FinAlpha{}, OpBicgS{st, r, Ap, s, 0.0}, a_all));          // :725, :727-731
+        TRY(k.drv.vecf(FinAlpha{}, OpBicgS{st, r, Ap, s, 0.0, nt}, a_all));          // :725, :727-731
         TRY(k.ax_dot(s, Ax, s, true, 0, &f));                                    // :733
         if (!f) TRY(k.drv.vec(OpDot2{st, Ax, s}, a_all));                        // :735-740
-        TRY(k.drv.vecf(FinOmega{}, OpBicgUpdate{st, m, r, pk, s, Ax, r0, 0.0, 0.0}, a_all));   // :741, :743-772
-        TRY(k.drv.vecf(FinClose<true>{}, OpBicgDir{st, pk, r, Ap, 0.0, 0.0}, a_all));          // :773-774, :776-780
+        TRY(k.drv.vecf(FinOmega{}, OpBicgUpdate{st, m, r, pk, s, Ax, r0, 0.0, 0.0, nt}, a_all));   // :741, :743-772
+        TRY(k.drv.vecf(FinClose<true>{}, OpBicgDir{st, pk, r, Ap, 0.0, 0.0, nt}, a_all));          // :773-774, :776-780
         return 0;
     });
     int rc2 = hb.close(c.stream);

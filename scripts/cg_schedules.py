@@ -1,9 +1,10 @@
-import sys, time
+import os, sys, time
 sys.path.insert(0, ".")
 import torch
 from liblcg_amd import _lib, api
 lib = _lib.load(); assert lib.lcg_hip_init(0) == 0
-for nx in (316, 1000, 2000, 3162):
+# CG_SIZES="1000,1414,...": grid sides instead of the default four
+for nx in [int(v) for v in os.environ["CG_SIZES"].split(",")] if os.environ.get("CG_SIZES") else (316, 1000, 2000, 3162):
     n = nx * nx
     A = api.CsrMatrix.laplace2d(nx, nx); A.build_jacobi()
     xt = torch.rand(n, dtype=torch.float64, device="cuda"); b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
