@@ -21,11 +21,13 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-@pytest.mark.parametrize("pattern", ["constant_diagonals", "row_random_band"])
-def test_config3_shards_full_size(pattern):
+@pytest.mark.parametrize("pattern,P", [("constant_diagonals", 8), ("row_random_band", 8), ("constant_diagonals", 2), ("constant_diagonals", 4),
+                                       ("row_random_band", 4)])
+def test_config3_shards_full_size(pattern, P):
+    """(P = 2 and 4: the shard sizes of the other points of the scaling curve BASELINE.json's metric is quoted on)"""
     from liblcg_amd import _lib, api, partition
     lib = _lib.load()
-    n, P, band = 10_000_000, 8, 131072
+    n, band = 10_000_000, 131072
     pat = api.GEN_DIAGONALS if pattern == "constant_diagonals" else api.GEN_ROW_RANDOM_BAND
     A = api.CsrMatrix.generate(n, 16, band, True, 1, 0.01, pattern=pat)
     x = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 1, 0, n, x)
