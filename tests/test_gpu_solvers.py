@@ -396,3 +396,22 @@ def test_temporaries_are_kept_between_solves_and_can_be_given_back(api, case10k,
     assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 21)        # nothing of the solves' scratch is still held
     i4, x4 = _solve_real(api, A10k, api.LCG_CGS, b, n, p)
     assert np.array_equal(x1, x4)
+
+
+def test_cache_policy_of_the_vector_passes_changes_no_bit():
+    """Large systems read and write what the next kernels do not need with non-temporal accesses (solvers_real.hip: stream_vectors).
+    That is a cache hint: with the policy forced off and forced on, in two processes, every solver's iterate after 25 iterations must be
+    the same to the last bit (CG and PCG + Jacobi in both schedules, CGS, BiCGStab)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for nt in ("0", "1"):
+        env = dict(os.environ); env["LCG_HIP_NT_VECTORS"] = nt
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_nt_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("iterate ")]
+        assert len(lines) == 7, r.stdout
+        outs.append(lines)
+    assert outs[0] == outs[1], outs
