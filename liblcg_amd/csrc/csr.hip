@@ -394,13 +394,14 @@ __device__ __forceinline__ unsigned long long tpl_row_mask(long row0, int r1, co
     return mask;
 }
 
-__global__ __launch_bounds__(64) void k_pk_meta(int n, const int *rowptr, const int *col, int *base, int *ngroups, int *maxspan, int runs)
+__global__ __launch_bounds__(64) void k_pk_meta(int n, const int *rowptr, const int *col, int *base, int *ngroups, int *maxspan, int runs, int R)
 {   // ngroups[b] = entries of block b for now, -L for a run block, -TPL_GRP - D for a template block (k_pk_groups turns them into groups);
     // maxspan[0] = widest block, [1] = longest row, [2] = run blocks, [3] = template blocks
+    // R: rows per block -- 64, or 32 / 16 for long rows (then runs == 0: run and template blocks are shapes of 64 rows, one per lane)
     __shared__ int tpl[TPL_MAXD + 1], dcount;
     const int b = blockIdx.x;
-    const long row0 = (long)b * PK_R;
-    const int r1 = (int)min((long)n, row0 + PK_R);
+    const long row0 = (long)b * R;
+    const int r1 = (int)min((long)n, row0 + R);
     const int s = rowptr[row0], e = rowptr[r1];
     int lo = 0x7fffffff, hi = 0;
     for (int k = s + threadIdx.x; k < e; k += 64) { const int c = col[k]; lo = min(lo, c); hi = max(hi, c); }
@@ -461,12 +462,12 @@ template <> __device__ __forceinline__ int pk_field<18>(u64 lo, u64 hi, int j)
 }
 
 template <int BITS>
-__global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const int *col, const int *base, const int *pofs, v4i *packed)
+__global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const int *col, const int *base, const int *pofs, v4i *packed, int R)
 {
     constexpr int PER = BITS > 0 ? 128 / BITS : 1;
     const int b = blockIdx.x;
-    const long row0 = (long)b * PK_R;
-    const int r1 = (int)min((long)n, row0 + PK_R);
+    const long row0 = (long)b * R;
+    const int r1 = (int)min((long)n, row0 + R);
     const int s = rowptr[row0], e = rowptr[r1];
     const int bs = base[b];
     if (BITS == 0 && bs >= 0) return;       // runs only: the other blocks keep nothing
@@ -514,7 +515,8 @@ __global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const 
 // end of a block of k_spmv_ldsp<DOT>: the first wavefront holds the finished rows (vfin) and their u; one sum per block
 __device__ __forceinline__ void ldsp_dot_tail(const DotPlan &dp, int bid, int j0, double vfin, double uv)
 {
-    if (j0 != 0) return;                // uniform per wavefront (64 rows per block: wavefront 0 is slot 0)
+    if (threadIdx.x >= 64) return;      // uniform per wavefront: the finished rows sit in wavefront 0 (all of it at 64 rows per block,
+    if (j0 != 0) vfin = 0.0;            // its first 32 / 16 lanes at 32 / 16 -- the other lanes add zeros)
     const double a0 = wave_sum(vfin * uv);
     if ((threadIdx.x & 63) == WSUM_LANE) dp.part[bid] = a0;
     if (dp.yy) {                        // uniform
@@ -539,7 +541,10 @@ static int pk_window(int max_slice)
     const int need = std::max(max_slice, env);
     return need <= PK_CH_8 ? PK_CH_8 : need <= PK_CH_7 ? PK_CH_7 : need <= PK_CH_SMALL ? PK_CH_SMALL : LdsCfg<double>::CH;
 }
-template <bool PUSH, int NS, int BITS, bool DOT = false, int CHE = LdsCfg<double>::CH>
+// RR: rows per block.  64 (T = 4 lanes per row) for rows of up to ~34 entries; 32 / 16 (T = 8 / 16) for longer rows -- packed columns
+// only, the first batch predicated for ANY NS (round 3, late: 27-point stencils with 2 / 3 unknowns per point, 54 / 81 entries per row,
+// took the 12-byte k_spmv_lds1 before).
+template <bool PUSH, int NS, int BITS, bool DOT = false, int CHE = LdsCfg<double>::CH, int RR = PK_R>
 __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__ rowptr, const v4i *__restrict__ packed,
                                                   const int *__restrict__ pofs, const int *__restrict__ pbase,
                                                   const double *__restrict__ val, const double *__restrict__ x,
@@ -548,7 +553,7 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     if (PUSH && (int)blockIdx.x < pp.nblocks) { push_block(pp, blockIdx.x); return; }
     if (PUSH && pp.nrecv > 0 && (int)blockIdx.x >= (int)gridDim.x - pp.nrecv) { recv_block(pp, (int)blockIdx.x - ((int)gridDim.x - pp.nrecv)); return; }
     const int bid = PUSH ? blockIdx.x - pp.nblocks : blockIdx.x;
-    constexpr int R = PK_R;
+    constexpr int R = RR;
     constexpr int T = VB / R;
     constexpr int UNR = NS;
     constexpr int CH = CHE;                             // entries per block at most (checked by the host)
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     double uv = 0.0;
     if (DOT) uv = dp.u[(j0 == 0 && rl < nrows) ? row0 + rl : 0];     // requested ahead of the stream: hidden behind it
 
-    if (bs <= -TPL_CODE) {
+    if (RR == 64 && bs <= -TPL_CODE) {     // (run and template blocks are shapes of 64 rows: the builder marks none at 32 / 16 rows per block)
         // TEMPLATE block (k_pk_meta): every entry lies on one of D <= 64 diagonals and every row says by a mask which of them it
         // has.  As in a run block nothing but the values streams and the x gathers go out beside the value stream -- their
         // addresses come from the row's mask and the D offsets (held one per lane, fetched by a wavefront shuffle), not from staged
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
         if (DOT) ldsp_dot_tail(dp, bid, j0, vfin, uv);
         return;
     }
-    if (bs < 0) {
+    if (RR == 64 && bs < 0) {
         // RUN block (k_pk_meta): every row holds L entries and column(row r, slot k) = column(row 0, slot k) + r.  Nothing but
         // the values streams; the columns are row 0's L integers, read through the scalar cache (a wavefront is one slot j0 of
         // 64 rows: its k is uniform), and -- the point -- the x gathers no longer wait for the staged columns: they go out
@@ -748,7 +753,7 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     __syncthreads();
     double acc = 0.0;
     int k = rs + j0;
-    if (NS > 8) {
+    if (NS > 8 || RR < 64) {
         int c[UNR]; double a[UNR], xv[UNR];
 #pragma unroll
         for (int q = 0; q < UNR; q++) {
@@ -1052,9 +1057,9 @@ struct PlanTimer {      // adds the host time of a build (it ends on a drained s
     ~PlanTimer() { (void)hipStreamSynchronize(s); P.plan_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
-static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only)
+static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only, int R = PK_R)
 {
-    if (P.pk_state != 0) return P.pk_state == (runs_only ? 2 : 1);
+    if (P.pk_state != 0) return P.pk_state == (runs_only ? 2 : 1) && P.pk_R == R;
     P.pk_state = -1;
     static const int env = [] { const char *e = std::getenv("LCG_HIP_PACKED"); return e ? atoi(e) : -1; }();
     const int mode = env >= 0 ? env : P.pk_mode;
@@ -1062,7 +1067,7 @@ static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only)
     if (!runs_only && mode < 0 && P.nnz < (1 << 22)) return false;       // small systems are launch-bound: not worth the memory
     PlanTimer timer(P, s);
     const int n = P.n_rows;
-    const int nb = (n + PK_R - 1) / PK_R;
+    const int nb = (n + R - 1) / R;
     int *ngr = nullptr, *span = nullptr;
     long total = 0;
     int hspan[4] = {0, 0, 0, 0};
@@ -1073,7 +1078,7 @@ static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only)
     if (ok) {
         // (k_pk_meta: 0 no run blocks, 1 run blocks and template blocks, 2 run blocks only)
         static const int tpls = [] { const char *e = std::getenv("LCG_HIP_PACKED_TEMPLATES"); return e ? atoi(e) : 1; }();    // 0: A/B runs without template blocks
-        hipLaunchKernelGGL(k_pk_meta, dim3(nb), dim3(64), 0, s, n, P.rowptr, P.col, P.pk_base, ngr, span, runs ? (tpls ? 1 : 2) : 0);
+        hipLaunchKernelGGL(k_pk_meta, dim3(nb), dim3(64), 0, s, n, P.rowptr, P.col, P.pk_base, ngr, span, (runs && R == PK_R) ? (tpls ? 1 : 2) : 0, R);
         ok = hipMemcpyAsync(hspan, span, 4 * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     }
     if (ok) ok = runs_only ? (runs && 2L * (hspan[2] + hspan[3]) >= nb) : hspan[0] < PK_SPAN;     // runs only: worth it when most blocks are runs or templates
@@ -1087,11 +1092,11 @@ static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only)
     if (ok) ok = hipMalloc(&P.pk_data, 16 * ((size_t)total + 4)) == hipSuccess;
     if (ok) {
         if (runs_only)
-            hipLaunchKernelGGL(k_pk_pack<0>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data));
+            hipLaunchKernelGGL(k_pk_pack<0>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data), R);
         else if (bits == 18)
-            hipLaunchKernelGGL(k_pk_pack<18>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data));
+            hipLaunchKernelGGL(k_pk_pack<18>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data), R);
         else
-            hipLaunchKernelGGL(k_pk_pack<21>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data));
+            hipLaunchKernelGGL(k_pk_pack<21>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data), R);
         ok = hipGetLastError() == hipSuccess;
     }
     if (ngr) hipFree(ngr);
@@ -1109,10 +1114,11 @@ static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only)
     P.pk_tpls = hspan[3];
     P.pk_groups = total;
     P.pk_bits = bits;
+    P.pk_R = R;
     P.pk_state = runs_only ? 2 : 1;
     return true;
 }
-static bool packed_ready(const CsrPart &P, hipStream_t s) { return packed_build(P, s, false); }
+static bool packed_ready(const CsrPart &P, hipStream_t s, int R = PK_R) { return packed_build(P, s, false, R); }
 
 // ---- scattered columns: which matrices take the two-pass binned product (csr_binned.hip) -----------------
 // mean column span (largest - smallest column) of the blocks of 64 rows
@@ -1517,6 +1523,12 @@ static void ranges_free(const CsrPart &P)
     P.rg_plan = nullptr; P.rg_state = 0;
 }
 
+static bool long_rows_packed()
+{   // LCG_HIP_PACKED_LONG=0: long rows stay with k_spmv_lds1 (A/B runs)
+    static const bool on = [] { const char *e = std::getenv("LCG_HIP_PACKED_LONG"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 template <class V, bool ACC, bool PUSH = false>
 static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V *x, V *y, hipStream_t s,
                          const int *done, const PushPlan &pp = PushPlan())
@@ -1620,6 +1632,33 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
                 HIPCHK(hipGetLastError());
                 P.last_kernel = ldsp_name(P, false);
                 return 0;
+            }
+            if constexpr (!PUSH) {
+                // long rows (a block of 64 does not fit the window): blocks of 32 / 16 rows, 8 / 16 lanes per row, packed columns only.
+                // ONE predicated batch of NS gathers per lane, NS the smallest of the instantiated ones that covers the longest row
+                // (nine where the rows are longer still: the loop takes the rest) -- every gather beyond a lane's entries is a wasted
+                // instruction, and with nine for all the packed form was no faster than the plain one.
+                if ((R == 32 || R == 16) && onewin && long_rows_packed() && packed_ready(P, s, R)) {
+                    const int T = VB / R;
+                    const int per_lane = (P.pk_maxrow + T - 1) / T;
+                    const int win = pk_window(P.max_slice);
+#define PKL_LAUNCH(NSS, BB, CC, RRR)                                                                                \
+        hipLaunchKernelGGL((k_spmv_ldsp<false, NSS, BB, false, CC, RRR>), dim3((n + RRR - 1) / RRR), dim3(VB), 0, s, n, P.rowptr, \
+                           static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, reinterpret_cast<const double *>(val), \
+                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, PushPlan(), DotPlan())
+#define PKL_WIN(NSS, BB, RRR)                                                                                       \
+        do { if (win == PK_CH_8) PKL_LAUNCH(NSS, BB, PK_CH_8, RRR); else if (win == PK_CH_7) PKL_LAUNCH(NSS, BB, PK_CH_7, RRR);   \
+             else if (win == PK_CH_SMALL) PKL_LAUNCH(NSS, BB, PK_CH_SMALL, RRR); else PKL_LAUNCH(NSS, BB, LdsCfg<double>::CH, RRR); } while (0)
+#define PKL_BITS(NSS, RRR) do { if (P.pk_bits == 18) PKL_WIN(NSS, 18, RRR); else PKL_WIN(NSS, 21, RRR); } while (0)
+                    if (R == 32) { if (per_lane <= 7) PKL_BITS(7, 32); else PKL_BITS(9, 32); }
+                    else { if (per_lane <= 6) PKL_BITS(6, 16); else PKL_BITS(9, 16); }
+#undef PKL_LAUNCH
+#undef PKL_WIN
+#undef PKL_BITS
+                    HIPCHK(hipGetLastError());
+                    P.last_kernel = P.pk_bits == 18 ? "k_spmv_ldsp (LDS-staged, long rows: 18-bit packed columns)" : "k_spmv_ldsp (LDS-staged, long rows: 21-bit packed columns)";
+                    return 0;
+                }
             }
         }
         // (real matrices, large enough for the memory system to matter: the smallest LDS window every block fits -- 27-point stencil
@@ -1737,9 +1776,11 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
     }
     int R = 0; bool onewin = false;
     { int rc = lds_shape<double>(P, -1, mean_row, s, &R, &onewin); if (rc) return rc; }
-    if (!onewin || R != PK_R || !packed_ready(P, s)) return 0;
     static const bool big_off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_PACKED"); return e && atoi(e) == 0; }();
-    if (big_off) return 0;
+    if (!onewin || big_off) return 0;
+    // (long rows -- blocks of 32 / 16 rows with packed columns, spmv_dispatch -- keep the dot as a pass of its own: carried in the
+    //  product it cost 32 us on the 27-point stencil x 3 unknowns, 187,500 blocks of 16 rows, where the separate pass costs 7)
+    if (R != PK_R || !packed_ready(P, s)) return 0;
     const int nblk = (n + PK_R - 1) / PK_R;
     if (!ensure_dot_part(P, nblk)) return 0;
     DotPlan dp; dp.u = u; dp.part = P.dot_part; dp.yy = yy; dp.stride = nblk;
@@ -1801,6 +1842,7 @@ int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int 
     { int rc = lds_shape<double>(P, -1, A->mean_row, s, &R, &onewin); if (rc) return rc; }
     if (!onewin) return 0;
     if (R == PK_R && packed_ready(P, s)) return csr_part_ax_dot(P, A->variant, A->mean_row, x, y, u, yy, part, slots, s, done, nullptr, nullptr, nullptr);
+    if ((R == 32 || R == 16) && long_rows_packed() && packed_ready(P, s, R)) return 0;     // (the product alone: see csr_part_ax_dot)
     const int nblk = (n + R - 1) / R;
     static const bool run1_off = [] { const char *e = std::getenv("LCG_HIP_RUN1"); return e && atoi(e) == 0; }();
     if (!run1_off && (R == 256 || R == 128) && packed_build(P, s, true) && P.pk_maxrow <= 15) {
@@ -2578,7 +2620,7 @@ int64_t lcg_hip_csr_packed_runs(lcg_hip_csr_t A, int64_t *blocks_out)
 {
     if (!A) return 0;
     const CsrPart &P = A->distributed ? A->loc : A->main;
-    if (blocks_out) *blocks_out = (P.n_rows + PK_R - 1) / PK_R;
+    if (blocks_out) *blocks_out = (P.n_rows + P.pk_R - 1) / P.pk_R;
     return P.pk_state > 0 ? P.pk_runs : 0;
 }
 
@@ -2595,7 +2637,7 @@ static int64_t part_traffic_model(const CsrPart &P)
     }
     const int64_t n = P.n_rows, ncols = P.n_cols > 0 ? P.n_cols : P.n_rows;
     const int64_t vectors = 4 * (n + 1) + 8 * ncols + 8 * n;       // row pointers, x once, y
-    const int64_t nb = (n + PK_R - 1) / PK_R;
+    const int64_t nb = (n + P.pk_R - 1) / P.pk_R;
     if (std::strncmp(k, "k_bin_", 6) == 0) return binned_traffic_bytes(P);
     if (std::strncmp(k, "k_tile", 6) == 0) return tiled_traffic_bytes(P);
     if (std::strncmp(k, "k_spmv_ldsp", 11) == 0)       // values + packed columns (run blocks: row 0's columns only) + two words per block
@@ -2627,7 +2669,7 @@ int lcg_hip_csr_plan_info(lcg_hip_csr_t A, double *build_ms, int64_t *extra_byte
     double ms = P.plan_ms;
     int64_t b = 0;
     auto add = [&](const CsrPart &Q) {
-        if (Q.pk_state > 0) b += 16 * ((int64_t)Q.pk_groups + 4) + 8 * (((int64_t)Q.n_rows + PK_R - 1) / PK_R + 1);
+        if (Q.pk_state > 0) b += 16 * ((int64_t)Q.pk_groups + 4) + 8 * (((int64_t)Q.n_rows + Q.pk_R - 1) / Q.pk_R + 1);
         if (Q.bn_plan) b += (int64_t)binned_plan_bytes(Q);
         if (Q.tl_plan) b += (int64_t)tiled_plan_bytes(Q);
     };

@@ -203,6 +203,7 @@ struct CsrPart {
     mutable void *pk_data = nullptr;                        // 16 bytes per group of 6 entries
     mutable int pk_maxrow = 0;                              // longest row (chooses the gather batch of the kernel)
     mutable int pk_bits = 21;                               // width of a packed column: 18 (seven per group) or 21 (six)
+    mutable int pk_R = 64;                                  // rows per block of the packed form (64; 32 / 16 for long rows)
     mutable int pk_runs = 0;                                // blocks stored as runs (row 0's columns only; csr.hip: k_pk_meta)
     mutable int pk_tpls = 0;                                // blocks stored as templates (<= 32 diagonals + a mask per row)
     mutable long pk_groups = 0;                             // 16-byte groups of the packed columns

@@ -35,8 +35,8 @@ def stencil(dims, faces, dof):
 
 
 def run(name, A, n, packed):
-    if packed:
-        assert lib.lcg_hip_csr_set_packed(A.h, 1) == 0
+    if packed is not None:          # True: packed columns forced; False: switched off (k_spmv_lds1); None: the automatic choice
+        assert lib.lcg_hip_csr_set_packed(A.h, 1 if packed else 0) == 0
     assert lib.lcg_hip_csr_set_tiled(A.h, 0) == 0 and lib.lcg_hip_csr_set_binned(A.h, 0) == 0
     x = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 5, 0, n, x)
     u = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 6, 0, n, u)
@@ -52,11 +52,11 @@ def run(name, A, n, packed):
 
 rng = np.random.default_rng(3)
 # 27-point stencil (1728 entries per 64-row block: the 1872 window), 7-point x 3 unknowns (1344: 1696), constant diagonals at 33 per
-# row (2112: 2208; the full window is what LCG_HIP_PACKED_WINDOW=2240 runs them all with), and long rows on the plain LDS-staged kernel (>= 4M entries)
+# row (2112: 2208; the full window is what LCG_HIP_PACKED_WINDOW=2240 runs them all with), and long rows (>= 4M entries) on the plain LDS-staged kernel and, by the automatic choice, in blocks of 32 rows with packed columns
 for name, dims, faces, dof, packed in (("stencil27", (40, 41, 42), False, 1, True), ("stencil7x3", (30, 31, 32), True, 3, True),
-                                       ("stencil27x2", (35, 36, 37), False, 2, False)):
+                                       ("stencil27x2", (35, 36, 37), False, 2, False), ("stencil27x2p", (35, 36, 37), False, 2, None)):
     n, rp, ci = stencil(dims, faces, dof)
-    v = rng.standard_normal(len(ci))
+    v = np.random.default_rng(sum(dims) + dof).standard_normal(len(ci))       # (the same values for the same system under two names)
     A = api.CsrMatrix.from_csr(rp, ci, v)
     run(name, A, n, packed)
 A = api.CsrMatrix.generate(200_000, 16, 3000, True, 4, 0.01, pattern=api.GEN_DIAGONALS)
