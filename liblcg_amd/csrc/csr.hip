@@ -583,7 +583,8 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
         // addresses come from the row's mask and the D offsets (held one per lane, fetched by a wavefront shuffle), not from staged
         // columns.  Entry e of a row is the e-th set bit of its mask (columns ascend); lane (row, j0) takes entries j0, j0 + T, ...
         // and the partial sums meet as in the general path: the same bits.
-        static_assert(UNR * T >= TPL_MAXROW, "one predicated batch covers the longest row of a template block");
+        // (NS < 8 is launched only for matrices whose LONGEST row has NS * T entries at most: its template blocks' rows fit too)
+        static_assert(UNR * T >= TPL_MAXROW || NS < 8, "one predicated batch covers the longest row of a template block");
         const int D = -bs - TPL_CODE;
         const int *tplp = reinterpret_cast<const int *>(packed + po);
         const int *mskp = tplp + ((D + 3) & ~3);           // 64 masks: 32 bits wide up to 32 diagonals, 64 beyond
@@ -753,7 +754,8 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     __syncthreads();
     double acc = 0.0;
     int k = rs + j0;
-    if (NS > 8 || RR < 64) {
+    {   // the first batch is predicated for every NS (it was for NS > 8 only: rows of fewer than 8 T entries then went through the
+        // serial loop at the end, one gather at a time -- 29 entries per row were slower than 33: 782 vs 759 us at 10M rows)
         int c[UNR]; double a[UNR], xv[UNR];
 #pragma unroll
         for (int q = 0; q < UNR; q++) {
@@ -1613,7 +1615,7 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
             if (R == PK_R && onewin && packed_ready(P, s)) {
                 // gathers per lane in the first batch: enough for the longest row when that is 9..12 per lane
                 const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);
-                const int ns = per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
+                const int ns = per_lane <= 6 ? 6 : per_lane <= 7 ? 7 : per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
                 const int win = pk_window(P.max_slice);             // the smallest LDS window every block fits: more workgroups per CU
 #define PK_LAUNCH(NSS, BB, CC)                                                                                      \
         hipLaunchKernelGGL((k_spmv_ldsp<PUSH, NSS, BB, false, CC>), dim3((n + PK_R - 1) / PK_R + xb), dim3(VB), 0, s, n, P.rowptr, \
@@ -1626,7 +1628,7 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
         else if (win == PK_CH_SMALL) { if (P.pk_bits == 18) PK_LAUNCH(NSS, 18, PK_CH_SMALL); else PK_LAUNCH(NSS, 21, PK_CH_SMALL); } \
         else { if (P.pk_bits == 18) PK_LAUNCH(NSS, 18, LdsCfg<double>::CH); else PK_LAUNCH(NSS, 21, LdsCfg<double>::CH); } \
         break;
-                switch (ns) { PK_CASE(8) PK_CASE(9) PK_CASE(10) PK_CASE(12) }
+                switch (ns) { PK_CASE(6) PK_CASE(7) PK_CASE(8) PK_CASE(9) PK_CASE(10) PK_CASE(12) }
 #undef PK_LAUNCH
 #undef PK_CASE
                 HIPCHK(hipGetLastError());
@@ -1785,7 +1787,7 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
     if (!ensure_dot_part(P, nblk)) return 0;
     DotPlan dp; dp.u = u; dp.part = P.dot_part; dp.yy = yy; dp.stride = nblk;
     const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);
-    const int ns = per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
+    const int ns = per_lane <= 6 ? 6 : per_lane <= 7 ? 7 : per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
     const PushPlan ppv = pp ? *pp : PushPlan();
     const unsigned xb = pp ? (unsigned)(pp->nblocks + pp->nrecv) : 0u;
     const int win = pk_window(P.max_slice);
@@ -1804,7 +1806,7 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
         if (pp) { if (P.pk_bits == 18) PKD_LAUNCH(true, NSS, 18); else PKD_LAUNCH(true, NSS, 21); }                 \
         else { if (P.pk_bits == 18) PKD_LAUNCH(false, NSS, 18); else PKD_LAUNCH(false, NSS, 21); }                  \
         break;
-    switch (ns) { PKD_CASE(8) PKD_CASE(9) PKD_CASE(10) PKD_CASE(12) }
+    switch (ns) { PKD_CASE(6) PKD_CASE(7) PKD_CASE(8) PKD_CASE(9) PKD_CASE(10) PKD_CASE(12) }
 #undef PKD_LAUNCH
 #undef PKD_LAUNCH1
 #undef PKD_CASE
