@@ -1368,6 +1368,9 @@ static int lds_shape(const CsrPart &P, int variant, double mean_row, hipStream_t
 // class: the product of a range is bit-identical to the product of that range as a stand-alone matrix.
 constexpr int RG_CHUNK = 2048;
 constexpr int RG_MAX = 8;           // most ranges (more classes changes than that: no split)
+constexpr int RG_ST = 4;            // statistics per 64-row block (k_range_stats)
+constexpr int LR_LONG = 1024;       // a row of more entries than this is multiplied by chunks (long_rows_launch): a dense "arrow" row
+constexpr int LR_MAXRUNS = 3;       // most stretches of such rows a matrix may have and still be split for them
 struct RangePlan {
     std::vector<CsrPart> parts;
     std::vector<int> r0;            // first row of each range
@@ -1375,7 +1378,7 @@ struct RangePlan {
     std::string desc;
 };
 
-// per 64-row block: [0] column span, [1] diagonal-like entries, [2] entries
+// per 64-row block: [0] column span, [1] diagonal-like entries, [2] entries, [3] longest row
 __global__ __launch_bounds__(64) void k_range_stats(int n, const int *__restrict__ rowptr, const int *__restrict__ col, unsigned int *stats)
 {
     const long row0 = (long)blockIdx.x * PK_R;
@@ -1385,6 +1388,7 @@ __global__ __launch_bounds__(64) void k_range_stats(int n, const int *__restrict
     for (int k = s + threadIdx.x; k < e; k += 64) { const int c = col[k]; lo = min(lo, c); hi = max(hi, c); }
     unsigned cnt = 0;
     const long i = row0 + threadIdx.x;
+    int len = i < r1 ? rowptr[i + 1] - rowptr[i] : 0;
     if (i < r1 && i + 1 < n) {
         const int a = rowptr[i], b = rowptr[i + 1], c = rowptr[i + 2];
         const int m = min(b - a, c - b);
@@ -1392,10 +1396,11 @@ __global__ __launch_bounds__(64) void k_range_stats(int n, const int *__restrict
     }
     for (int off = 32; off > 0; off >>= 1) {
         lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); cnt += __shfl_down(cnt, off, 64);
+        len = max(len, __shfl_down(len, off, 64));
     }
     if (threadIdx.x == 0) {
-        unsigned int *st = stats + 3 * (long)blockIdx.x;
-        st[0] = e > s ? (unsigned)(hi - lo) : 0u; st[1] = cnt; st[2] = (unsigned)(e - s);
+        unsigned int *st = stats + RG_ST * (long)blockIdx.x;
+        st[0] = e > s ? (unsigned)(hi - lo) : 0u; st[1] = cnt; st[2] = (unsigned)(e - s); st[3] = (unsigned)len;
     }
 }
 
@@ -1415,7 +1420,7 @@ static bool ranges_chosen(const CsrPart &P, hipStream_t s)
     const int nb = (n + PK_R - 1) / PK_R;
     constexpr int BPC = RG_CHUNK / PK_R;         // blocks per chunk
     const int nc = (nb + BPC - 1) / BPC;
-    std::vector<unsigned int> hb(3 * (size_t)nb);
+    std::vector<unsigned int> hb(RG_ST * (size_t)nb);
     {
         unsigned int *d = nullptr;
         bool ok = hipMalloc(&d, sizeof(unsigned int) * hb.size()) == hipSuccess;
@@ -1439,16 +1444,36 @@ static bool ranges_chosen(const CsrPart &P, hipStream_t s)
         const double fill = 128.0 * (ent / blocks) / ((span + 8192.0) / 2048.0);
         return fill < tiled_fill_threshold() && span >= (double)(1 << 19) ? 2 : 1;
     };
-    auto block_class = [&](int b) { return classify((double)hb[3 * (size_t)b], (double)hb[3 * (size_t)b + 1], (double)hb[3 * (size_t)b + 2], 1.0); };
+    // class 3: a 64-row block that holds a row of more than LR_LONG entries (a dense row of an "arrow" matrix: constraints, mean values).
+    // One such row makes its block's slice larger than any LDS window, the whole part falls to the window-by-window kernel and ONE
+    // workgroup walks the row alone (a 10M-entry row: milliseconds).  Its stretch becomes a range of its own whose rows are multiplied in
+    // chunks by many workgroups (long_rows_launch); up to LR_MAXRUNS such stretches, else the class is not used.
+    bool use_long = true;
+    auto block_class = [&](int b) {
+        if (use_long && hb[RG_ST * (size_t)b + 3] > (unsigned)LR_LONG) return 3;
+        return classify((double)hb[RG_ST * (size_t)b], (double)hb[RG_ST * (size_t)b + 1], (double)hb[RG_ST * (size_t)b + 2], 1.0);
+    };
     std::vector<int> cls(nc);
     std::vector<double> cent(nc);
-    for (int c = 0; c < nc; c++) {
-        double sp = 0.0, dl = 0.0, ent = 0.0, blocks = 0.0;
-        for (int b = c * BPC; b < std::min(nb, (c + 1) * BPC); b++)
-            if (hb[3 * (size_t)b + 2]) { sp += hb[3 * (size_t)b]; dl += hb[3 * (size_t)b + 1]; ent += hb[3 * (size_t)b + 2]; blocks += 1.0; }
-        cls[c] = classify(sp, dl, ent, blocks); cent[c] = ent;
+    auto class_chunks = [&]() {
+        for (int c = 0; c < nc; c++) {
+            double sp = 0.0, dl = 0.0, ent = 0.0, blocks = 0.0;
+            bool lng = false;
+            for (int b = c * BPC; b < std::min(nb, (c + 1) * BPC); b++)
+                if (hb[RG_ST * (size_t)b + 2]) {
+                    if (use_long && hb[RG_ST * (size_t)b + 3] > (unsigned)LR_LONG) { lng = true; continue; }       // (its entries would drown the chunk's statistics)
+                    sp += hb[RG_ST * (size_t)b]; dl += hb[RG_ST * (size_t)b + 1]; ent += hb[RG_ST * (size_t)b + 2]; blocks += 1.0;
+                }
+            cls[c] = lng ? 3 : classify(sp, dl, ent, blocks); cent[c] = ent;
+        }
+        for (int c = 0; c < nc; c++) if (cls[c] < 0) cls[c] = c > 0 ? cls[c - 1] : 0;      // empty chunks follow their predecessor
+    };
+    class_chunks();
+    {
+        int longruns = 0;
+        for (int c = 0; c < nc; c++) longruns += cls[c] == 3 && (c == 0 || cls[c - 1] != 3);
+        if (longruns > LR_MAXRUNS) { use_long = false; class_chunks(); }
     }
-    for (int c = 0; c < nc; c++) if (cls[c] < 0) cls[c] = c > 0 ? cls[c - 1] : 0;      // empty chunks follow their predecessor
     struct Run { int c0, c1, k; double ent; };
     std::vector<Run> runs;
     for (int c = 0; c < nc; c++) {
@@ -1459,10 +1484,17 @@ static bool ranges_chosen(const CsrPart &P, hipStream_t s)
     const double min_ent = mode > 0 ? 1.0 : (double)(1 << 18);
     for (;;) {
         if (runs.size() < 2) break;
+        // (a stretch of long rows never joins a neighbour: it would take the neighbour's one-window kernels away)
+        auto weight = [&](size_t i) { return runs[i].k == 3 ? 1e300 : runs[i].ent; };
         size_t w = 0;
-        for (size_t i = 1; i < runs.size(); i++) if (runs[i].ent < runs[w].ent) w = i;
-        if (runs[w].ent >= min_ent && runs.size() <= (size_t)RG_MAX) break;
-        const size_t to = w == 0 ? 1 : (w + 1 == runs.size() ? w - 1 : (runs[w - 1].ent >= runs[w + 1].ent ? w - 1 : w + 1));
+        for (size_t i = 1; i < runs.size(); i++) if (weight(i) < weight(w)) w = i;
+        if (weight(w) >= min_ent && runs.size() <= (size_t)RG_MAX) break;
+        if (runs[w].k == 3) return false;                   // (more stretches than ranges even so: no split)
+        size_t to = w == 0 ? 1 : (w + 1 == runs.size() ? w - 1 : (runs[w - 1].ent >= runs[w + 1].ent ? w - 1 : w + 1));
+        if (runs[to].k == 3) {                              // (not into a stretch of long rows either, where there is another neighbour)
+            const size_t other = to == w + 1 ? (w > 0 ? w - 1 : to) : (w + 1 < runs.size() ? w + 1 : to);
+            if (runs[other].k != 3) to = other;
+        }
         runs[to].c0 = std::min(runs[to].c0, runs[w].c0); runs[to].c1 = std::max(runs[to].c1, runs[w].c1); runs[to].ent += runs[w].ent;
         runs.erase(runs.begin() + (long)w);
         for (size_t i = 0; i + 1 < runs.size();)      // neighbours of one class become one stretch
@@ -1476,6 +1508,20 @@ static bool ranges_chosen(const CsrPart &P, hipStream_t s)
     cutb[0] = 0; cutb[runs.size()] = nb;
     for (size_t i = 1; i < runs.size(); i++) {
         const int ka = runs[i - 1].k;
+        if (runs[i].k == 3 || ka == 3) {
+            // around long rows the cut hugs the blocks that hold them: in front of the first such block of the stretch's first chunk,
+            // behind the last one of its last chunk (the other blocks of those chunks belong to the neighbours)
+            int at;
+            if (runs[i].k == 3) {
+                at = runs[i].c0 * BPC;
+                while (at < std::min(nb, (runs[i].c0 + 1) * BPC) && block_class(at) != 3) at++;
+            } else {
+                at = std::min(nb, runs[i].c0 * BPC);
+                while (at > (runs[i].c0 - 1) * BPC && block_class(at - 1) != 3) at--;
+            }
+            cutb[i] = std::max(at, cutb[i - 1]);
+            continue;
+        }
         const int b0 = std::max(cutb[i - 1], (runs[i].c0 - 1) * BPC), b1 = std::min(nb, (runs[i].c0 + 1) * BPC);
         int wrong = 0;
         for (int b = b0; b < b1; b++) { const int k = block_class(b); wrong += k == ka; }     // cut at b0: every block of class a on the wrong side
@@ -1506,6 +1552,7 @@ static bool ranges_chosen(const CsrPart &P, hipStream_t s)
         // a stretch classed as scattered takes the binned product where it is eligible at all (its own mean span may sit just
         // under the whole-matrix threshold: the class was decided chunk by chunk)
         if (runs[i].k == 2 && P.bn_mode < 0 && V.nnz >= (1 << 22)) V.bn_mode = 1;
+        if (runs[i].k == 3) V.lr_mode = 1;
         R->parts.push_back(V); R->r0.push_back(r0); R->seen.push_back(nullptr);
     }
     if (R->parts.size() < 2) { delete R; return false; }
@@ -1516,6 +1563,105 @@ static bool ranges_chosen(const CsrPart &P, hipStream_t s)
         std::fprintf(stderr, "\n");
     }
     return true;
+}
+
+// ---- rows far longer than an LDS window (class 3 of the row ranges) -----------------------------------------------------------
+// Every row of the stretch is cut into chunks of LR_CHUNK entries; one workgroup sums a chunk (strided over the lanes, four entries in
+// flight per lane, a fixed tree at the end), one thread per row then adds the row's chunk sums in chunk order: the same bits from call to
+// call.  The stretch is small (a few 64-row blocks around the long rows), so the lists are built on the host from its row pointers.
+constexpr int LR_CHUNK = 8192;
+struct LongRowPlan {
+    int nitems = 0;
+    int *k0 = nullptr, *k1 = nullptr;   // [nitems] absolute entry offsets of the chunks
+    int *first = nullptr;               // [n_rows + 1] first chunk of every row
+    double *partial = nullptr;          // [nitems]
+};
+
+__global__ __launch_bounds__(VB) void k_lr_partial(const int *__restrict__ k0, const int *__restrict__ k1, const int *__restrict__ col,
+                                                   const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ partial,
+                                                   const int *done)
+{
+    __shared__ double sh[VB / 64];
+    if (done && *done) return;
+    const int a = k0[blockIdx.x], b = k1[blockIdx.x];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int k = a + (int)threadIdx.x;
+    for (; k + 3 * VB < b; k += 4 * VB) {
+        int c[4]; double v[4], xv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { c[q] = col[k + q * VB]; v[q] = val[k + q * VB]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) xv[q] = x[c[q]];
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = fma(v[q], xv[q], acc[q]);
+    }
+    for (int q = 0; k < b; k += VB, q++) acc[q] = fma(val[k], x[col[k]], acc[q]);
+    double t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    t = wave_sum(t);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == WSUM_LANE) sh[w] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sh[0];
+#pragma unroll
+        for (int q = 1; q < VB / 64; q++) r += sh[q];
+        partial[blockIdx.x] = r;
+    }
+}
+
+__global__ __launch_bounds__(VB) void k_lr_rows(int n, const int *__restrict__ first, const double *__restrict__ partial, double *__restrict__ y,
+                                                const int *done)
+{
+    if (done && *done) return;
+    const int r = blockIdx.x * VB + threadIdx.x;
+    if (r >= n) return;
+    double t = 0.0;
+    for (int i = first[r]; i < first[r + 1]; i++) t += partial[i];
+    y[r] = t;
+}
+
+static void long_rows_free(const CsrPart &P)
+{
+    LongRowPlan *L = static_cast<LongRowPlan *>(P.lr_plan);
+    if (!L) return;
+    for (void *p : {(void *)L->k0, (void *)L->k1, (void *)L->first, (void *)L->partial}) if (p) (void)hipFree(p);
+    delete L;
+    P.lr_plan = nullptr;
+}
+
+static int long_rows_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done)
+{
+    const int n = P.n_rows;
+    LongRowPlan *L = static_cast<LongRowPlan *>(P.lr_plan);
+    if (!L) {
+        PlanTimer timer(P, s);
+        std::vector<int> rp((size_t)n + 1);
+        HIPCHK(hipMemcpyAsync(rp.data(), P.rowptr, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<int> k0, k1, first((size_t)n + 1);
+        for (int r = 0; r < n; r++) {
+            first[r] = (int)k0.size();
+            for (long a = rp[r]; a < rp[r + 1]; a += LR_CHUNK) { k0.push_back((int)a); k1.push_back((int)std::min<long>(rp[r + 1], a + LR_CHUNK)); }
+        }
+        first[n] = (int)k0.size();
+        L = new LongRowPlan();
+        L->nitems = (int)k0.size();
+        const size_t ni = std::max<size_t>(1, k0.size());
+        bool ok = hipMalloc(&L->k0, sizeof(int) * ni) == hipSuccess && hipMalloc(&L->k1, sizeof(int) * ni) == hipSuccess &&
+                  hipMalloc(&L->first, sizeof(int) * ((size_t)n + 1)) == hipSuccess && hipMalloc(&L->partial, sizeof(double) * ni) == hipSuccess;
+        if (ok && L->nitems)
+            ok = hipMemcpyAsync(L->k0, k0.data(), sizeof(int) * k0.size(), hipMemcpyHostToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(L->k1, k1.data(), sizeof(int) * k1.size(), hipMemcpyHostToDevice, s) == hipSuccess;
+        if (ok) ok = hipMemcpyAsync(L->first, first.data(), sizeof(int) * first.size(), hipMemcpyHostToDevice, s) == hipSuccess &&
+                     hipStreamSynchronize(s) == hipSuccess;          // (the host vectors go out of scope)
+        P.lr_plan = L;
+        if (!ok) { long_rows_free(P); return fail(hipGetLastError(), "long-row plan", __FILE__, __LINE__); }
+    }
+    if (L->nitems) hipLaunchKernelGGL(k_lr_partial, dim3(L->nitems), dim3(VB), 0, s, L->k0, L->k1, P.col, P.val, x, L->partial, done);
+    hipLaunchKernelGGL(k_lr_rows, dim3((n + VB - 1) / VB), dim3(VB), 0, s, n, L->first, L->partial, y, done);
+    HIPCHK(hipGetLastError());
+    P.last_kernel = "k_lr_partial + k_lr_rows (long rows multiplied in chunks of 8192 entries)";
+    return 0;
 }
 
 static void ranges_free(const CsrPart &P)
@@ -1538,6 +1684,8 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
     const int n = P.n_rows;
     const unsigned xb = PUSH ? (unsigned)(pp.nblocks + pp.nrecv) : 0u;       // pushing blocks in front of the grid, receiving blocks behind it
     if constexpr (sizeof(V) == 8 && !ACC && !PUSH) {
+        if (n > 0 && P.lr_mode == 1)        // a range of long rows (ranges_chosen, class 3)
+            return long_rows_launch(P, reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), s, done);
         if (n > 0 && (variant == 0 || variant == -1) && ranges_chosen(P, s)) {
             RangePlan *R = static_cast<RangePlan *>(P.rg_plan);
             bool changed = false;
@@ -2271,6 +2419,7 @@ static int alloc_part(CsrPart &P, int n_rows, long nnz, bool cplx)
 
 void free_part(CsrPart &P)
 {
+    long_rows_free(P);
     ranges_free(P);
     binned_free(P);
     tiled_free(P);
@@ -2640,6 +2789,7 @@ static int64_t part_traffic_model(const CsrPart &P)
     const int64_t n = P.n_rows, ncols = P.n_cols > 0 ? P.n_cols : P.n_rows;
     const int64_t vectors = 4 * (n + 1) + 8 * ncols + 8 * n;       // row pointers, x once, y
     const int64_t nb = (n + P.pk_R - 1) / P.pk_R;
+    if (std::strncmp(k, "k_lr_", 5) == 0) return 12 * P.nnz + vectors;       // CSR as it is, the chunk lists are small
     if (std::strncmp(k, "k_bin_", 6) == 0) return binned_traffic_bytes(P);
     if (std::strncmp(k, "k_tile", 6) == 0) return tiled_traffic_bytes(P);
     if (std::strncmp(k, "k_spmv_ldsp", 11) == 0)       // values + packed columns (run blocks: row 0's columns only) + two words per block

@@ -229,6 +229,8 @@ struct CsrPart {
     mutable int rg_mode = -1;      // -1 auto (>= 4M entries), 0 never, 1 whenever two classes are found
     mutable int rg_state = 0;      // 0 not tried, 1 split, -1 one range
     mutable void *rg_plan = nullptr;
+    int lr_mode = 0;               // a view only: 1 = rows far longer than an LDS window live here (csr.hip: long_rows_launch)
+    mutable void *lr_plan = nullptr;
     mutable const char *last_kernel = "";   // name of the kernel family the latest product used
     mutable double plan_ms = 0.0;           // host time spent choosing a kernel family and building its copy of the matrix (first product)
 };

@@ -284,3 +284,66 @@ def test_random_class_layouts(port):
                 assert nr == 0 or mode == -1
         A.destroy()
     assert seen_ranges >= 12        # the split really was exercised
+
+
+def test_arrow_matrix_dense_rows_get_their_own_range(port):
+    """A banded SPD matrix with dense rows and columns (constraint / mean-value rows: 300,000, 120,000 and 60,000 entries in rows of a
+    300,000-row system).  One such row makes its 64-row block larger than any LDS window; left in the part, it sends ALL rows to the
+    window-by-window kernel and one workgroup walks the dense row alone.  The row ranges cut the blocks that hold them out (class 3) and
+    multiply those rows in chunks; the rest keeps the one-window kernels.  A.x and CG against the oracle."""
+    import time
+    import scipy.sparse as sp
+    from liblcg_amd import _lib, api
+    from oracle import pyoracle as po
+    lib = _lib.load()
+    rng = np.random.default_rng(314)
+    n = 300_000
+    offs = np.unique(np.concatenate([[0], rng.integers(1, 3000, 8)]))
+    diags = [rng.standard_normal(n - o) * 0.1 for o in offs]
+    B = sp.diags(diags, offs, shape=(n, n), format="coo")
+    rows = [B.row, B.col[B.row != B.col]]; cols = [B.col, B.row[B.row != B.col]]; vals = [B.data, B.data[B.row != B.col]]
+    dense = {n - 1: n - 1, n // 2 + 17: 120_000, 70_001: 60_000}       # row -> number of off-diagonal entries
+    for r, cnt in dense.items():
+        c = rng.choice(np.setdiff1d(np.arange(n), [r], assume_unique=True), cnt, replace=False) if cnt < n - 1 else np.delete(np.arange(n), r)
+        v = rng.standard_normal(len(c)) * 1e-3
+        rows += [np.full(len(c), r), c]; cols += [c, np.full(len(c), r)]; vals += [v, v]
+    M = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+    M.sum_duplicates()
+    M = M + sp.diags(np.asarray(abs(M).sum(axis=1)).ravel() + 1.0)         # strictly diagonally dominant: SPD
+    M = M.tocsr(); M.sort_indices()
+    rp, ci, v = M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(np.float64)
+    assert len(ci) >= 4_000_000 and int(np.diff(rp).max()) == n
+    A = api.CsrMatrix.from_csr(rp, ci, v)
+    xh = rng.standard_normal(n)
+    x = torch.from_numpy(xh).cuda(); y = torch.empty_like(x)
+    A.spmv(x, y); api.synchronize()
+    first = (C.c_int * 8)()
+    nr = lib.lcg_hip_csr_ranges(A.h, 8, first)
+    name = lib.lcg_hip_csr_last_kernel(A.h).decode()
+    assert nr == 6, (nr, list(first[:nr]), name)                    # band | dense | band | dense | band | dense
+    parts = name.split(" | ")
+    assert [("k_lr_partial" in p) for p in parts] == [False, True, False, True, False, True], name
+    assert all("k_spmv_lds" in p and "ldsw" not in p for p in parts[0::2]), name
+    for r in dense:                                                 # each dense row inside a long-row range of a few 64-row blocks
+        i = max(j for j in range(nr) if first[j] <= r)
+        assert "k_lr_partial" in parts[i] and (first[i + 1] if i + 1 < nr else n) - first[i] <= 4096, (r, i, list(first[:nr]))
+    ref = port.csr_matvec(rp, ci, v, xh)
+    bound = port.csr_matvec(rp, ci, np.abs(v), np.abs(xh))
+    assert float(np.max(np.abs(y.cpu().numpy() - ref) / bound)) <= 1e-13, name
+    y2 = torch.empty_like(x); A.spmv(x, y2); api.synchronize()
+    assert torch.equal(y, y2)                                       # the same bits from call to call
+    t0 = time.perf_counter()
+    for _ in range(20):
+        A.spmv(x, y2)
+    api.synchronize()
+    per = (time.perf_counter() - t0) / 20
+    assert per < 1e-3, per                                          # (the window-by-window kernel alone on the dense row: several ms)
+    # CG through the split product against the oracle's loop
+    xt = rng.standard_normal(n); bh = port.csr_matvec(rp, ci, v, xt)
+    m = torch.zeros(n, dtype=torch.float64, device="cuda")
+    info = api.lcg_solver("lcg_hip_csr_ax", None, m, torch.from_numpy(bh).cuda(), n, api.lcg_default_parameters(epsilon=1e-12, abs_diff=1), A, api.LCG_CG)
+    refs = port.solve(po.LCG_CG, rp, ci, v, bh, para=po.default_para(epsilon=1e-12, abs_diff=1))
+    assert info.ret == refs["ret"] == 0 and abs(info.iterations - refs["iters"]) <= 2, (info.iterations, refs["iters"])
+    mh = m.cpu().numpy()
+    assert float(np.max(np.abs(mh - refs["x"]))) <= 1e-9 * float(np.max(np.abs(xt))) and float(np.max(np.abs(mh - xt))) <= 1e-6
+    A.destroy()
