@@ -1415,7 +1415,23 @@ static bool ranges_chosen(const CsrPart &P, hipStream_t s)
     const int mode = env >= 0 ? env : P.rg_mode;
     const int n = P.n_rows;
     if (mode == 0 || P.end_abs >= 0 || n < 2 * RG_CHUNK || P.n_cols <= 0 || P.nnz <= 0) return false;
-    if (mode < 0 && P.nnz < (1 << 22)) return false;
+    bool only_long = false;             // split for long rows only (small systems)
+    if (mode < 0 && P.nnz < (1 << 22)) {
+        only_long = true;
+        // small systems are not worth several launches -- unless a 64-row block holds many LDS windows of entries (a dense row): then
+        // one workgroup would walk it window by window while the rest of the product takes a few microseconds
+        if (P.nnz < (1 << 17)) return false;
+        int *d = nullptr, h = 0;
+        bool ok = hipMalloc(&d, sizeof(int)) == hipSuccess && hipMemsetAsync(d, 0, sizeof(int), s) == hipSuccess;
+        if (ok) {
+            const int nb64 = (n + PK_R - 1) / PK_R;
+            hipLaunchKernelGGL(k_max_slice, dim3((nb64 + VB - 1) / VB), dim3(VB), 0, s, n, PK_R, P.rowptr, d);
+            ok = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        }
+        if (d) hipFree(d);
+        if (!ok) { (void)hipGetLastError(); return false; }
+        if (h <= 8 * LdsCfg<double>::CH) return false;
+    }
     PlanTimer timer(P, s);
     const int nb = (n + PK_R - 1) / PK_R;
     constexpr int BPC = RG_CHUNK / PK_R;         // blocks per chunk
@@ -1436,9 +1452,9 @@ static bool ranges_chosen(const CsrPart &P, hipStream_t s)
     // (a stretch whose columns are drawn per row but too widely for the tiled product -- its workgroups of 8192 rows would find
     //  fewer entries per 2048-column tile than the tiled plan asks for -- is multiplied like scattered columns: the row-block
     //  kernels, its only other choice, pay a cache line per gather there)
-    auto classify = [](double span_sum, double dl, double ent, double blocks) {
+    auto classify = [only_long](double span_sum, double dl, double ent, double blocks) {
         if (ent <= 0.0 || blocks <= 0.0) return -1;
-        if (dl / ent > 0.5) return 0;
+        if (only_long || dl / ent > 0.5) return 0;
         const double span = span_sum / blocks;
         if (span >= span_threshold()) return 2;
         const double fill = 128.0 * (ent / blocks) / ((span + 8192.0) / 2048.0);
@@ -1481,7 +1497,7 @@ static bool ranges_chosen(const CsrPart &P, hipStream_t s)
         runs.back().c1 = c + 1; runs.back().ent += cent[c];
     }
     // a stretch with fewer entries than a launch of its own is worth joins its larger neighbour (smallest first)
-    const double min_ent = mode > 0 ? 1.0 : (double)(1 << 18);
+    const double min_ent = (mode > 0 || only_long) ? 1.0 : (double)(1 << 18);      // (only_long: the few stretches there are stand for the dense rows)
     for (;;) {
         if (runs.size() < 2) break;
         // (a stretch of long rows never joins a neighbour: it would take the neighbour's one-window kernels away)

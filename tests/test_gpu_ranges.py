@@ -347,3 +347,41 @@ def test_arrow_matrix_dense_rows_get_their_own_range(port):
     mh = m.cpu().numpy()
     assert float(np.max(np.abs(mh - refs["x"]))) <= 1e-9 * float(np.max(np.abs(xt))) and float(np.max(np.abs(mh - xt))) <= 1e-6
     A.destroy()
+
+
+def test_small_system_with_a_dense_row(port):
+    """Below 4M entries the ranges are not tried -- unless a 64-row block holds many LDS windows of entries: 60,000 rows of a 5-point-like
+    band plus one dense row and column.  Only the dense row's block is cut out; the other rows keep one kernel."""
+    import scipy.sparse as sp
+    from liblcg_amd import _lib, api
+    lib = _lib.load()
+    rng = np.random.default_rng(2718)
+    n = 60_000
+    B = sp.diags([rng.standard_normal(n - o) for o in (0, 1, 300)], (0, 1, 300), shape=(n, n), format="coo")
+    r = 31_007
+    c = np.delete(np.arange(n), r); vv = rng.standard_normal(n - 1) * 1e-2
+    M = sp.coo_matrix((np.concatenate([B.data, B.data[B.row != B.col], vv, vv]),
+                       (np.concatenate([B.row, B.col[B.row != B.col], np.full(n - 1, r), c]),
+                        np.concatenate([B.col, B.row[B.row != B.col], c, np.full(n - 1, r)]))), shape=(n, n)).tocsr()
+    M.sum_duplicates(); M.sort_indices()
+    rp, ci, v = M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(np.float64)
+    assert len(ci) < 1_000_000
+    A = api.CsrMatrix.from_csr(rp, ci, v)
+    xh = rng.standard_normal(n)
+    x = torch.from_numpy(xh).cuda(); y = torch.empty_like(x)
+    A.spmv(x, y); api.synchronize()
+    first = (C.c_int * 8)()
+    nr = lib.lcg_hip_csr_ranges(A.h, 8, first)
+    name = lib.lcg_hip_csr_last_kernel(A.h).decode()
+    assert nr == 3 and first[1] == (r // 64) * 64 and first[2] == first[1] + 64, (nr, list(first[:nr]), name)
+    assert "k_lr_partial" in name.split(" | ")[1] and "k_lr_" not in name.split(" | ")[0] + name.split(" | ")[2], name
+    ref = port.csr_matvec(rp, ci, v, xh)
+    bound = port.csr_matvec(rp, ci, np.abs(v), np.abs(xh))
+    assert float(np.max(np.abs(y.cpu().numpy() - ref) / bound)) <= 1e-13, name
+    A.destroy()
+    # the same band without the dense row: one kernel, no ranges
+    M0 = (B + sp.triu(B, 1).T).tocsr(); M0.sort_indices()
+    A0 = api.CsrMatrix.from_csr(M0.indptr.astype(np.int32), M0.indices.astype(np.int32), M0.data.astype(np.float64))
+    A0.spmv(x, y); api.synchronize()
+    assert lib.lcg_hip_csr_ranges(A0.h, 8, first) == 0, lib.lcg_hip_csr_last_kernel(A0.h).decode()
+    A0.destroy()
