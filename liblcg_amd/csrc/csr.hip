@@ -922,64 +922,83 @@ __device__ __forceinline__ double run1_block(int b, int wv, int n, int LP, const
         const int *bcol = pcols + 4 * (long)po;
         double *mine = wlds + (size_t)wv * 64 * LP;
         const int tot = nrows * L;
-        const float invL = 1.0f / (float)L;
-        double xv[NB];
+        // the batch is as wide as the rows are long (4 / 6 / 8: L is uniform) -- with eight slots for every block a tridiagonal system
+        // issued eight value loads and eight gathers per lane for three entries, the 5-point Laplacian for five
+        auto run_rows = [&](auto nbt) {
+            constexpr int NBX = decltype(nbt)::value;
+            static_assert(NBX % T == 0, "entry k goes to partial sum k mod T");
+            const float invL = 1.0f / (float)L;
+            double xv[NBX];
 #pragma unroll
-        for (int q = 0; q < NB; q++) {                  // the gathers of the first batch leave with the values
-            const int c0 = bcol[q < L ? q : 0];
-            xv[q] = x[(q < L && live) ? c0 + lane : 0];
-        }
-        for (int j0 = 0; j0 < L; j0 += NB) {
-            double v[NB];
-#pragma unroll
-            for (int q = 0; q < NB; q++) {
-                const int e = (j0 + q) * 64 + lane;
-                v[q] = val[s + ((j0 + q < L && e < tot) ? e : 0)];
+            for (int q = 0; q < NBX; q++) {                  // the gathers of the first batch leave with the values
+                const int c0 = bcol[q < L ? q : 0];
+                xv[q] = x[(q < L && live) ? c0 + lane : 0];
             }
+            for (int j0 = 0; j0 < L; j0 += NBX) {
+                double v[NBX];
 #pragma unroll
-            for (int q = 0; q < NB; q++) {
-                const int e = (j0 + q) * 64 + lane;
-                if (j0 + q < L && e < tot) {
-                    int r = (int)(((float)e + 0.5f) * invL);        // e / L (e < 2^16: exact after the correction below)
-                    r -= r * L > e; r += (r + 1) * L <= e;
-                    mine[r * LP + (e - r * L)] = v[q];
+                for (int q = 0; q < NBX; q++) {
+                    const int e = (j0 + q) * 64 + lane;
+                    v[q] = val[s + ((j0 + q < L && e < tot) ? e : 0)];
+                }
+#pragma unroll
+                for (int q = 0; q < NBX; q++) {
+                    const int e = (j0 + q) * 64 + lane;
+                    if (j0 + q < L && e < tot) {
+                        int r = (int)(((float)e + 0.5f) * invL);        // e / L (e < 2^16: exact after the correction below)
+                        r -= r * L > e; r += (r + 1) * L <= e;
+                        mine[r * LP + (e - r * L)] = v[q];
+                    }
                 }
             }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double *row = mine + lane * LP;
-        for (int k0 = 0; k0 < L; k0 += NB) {
-            if (k0 > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double *row = mine + lane * LP;
+            for (int k0 = 0; k0 < L; k0 += NBX) {
+                if (k0 > 0) {
 #pragma unroll
-                for (int q = 0; q < NB; q++) {
-                    const int k = k0 + q;
-                    const int c0 = bcol[k < L ? k : 0];
-                    xv[q] = x[(k < L && live) ? c0 + lane : 0];
+                    for (int q = 0; q < NBX; q++) {
+                        const int k = k0 + q;
+                        const int c0 = bcol[k < L ? k : 0];
+                        xv[q] = x[(k < L && live) ? c0 + lane : 0];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NBX; q++) {
+                    const double a = (k0 + q < L && live) ? row[k0 + q] : 0.0;
+                    acc[q % T] = (k0 + q < L) ? fma(a, xv[q], acc[q % T]) : acc[q % T];
                 }
             }
-#pragma unroll
-            for (int q = 0; q < NB; q++) {
-                const double a = (k0 + q < L && live) ? row[k0 + q] : 0.0;
-                acc[q % T] = (k0 + q < L) ? fma(a, xv[q], acc[q % T]) : acc[q % T];
-            }
-        }
+        };
+        if (L <= 4) run_rows(std::integral_constant<int, 4>{});
+        else if (L <= 6) run_rows(std::integral_constant<int, 6>{});
+        else run_rows(std::integral_constant<int, NB>{});
     } else {
         // not a run: every lane walks its own row out of the CSR arrays, NB entries at a time -- all columns and values of a
         // batch requested before the first gather, all gathers before the first product (a one-by-one walk is a chain of
         // 2 L dependent loads, and 13 % of the Laplacian's blocks take this path)
         int rs = 0, re = 0;
         if (live) { rs = rowptr[row0 + lane]; re = rowptr[row0 + lane + 1]; }
-        for (int k0 = rs; __ballot(k0 < re) != 0; k0 += NB) {
-            int c[NB]; double a[NB], xv[NB];
+        // (the batch as wide as the block's longest row needs, like the run blocks above)
+        int longest = re - rs;
+        for (int off = 32; off > 0; off >>= 1) longest = max(longest, __shfl_xor(longest, off, 64));
+        auto walk_rows = [&](auto nbt) {
+            constexpr int NBX = decltype(nbt)::value;
+            static_assert(NBX % T == 0, "entry k goes to partial sum k mod T");
+            for (int k0 = rs; __ballot(k0 < re) != 0; k0 += NBX) {
+                int c[NBX]; double a[NBX], xv[NBX];
 #pragma unroll
-            for (int q = 0; q < NB; q++) { const bool ok = k0 + q < re; c[q] = col[ok ? k0 + q : 0]; a[q] = val[ok ? k0 + q : 0]; }
+                for (int q = 0; q < NBX; q++) { const bool ok = k0 + q < re; c[q] = col[ok ? k0 + q : 0]; a[q] = val[ok ? k0 + q : 0]; }
 #pragma unroll
-            for (int q = 0; q < NB; q++) xv[q] = x[k0 + q < re ? c[q] : 0];
+                for (int q = 0; q < NBX; q++) xv[q] = x[k0 + q < re ? c[q] : 0];
 #pragma unroll
-            for (int q = 0; q < NB; q++) acc[q % T] = (k0 + q < re) ? fma(a[q], xv[q], acc[q % T]) : acc[q % T];
-        }
+                for (int q = 0; q < NBX; q++) acc[q % T] = (k0 + q < re) ? fma(a[q], xv[q], acc[q % T]) : acc[q % T];
+            }
+        };
+        if (longest <= 4) walk_rows(std::integral_constant<int, 4>{});
+        else if (longest <= 6) walk_rows(std::integral_constant<int, 6>{});
+        else walk_rows(std::integral_constant<int, NB>{});
     }
     double v = acc[0];
 #pragma unroll
