@@ -837,3 +837,42 @@ def test_long_rows_take_packed_columns(api, port):
         assert float(np.max(np.abs(yh - ref) / np.maximum(scale, 1e-300))) <= 1e-13, name
         assert 8 * len(ci) < lib.lcg_hip_csr_last_traffic_model(A.h) < 12 * len(ci) + 40 * n
         A.destroy()
+
+
+def test_odd_shapes_against_the_oracle(api, port):
+    """Shapes no benchmark has (scripts/odd_shapes.py at test size): rows of power-law lengths (most rows a few entries, some thousands),
+    dense diagonal blocks, 200 diagonals, tridiagonal, diagonal only, a diagonal with one dense column -- whatever kernel the automatic
+    choice takes, the product meets the oracle's row-wise bound, and repeats bit for bit."""
+    import scipy.sparse as sp
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    shapes = []
+    n = 120_000
+    lens = np.minimum((rng.pareto(1.3, n) * 4 + 1).astype(np.int64), 3000)
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum(lens)
+    ci = (np.repeat(np.arange(n), lens) + rng.integers(-20000, 20000, rp[-1])) % n
+    shapes.append(("power-law rows", sp.csr_matrix((rng.standard_normal(rp[-1]), ci, rp), shape=(n, n))))
+    shapes.append(("dense blocks", sp.block_diag([sp.csr_matrix(rng.standard_normal((96, 96))) for _ in range(300)], format="csr")))
+    n = 30_000
+    shapes.append(("200 diagonals", sp.diags([rng.standard_normal(n - o) for o in range(0, 2000, 10)], list(range(0, 2000, 10)), shape=(n, n))))
+    n = 1_000_003
+    shapes.append(("tridiagonal", sp.diags([rng.standard_normal(n - 1), rng.standard_normal(n), rng.standard_normal(n - 1)], [-1, 0, 1], shape=(n, n))))
+    shapes.append(("diagonal", sp.diags([rng.standard_normal(n)], [0], shape=(n, n))))
+    n = 400_000
+    shapes.append(("dense column", sp.diags([np.ones(n)], [0], shape=(n, n), format="csr")
+                   + sp.csr_matrix((rng.standard_normal(n), (np.arange(n), np.full(n, 7))), shape=(n, n))))
+    for name, M in shapes:
+        M = M.tocsr(); M.sum_duplicates(); M.sort_indices()
+        n = M.shape[0]
+        rp, ci, v = M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(np.float64)
+        A = api.CsrMatrix.from_csr(rp, ci, v)
+        xh = rng.standard_normal(n)
+        x = torch.from_numpy(xh).cuda(); y = torch.full((n,), 3.0, dtype=torch.float64, device="cuda"); y2 = torch.full_like(y, 4.0)
+        A.spmv(x, y); A.spmv(x, y2); api.synchronize()
+        k = lib.lcg_hip_csr_last_kernel(A.h).decode()
+        assert torch.equal(y, y2), (name, k)
+        ref = port.csr_matvec(rp, ci, v, xh)
+        scale = port.csr_matvec(rp, ci, np.abs(v), np.abs(xh))
+        assert float(np.max(np.abs(y.cpu().numpy() - ref) / np.maximum(scale, 1e-300))) <= 1e-13, (name, k)
+        A.destroy()
