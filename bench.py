@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms work for every N.  The first one, given --gpus N > 1 outside a launcher's environment, starts the second one
+itself (N fresh child processes, one per GPU, on a free port of 127.0.0.1) BEFORE anything touches the GPU, relays rank 0's
+JSON line and exits with the children's code; when they fail or overrun --budget-seconds it still prints one line
+({"value": 0.0, "error": ...}).
+
 One "step" is one CG iteration (lcg.cpp:206-264: A.d, three inner products, three vector
 updates, stop test) executed by lcg_hip_lcg() through the C ABI with inputs resident in HBM.
 The K-step solve is timed `--reps` times (default 5), each bracketed by barrier + synchronise;
@@ -55,6 +60,114 @@ def emit(line):
 
 
 _REAL_STDOUT = 1
+_T0 = float(os.environ.get("LCG_BENCH_T0", time.time()))      # the self-launcher hands its own start time down
+
+
+def time_left(args):
+    """Seconds of --budget-seconds not yet spent (the clock started when the command did)."""
+    return args.budget_seconds - (time.time() - _T0)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks as FRESH child processes (this process never
+    initialises the GPU -- nothing before this point imports torch), one per GPU, rendezvous on a free port of 127.0.0.1; relay rank
+    0's JSON line; exit with the children's code.  A failure or an overrun still leaves ONE line on the standard output."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL and the peer-mapped mailboxes need it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["LCG_BENCH_T0"] = repr(time.time())                # the children's budget clock starts with the launcher's
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    t0 = time.time()
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True, text=True)      # stderr: inherited
+    lines, result_at = [], []
+
+    def is_result(cand):
+        cand = cand.strip()
+        if not (cand.startswith("{") and cand.endswith("}")):
+            return False
+        try:
+            d = json.loads(cand)
+        except ValueError:
+            return False
+        return "metric" in d or "dry_launch" in d
+
+    def reader():
+        for ln in p.stdout:
+            lines.append(ln)
+            if is_result(ln):
+                result_at.append(time.time())
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    killed = ""
+    grace = float(os.environ.get("LCG_BENCH_EXIT_GRACE", 60.0))
+    while p.poll() is None:
+        now = time.time()
+        if result_at and now - result_at[-1] > grace:
+            killed = f"the ranks did not exit within {grace:.0f} s of their result line: ended by the launcher"
+        elif now - t0 > args.budget_seconds + 60.0:
+            killed = f"no result after {now - t0:.0f} s (budget {args.budget_seconds:.0f} s + 60 s): ranks ended by the launcher"
+        if killed:
+            for sig, wait in ((signal.SIGTERM, 15.0), (signal.SIGKILL, 15.0)):
+                try:
+                    os.killpg(p.pid, sig)      # exactly the session started above
+                except ProcessLookupError:
+                    break
+                try:
+                    p.wait(timeout=wait)
+                    break
+                except subprocess.TimeoutExpired:
+                    pass
+            break
+        time.sleep(0.2)
+    th.join(timeout=10.0)
+    line = next((ln.strip() for ln in reversed(lines) if is_result(ln)), None)
+    rc = p.returncode if p.returncode is not None else 1
+    if line is not None and killed:         # measured, reported, and then stuck in its teardown: the measurement stands, flagged
+        got = json.loads(line)
+        got["launcher_note"] = killed
+        line, rc = json.dumps(got), 0
+    elif line is None:
+        line = json.dumps({"metric": "cg_iterations_per_sec", "unit": "iter/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                           "value": 0.0, "ms_per_step": None, "error": killed or f"the ranks ended with code {rc} and no result line",
+                           "config": {"workload": workload_name(args.pattern, args.band, args.npairs, args.solver)}})
+        rc = rc or 1
+    emit(line)
+    return rc
+
+
+def dry_launch(args):
+    """The launch rehearsed on CPUs (tests/test_bench_launch.py): every rank joins a gloo group under the launcher's environment and
+    rank 0 reports who came.  No GPU call, no library load."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if os.environ.get("LCG_BENCH_DRY_FAIL") == str(rank):      # lets a test watch a rank die before it reports
+        raise SystemExit(3)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = torch.tensor([rank, int(os.environ.get("LOCAL_RANK", -1)), world, os.getpid()], dtype=torch.int64)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    if rank == 0:
+        emit(json.dumps({"dry_launch": True, "n_gpus": world, "gpus_asked": args.gpus, "ranks": [int(g[0]) for g in got],
+                         "local_ranks": [int(g[1]) for g in got], "world_sizes": [int(g[2]) for g in got],
+                         "pids": [int(g[3]) for g in got], "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+                         "steps": args.steps, "warmup": args.warmup}))
+    dist.barrier()
+    dist.destroy_process_group()
+    time.sleep(float(os.environ.get("LCG_BENCH_DRY_SLEEP", 0)))        # lets a test watch the launcher end ranks that overrun
 
 
 def main():
@@ -80,7 +193,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not collect roofline.traffic with rocprofv3 child runs (N = 1); use the committed figure")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--budget-seconds", type=float, default=540.0,
+                    help="wall-clock budget of the whole run: optional parts (exchange configurations beyond the RCCL baseline, variants, "
+                         "live counters) are skipped when the clock says they no longer fit; the self-launcher ends its children 60 s after it")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="rehearse the launch only: every rank reports its RANK / LOCAL_RANK / WORLD_SIZE over gloo, no GPU is touched")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if args.dry_launch:
+        return dry_launch(args)
 
     import numpy as np
     import torch
@@ -90,8 +212,7 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    args.gpus = world       # inside a launcher its environment decides
     torch.cuda.set_device(local_rank)
     lib = _lib.load()
     rc = lib.lcg_hip_init(local_rank)
@@ -321,12 +442,19 @@ def main():
         achieved = shard_bytes / (ax_us * 1e-6) / 1e9
         kernel = lib.lcg_hip_csr_last_kernel(S.A.h).decode()
         traffic, source = pmc_traffic(args.pattern, kernel, S.nnz_local) if world == 1 and not sharded else (None, "not collected for sharded runs")
-        if world == 1 and not sharded and not args.no_live_pmc:
+        if world == 1 and not sharded:
             # the same counters collected NOW, on this box, by two rocprofv3 child runs of the product alone (counters cannot be read
-            # from inside this process): the committed figure above is the fallback when the profiler is not available
-            live, why = live_pmc_traffic(args, kernel)
+            # from inside this process), each held to 75 s and started only while more than half of the budget is left: the
+            # committed figure is the fallback, and both are always in the line under fixed keys
+            out["traffic_committed"] = {"traffic": traffic, "traffic_source": source}
+            if args.no_live_pmc:
+                live, why = None, "--no-live-pmc"
+            elif time_left(args) < 0.5 * args.budget_seconds:
+                live, why = None, f"{time_left(args):.0f} s of the budget left"
+            else:
+                live, why = live_pmc_traffic(args, kernel)
+            out["traffic_live"] = {"traffic": live, "traffic_source": why if live else f"not collected: {why}"}
             if live:
-                out["traffic_committed"] = {"traffic": traffic, "traffic_source": source}
                 traffic, source = live, why
             else:
                 source = f"{source}; live collection skipped: {why}"
@@ -340,6 +468,9 @@ def main():
                                               "carries (rocprofv3 lists the two separately: profiles/*_kernel_stats.csv)")
     if comm_probe is not None:
         out["comm_probe"] = comm_probe
+    if sharded:
+        out["rccl_ranks"] = int(lib.lcg_hip_comm_size())       # what the library's RCCL communicator spans (not torch's)
+        out["torch_world_size"] = dist.get_world_size()
 
     if rank == 0 and world == 1 and "roofline" in out:
         # what THIS box's memory system sustains on a plain device copy (1 GiB read + 1 GiB written),
@@ -394,7 +525,12 @@ def variants(args, System, S, lib, api, n, spmv_bytes, iteration_bytes):
     rows constant diagonals, 20 % scrambled -- multiplied range by range (the kernel string names the ranges); `stencil27`: a real
     27-point stencil on a cubic grid of ~0.8 x --rows points (run blocks + template blocks)."""
     res = {}
+    dearest = 0.0
     for pattern in ("constant_diagonals", "row_random_band", "scrambled", "mixed_rows", "stencil27"):
+        if time_left(args) < 1.5 * dearest + (0 if args.no_cpu_baseline else 1.5 * args.cpu_seconds) + 20.0:
+            res[pattern] = {"skipped": f"{time_left(args):.0f} s of the budget left"}
+            continue
+        t_var = time.time()
         if pattern == S.pattern:
             V, own = S, False
         else:
@@ -416,6 +552,7 @@ def variants(args, System, S, lib, api, n, spmv_bytes, iteration_bytes):
         if own:
             V.A.destroy()
             del V
+        dearest = max(dearest, time.time() - t_var)
     return res
 
 
@@ -468,7 +605,7 @@ def live_pmc_traffic(args, kernel_description):
             cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "-o", "pmc", "--",
                    sys.executable, os.path.join(ROOT, "scripts", "ax_variants.py"), "--rows", str(args.rows), "--band", str(args.band),
                    "--patterns", str(PATTERNS[args.pattern]), "--modes", "auto", "--reps", "3", "--dot", "1"]
-            p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=180)
+            p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=75)
             if p.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} ended with {p.returncode}"
             got = {}
@@ -537,6 +674,7 @@ def run_sharded(args, S, lib, api, partition, dist, torch, n, rank, barrier, all
         return not anybody(failed)
 
     # ---- 1. the north-star configuration: RCCL all-gather of x, RCCL all-reduce of the dots --------------------------
+    t_phase = time.time()
     A.distribute(n, 0)
     S.rhs()
     x2 = 2.0 * xt + 1.0
@@ -551,6 +689,8 @@ def run_sharded(args, S, lib, api, partition, dist, torch, n, rank, barrier, all
     out["ms_per_step_rccl_allgather"] = 1e3 * base_med / args.steps
     tried = {"all-gather + rccl all-reduce": args.steps / base_med}
     best = (base_med, 0, False, base_times, base_ax_us, base_ax_calls)
+    cost = time.time() - t_phase        # what one configuration costs on this node (plan, guard, timed solves); the dearest seen so far
+    skipped = []
 
     # ---- 2. cheaper exchanges, each admitted only if it reproduces the all-gather product on this node ----------------
     want = int(os.environ.get("LCG_HIP_DIST_MODE", "2"))
@@ -600,10 +740,15 @@ def run_sharded(args, S, lib, api, partition, dist, torch, n, rank, barrier, all
             if mode == 0 and not direct_sum:
                 continue        # the baseline, measured above
             configs.append((mode, direct_sum))
-    for mode, direct_sum in configs:
+    for mode, direct_sum in reversed(configs):      # the cheapest exchange first: if the clock allows only one, it is the one that matters
         if (mode == 2 or direct_sum) and not p2p:
             continue
         name = f"{labels[mode]} + {'direct' if direct_sum else 'rccl'} all-reduce"
+        # the clock: this configuration + the final measurement of the winner + the probes must still fit (every rank votes)
+        if anybody(time_left(args) < 2.5 * cost + 30.0):
+            skipped.append(name)
+            continue
+        t_phase = time.time()
         if p2p:
             lib.lcg_hip_p2p_enable(1 if (direct_sum or mode == 2) else 0)   # mode 2's plan is agreed over the mailboxes
         if not attempt(lambda: A.distribute(n, mode), f"exchange mode {mode} unavailable"):
@@ -633,6 +778,7 @@ def run_sharded(args, S, lib, api, partition, dist, torch, n, rank, barrier, all
         if p2p and anybody(lib.lcg_hip_p2p_status() < 0):
             teardown_p2p("an exchange timed out")
         attempt(lambda: A.distribute(n, 0), "back to all-gather")
+        cost = max(cost, time.time() - t_phase)
     # ---- 3. the best validated configuration, measured like the baseline ------------------------------------------------
     _, mode, direct_sum, times, ax_us, ax_calls = best
     if p2p:
@@ -657,6 +803,7 @@ def run_sharded(args, S, lib, api, partition, dist, torch, n, rank, barrier, all
             attempt(lambda: A.distribute(n, 0), "back to all-gather")
             times, ax_us, ax_calls = base_times, base_ax_us, base_ax_calls
     probe = {"configurations_it_per_s": {k: round(v, 1) for k, v in tried.items()},
+             "configurations_skipped_for_the_clock": skipped, "seconds_per_configuration": round(cost, 1),
              "chosen": f"{labels[mode]} + {'direct' if direct_sum else 'rccl'} all-reduce",
              "direct_paths": "connected and self-tested" if p2p else f"not used: {p2p_why}"}
     # what the two collectives of an iteration cost on this node's links (dependent back-to-back calls)
