@@ -853,7 +853,7 @@ static int remote_sums_launch(lcg_hip_csr *A, const double *xfull, double *out, 
     if (nr <= 0) return 0;
     const double mean_r = (double)A->remc.nnz / nr;
     int T = mean_r <= 8.0 ? 1 : (mean_r <= 24.0 ? 2 : 4);
-    if (const char *e = std::getenv("LCG_HIP_REMOTE_T")) T = atoi(e);
+    if (const char *e = lab_env("LCG_HIP_REMOTE_T")) T = atoi(e);
     if (T != 1 && T != 2 && T != 4) return fail(hipErrorInvalidValue, "bad lanes-per-row for the remote-column product", __FILE__, __LINE__);
     const unsigned g = (unsigned)(((long)nr * T + VB - 1) / VB);
 #define RS_LAUNCH(TT)                                                                                                \
@@ -911,13 +911,13 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
         const double mean_l = A->n_rows ? (double)A->loc.nnz / A->n_rows : 0.0;
         // test hook (tests/test_gpu_direct.py): this rank computes but never pushes -- what a dead link looks like to its neighbours
         static const bool withhold = std::getenv("LCG_HIP_TEST_WITHHOLD_PUSH") != nullptr;
-        static const bool one_stream_ = [] { const char *e = std::getenv("LCG_HIP_DIRECT_STREAMS"); return !(e && atoi(e) == 2); }();
-        static const bool land_ = [] { const char *e = std::getenv("LCG_HIP_DIRECT_LAND"); return e && atoi(e) == 1; }();
+        static const bool one_stream_ = [] { const char *e = lab_env("LCG_HIP_DIRECT_STREAMS"); return !(e && atoi(e) == 2); }();
+        static const bool land_ = [] { const char *e = lab_env("LCG_HIP_DIRECT_LAND"); return e && atoi(e) == 1; }();
         // The receiving blocks ride in the tail of the product's grid (devcommon.hpp: recv_block) instead of being a kernel of their
         // own behind it: one launch and one kernel boundary less per product, and the copies run beside the product's last blocks.
         // They are the LAST blocks to be dispatched and few (one per 4096 doubles received), so they cannot keep the pushing
         // blocks of a rank that shares this GPU from running.  LCG_HIP_RECV_KERNEL=1: k_recv as its own kernel again (A/B runs).
-        static const bool recv_kernel_ = [] { const char *e = std::getenv("LCG_HIP_RECV_KERNEL"); return e && atoi(e) == 1; }();
+        static const bool recv_kernel_ = [] { const char *e = lab_env("LCG_HIP_RECV_KERNEL"); return e && atoi(e) == 1; }();
         const bool recv_in_tail = !recv_kernel_ && !withhold && one_stream_ && !land_ && wp.n > 0;
         if (recv_in_tail) {
             pp.nrecv = cp.nblocks; pp.rnseg = cp.nseg; pp.wp = wp; pp.rst = c.in_solve ? c.state : nullptr;
@@ -949,7 +949,7 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
         // my wait) and without a fork event (they depend on the neighbours' flags, not on this stream);
         // their sums land in the half of rem_y that belongs to this call and are added to y behind one
         // join event.  Measured equal on the 8-way shard (114.2 vs 114.6 us): the join costs what it hides.
-        static const bool one_stream = [] { const char *e = std::getenv("LCG_HIP_DIRECT_STREAMS"); return !(e && atoi(e) == 2); }();
+        static const bool one_stream = [] { const char *e = lab_env("LCG_HIP_DIRECT_STREAMS"); return !(e && atoi(e) == 2); }();
         hipStream_t rs = one_stream ? c.stream : c.comm_stream;
         Direct *D = static_cast<Direct *>(A->direct);
         // LCG_HIP_DIRECT_LAND=1: the remote-column product gathers straight from the landing zone (every block
@@ -958,10 +958,10 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
         // with one rank per GPU that is harmless, but ranks that share a GPU (the 4-rank stress of
         // scripts/direct_stress.py) fill every CU slot with spinning blocks and starve the product whose
         // pushing blocks they wait for.  k_recv spins with a few dozen blocks only.
-        static const int land_env = [] { const char *e = std::getenv("LCG_HIP_DIRECT_LAND"); return e ? atoi(e) : 0; }();
+        static const int land_env = [] { const char *e = lab_env("LCG_HIP_DIRECT_LAND"); return e ? atoi(e) : 0; }();
         const bool sparse_halo = D->recv_total * 4 <= (long long)(A->n_global - A->n_rows);
         const bool land = land_env == 1 && one_stream && A->remc.n_rows > 0;
-        if (std::getenv("LCG_HIP_DEBUG_DIRECT") && D->calls == 1)
+        if (debug_on() && D->calls == 1)
             std::fprintf(stderr, "[lcg_hip] direct: land=%d (env %d, sparse %d, recv %lld, n_global %lld, rows %d) one_stream=%d\n", (int)land,
                          land_env, (int)sparse_halo, D->recv_total, (long long)A->n_global, A->n_rows, (int)one_stream);
         const double *landing = D->recv + (size_t)(D->calls & 1) * D->half;
@@ -975,7 +975,7 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
             double *sums = A->rem_y + (size_t)(D->calls & 1) * w * (size_t)nr;
             const double mean_r = (double)A->remc.nnz / nr;
             int T = mean_r <= 8.0 ? 1 : (mean_r <= 24.0 ? 2 : 4);
-            if (const char *e = std::getenv("LCG_HIP_REMOTE_T")) T = atoi(e);
+            if (const char *e = lab_env("LCG_HIP_REMOTE_T")) T = atoi(e);
 #define REMOTE_LAUNCH(TT, TOY, OUT)                                                                                  \
     do {                                                                                                             \
         const unsigned g = (unsigned)(((long)nr * TT + VB - 1) / VB);                                                \
@@ -1055,7 +1055,7 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
     // ... followed there by the product of the remote columns (few rows: their sums go to rem_y) ...
     int rc = 0;
     if (A->remc.n_rows > 0) {
-        static const bool rowblocks = [] { const char *e = std::getenv("LCG_HIP_REMOTE_ROWBLOCKS"); return e && atoi(e) == 1; }();     // A/B runs
+        static const bool rowblocks = [] { const char *e = lab_env("LCG_HIP_REMOTE_ROWBLOCKS"); return e && atoi(e) == 1; }();     // A/B runs
         const double mean_r = (double)A->remc.nnz / A->remc.n_rows;
         rc = rowblocks ? spmv_launch(A->remc, A->is_complex, 0, mean_r, A->xfull, A->rem_y, false, c.comm_stream, done)
                        : remote_sums_launch(A, A->xfull, A->rem_y, c.comm_stream, done);
@@ -1109,7 +1109,7 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y) { return dist_spmv_imp
 
 int dist_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots, FinishPlan *fp)
 {
-    static const bool off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_SHARDED"); return e && atoi(e) == 0; }();     // A/B runs
+    static const bool off = [] { const char *e = lab_env("LCG_HIP_AX_DOT_SHARDED"); return e && atoi(e) == 0; }();     // A/B runs
     // The step in the finishing kernel's last block (finish_body) is OPT-IN (LCG_HIP_FINISHER=1): measured on the one-rank rehearsal of
     // the 8-way shard it buys nothing -- 101.2 vs 100.4 us per iteration at K = 500, 116.5 vs 114.1 at K = 20 (slow box), 101.2 vs 101.7
     // and 112.9 vs 113.8 (fast box): what a scalar step costs is its chain of dependent memory round trips (partials, mailbox

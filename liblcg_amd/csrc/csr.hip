@@ -535,6 +535,7 @@ __device__ __forceinline__ void ldsp_dot_tail(const DotPlan &dp, int bid, int j0
 // six already), 1696 (20.4 KB, eight: rows of up to 26 entries).
 constexpr int PK_CH_SMALL = 2208;
 constexpr int PK_CH_7 = 1872, PK_CH_8 = 1696;
+static DotPlan ldsp_plain_plan() { DotPlan d; d.ystore = y_store_policy(); return d; }
 static int pk_window(int max_slice)
 {
     static const int env = [] { const char *e = std::getenv("LCG_HIP_PACKED_WINDOW"); return e ? atoi(e) : 0; }();     // A/B runs: least window
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
                 double v = sred[0][rl];
 #pragma unroll
                 for (int j = 1; j < T; j++) v += sred[j][rl];
-                y[row0 + rl] = v;
+                store_y(y + row0 + rl, v, dp.ystore);
                 vfin = v;
             }
         };
@@ -705,7 +706,7 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
             double v = sred[0][rl];
 #pragma unroll
             for (int j = 1; j < T; j++) v += sred[j][rl];
-            y[row0 + rl] = v;
+            store_y(y + row0 + rl, v, dp.ystore);
             vfin = v;
         }
         if (DOT) ldsp_dot_tail(dp, bid, j0, vfin, uv);
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
         double v = sred[0][rl];
 #pragma unroll
         for (int j = 1; j < T; j++) v += sred[j][rl];
-        y[row0 + rl] = v;
+        store_y(y + row0 + rl, v, dp.ystore);
         vfin = v;
     }
     if (DOT) ldsp_dot_tail(dp, bid, j0, vfin, uv);
@@ -1092,18 +1093,18 @@ static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only, int R 
     int *ngr = nullptr, *span = nullptr;
     long total = 0;
     int hspan[4] = {0, 0, 0, 0};
-    static const int runs = [] { const char *e = std::getenv("LCG_HIP_PACKED_RUNS"); return e ? atoi(e) : 1; }();    // 0: A/B runs without run blocks
+    static const int runs = [] { const char *e = lab_env("LCG_HIP_PACKED_RUNS"); return e ? atoi(e) : 1; }();    // 0: A/B runs without run blocks
     bool ok = hipMalloc(&P.pk_base, sizeof(int) * (size_t)nb) == hipSuccess && hipMalloc(&P.pk_ofs, sizeof(int) * ((size_t)nb + 1)) == hipSuccess &&
               hipMalloc(&ngr, sizeof(int) * (size_t)nb) == hipSuccess && hipMalloc(&span, 4 * sizeof(int)) == hipSuccess &&
               hipMemsetAsync(span, 0, 4 * sizeof(int), s) == hipSuccess;
     if (ok) {
         // (k_pk_meta: 0 no run blocks, 1 run blocks and template blocks, 2 run blocks only)
-        static const int tpls = [] { const char *e = std::getenv("LCG_HIP_PACKED_TEMPLATES"); return e ? atoi(e) : 1; }();    // 0: A/B runs without template blocks
+        static const int tpls = [] { const char *e = lab_env("LCG_HIP_PACKED_TEMPLATES"); return e ? atoi(e) : 1; }();    // 0: A/B runs without template blocks
         hipLaunchKernelGGL(k_pk_meta, dim3(nb), dim3(64), 0, s, n, P.rowptr, P.col, P.pk_base, ngr, span, (runs && R == PK_R) ? (tpls ? 1 : 2) : 0, R);
         ok = hipMemcpyAsync(hspan, span, 4 * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     }
     if (ok) ok = runs_only ? (runs && 2L * (hspan[2] + hspan[3]) >= nb) : hspan[0] < PK_SPAN;     // runs only: worth it when most blocks are runs or templates
-    static const int force_bits = [] { const char *e = std::getenv("LCG_HIP_PACKED_BITS"); return e ? atoi(e) : 0; }();   // 21: A/B runs
+    static const int force_bits = [] { const char *e = lab_env("LCG_HIP_PACKED_BITS"); return e ? atoi(e) : 0; }();   // 21: A/B runs
     const int bits = runs_only ? 0 : ((hspan[0] < (1 << 18) && force_bits != 21) ? 18 : 21);     // seven 18-bit columns per group where the blocks are narrow enough
     if (ok) {
         hipLaunchKernelGGL(k_pk_groups, dim3((nb + VB - 1) / VB), dim3(VB), 0, s, nb, runs_only ? 0 : 128 / bits, ngr);
@@ -1156,7 +1157,7 @@ __global__ __launch_bounds__(64) void k_span_sum(int n, const int *__restrict__ 
 
 static double span_threshold()
 {   // LCG_HIP_BINNED_SPAN: mean block span (columns) from which the automatic choice takes the binned product
-    static const double v = [] { const char *e = std::getenv("LCG_HIP_BINNED_SPAN"); return e ? atof(e) : (double)(1 << 20); }();
+    static const double v = [] { const char *e = lab_env("LCG_HIP_BINNED_SPAN"); return e ? atof(e) : (double)(1 << 20); }();
     return v;
 }
 
@@ -1283,7 +1284,7 @@ static bool line_ratio_measured(const CsrPart &P, hipStream_t s)
 }
 static double line_ratio_threshold()
 {   // LCG_HIP_LINE_RATIO: least share of gathers that have a line of their own for the tiled / binned products to be considered
-    static const double v = [] { const char *e = std::getenv("LCG_HIP_LINE_RATIO"); return e ? atof(e) : 0.5; }();
+    static const double v = [] { const char *e = lab_env("LCG_HIP_LINE_RATIO"); return e ? atof(e) : 0.5; }();
     return v;
 }
 
@@ -1291,13 +1292,13 @@ static double tiled_line_ratio_threshold()
 {   // the same for the tiled product alone.  Measured at N = 1e7, 33 per row, columns drawn per row inside a band (round 3, one box):
     // line ratio 0.063 / 0.125 / 0.244 / 0.434 (band 2048 / 4096 / 8192 / 16384): tiled 917 / 886 / 689 / 604 us, packed row blocks
     // 728 / 808 / 900 / 1062 us; block-structured stencils sit below 0.05
-    static const double v = [] { const char *e = std::getenv("LCG_HIP_LINE_RATIO_TILED"); return e ? atof(e) : 0.18; }();
+    static const double v = [] { const char *e = lab_env("LCG_HIP_LINE_RATIO_TILED"); return e ? atof(e) : 0.18; }();
     return v;
 }
 
 static double tiled_fill_threshold()
 {
-    static const double fill = [] { const char *e = std::getenv("LCG_HIP_TILED_FILL"); return e ? atof(e) : 700.0; }();
+    static const double fill = [] { const char *e = lab_env("LCG_HIP_TILED_FILL"); return e ? atof(e) : 700.0; }();
     return fill;
 }
 
@@ -1314,7 +1315,7 @@ static bool tiled_chosen(const CsrPart &P, hipStream_t s)
         if (!diag_like_measured(P, s)) { P.tl_state = -1; return false; }
         if (P.diag_like > 0.5) { P.tl_state = -1; P.tl_why = "automatic mode: the columns run along diagonals (the row-block kernels gather contiguously)"; return false; }
         const bool lr = line_ratio_measured(P, s);
-        if (std::getenv("LCG_HIP_DEBUG_BINNED")) std::fprintf(stderr, "[lcg_hip] tiled choice: diag_like %.3f, line_ratio %.3f\n", P.diag_like, P.line_ratio);
+        if (debug_on()) std::fprintf(stderr, "[lcg_hip] tiled choice: diag_like %.3f, line_ratio %.3f\n", P.diag_like, P.line_ratio);
         if (lr && P.line_ratio < tiled_line_ratio_threshold()) {
             P.tl_state = -1; P.tl_why = "automatic mode: neighbouring rows share their cache lines of x (block-structured: the row-block kernels fetch few lines per entry)";
             return false;
@@ -1592,7 +1593,7 @@ static bool ranges_chosen(const CsrPart &P, hipStream_t s)
     }
     if (R->parts.size() < 2) { delete R; return false; }
     P.rg_plan = R; P.rg_state = 1;
-    if (std::getenv("LCG_HIP_DEBUG_BINNED")) {
+    if (debug_on()) {
         std::fprintf(stderr, "[lcg_hip] row ranges of %d rows:", n);
         for (size_t i = 0; i < R->parts.size(); i++) std::fprintf(stderr, " [%d, %d) %ld entries;", R->r0[i], R->r0[i] + R->parts[i].n_rows, (long)R->parts[i].nnz);
         std::fprintf(stderr, "\n");
@@ -1702,13 +1703,15 @@ static int long_rows_launch(const CsrPart &P, const double *x, double *y, hipStr
 static void ranges_free(const CsrPart &P)
 {
     RangePlan *R = static_cast<RangePlan *>(P.rg_plan);
-    if (R) { for (CsrPart &V : R->parts) free_part(V); delete R; }
+    // the range-by-range product's description lives in the plan (R->desc): nobody may be left pointing into it
+    // (lcg_hip_csr_last_kernel / _last_traffic_model between this call and the next product)
+    if (R) { for (CsrPart &V : R->parts) free_part(V); delete R; P.last_kernel = ""; }
     P.rg_plan = nullptr; P.rg_state = 0;
 }
 
 static bool long_rows_packed()
 {   // LCG_HIP_PACKED_LONG=0: long rows stay with k_spmv_lds1 (A/B runs)
-    static const bool on = [] { const char *e = std::getenv("LCG_HIP_PACKED_LONG"); return !e || atoi(e) != 0; }();
+    static const bool on = [] { const char *e = lab_env("LCG_HIP_PACKED_LONG"); return !e || atoi(e) != 0; }();
     return on;
 }
 
@@ -1777,7 +1780,7 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
         if constexpr (sizeof(V) == 8 && !ACC) {
             if constexpr (!PUSH) {
                 // short rows whose blocks of 64 are mostly runs: one wavefront per block, no staging (k_spmv_run1)
-                static const bool run1_off = [] { const char *e = std::getenv("LCG_HIP_RUN1"); return e && atoi(e) == 0; }();
+                static const bool run1_off = [] { const char *e = lab_env("LCG_HIP_RUN1"); return e && atoi(e) == 0; }();
                 // (its wavefront-private LDS is dynamic: 4 wavefronts x 64 rows x LP doubles must stay within the 64 KB a launch
                 //  may ask for without further ado -- rows of up to 30 entries)
                 if (!run1_off && variant == -1 && (R == 256 || R == 128) && packed_build(P, s, true) && P.pk_maxrow <= 30) {
@@ -1803,7 +1806,7 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
 #define PK_LAUNCH(NSS, BB, CC)                                                                                      \
         hipLaunchKernelGGL((k_spmv_ldsp<PUSH, NSS, BB, false, CC>), dim3((n + PK_R - 1) / PK_R + xb), dim3(VB), 0, s, n, P.rowptr, \
                            static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, reinterpret_cast<const double *>(val), \
-                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, pp, DotPlan())
+                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, pp, ldsp_plain_plan())
 #define PK_CASE(NSS)                                                                                                \
     case NSS:                                                                                                       \
         if (win == PK_CH_8) { if (P.pk_bits == 18) PK_LAUNCH(NSS, 18, PK_CH_8); else PK_LAUNCH(NSS, 21, PK_CH_8); } \
@@ -1830,7 +1833,7 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
 #define PKL_LAUNCH(NSS, BB, CC, RRR)                                                                                \
         hipLaunchKernelGGL((k_spmv_ldsp<false, NSS, BB, false, CC, RRR>), dim3((n + RRR - 1) / RRR), dim3(VB), 0, s, n, P.rowptr, \
                            static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, reinterpret_cast<const double *>(val), \
-                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, PushPlan(), DotPlan())
+                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, PushPlan(), ldsp_plain_plan())
 #define PKL_WIN(NSS, BB, RRR)                                                                                       \
         do { if (win == PK_CH_8) PKL_LAUNCH(NSS, BB, PK_CH_8, RRR); else if (win == PK_CH_7) PKL_LAUNCH(NSS, BB, PK_CH_7, RRR);   \
              else if (win == PK_CH_SMALL) PKL_LAUNCH(NSS, BB, PK_CH_SMALL, RRR); else PKL_LAUNCH(NSS, BB, LdsCfg<double>::CH, RRR); } while (0)
@@ -1939,7 +1942,7 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
     if (!pp && binned_chosen(P, s)) return 0;
     if (tiled_chosen(P, s)) {
         // the tiled product: one sum per chunk of 1024 rows (per consumer wavefront), folded like the packed kernel's per-block sums
-        static const bool tl_off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_TILED"); return e && atoi(e) == 0; }();
+        static const bool tl_off = [] { const char *e = lab_env("LCG_HIP_AX_DOT_TILED"); return e && atoi(e) == 0; }();
         if (tl_off || !tiled_dot_ok(P)) return 0;
         const int nchunk = tiled_chunks(P);
         if (nchunk <= 0) return 0;
@@ -1961,14 +1964,14 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
     }
     int R = 0; bool onewin = false;
     { int rc = lds_shape<double>(P, -1, mean_row, s, &R, &onewin); if (rc) return rc; }
-    static const bool big_off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_PACKED"); return e && atoi(e) == 0; }();
+    static const bool big_off = [] { const char *e = lab_env("LCG_HIP_AX_DOT_PACKED"); return e && atoi(e) == 0; }();
     if (!onewin || big_off) return 0;
     // (long rows -- blocks of 32 / 16 rows with packed columns, spmv_dispatch -- keep the dot as a pass of its own: carried in the
     //  product it cost 32 us on the 27-point stencil x 3 unknowns, 187,500 blocks of 16 rows, where the separate pass costs 7)
     if (R != PK_R || !packed_ready(P, s)) return 0;
     const int nblk = (n + PK_R - 1) / PK_R;
     if (!ensure_dot_part(P, nblk)) return 0;
-    DotPlan dp; dp.u = u; dp.part = P.dot_part; dp.yy = yy; dp.stride = nblk;
+    DotPlan dp; dp.u = u; dp.part = P.dot_part; dp.yy = yy; dp.stride = nblk; dp.ystore = y_store_policy();
     const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);
     const int ns = per_lane <= 6 ? 6 : per_lane <= 7 ? 7 : per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
     const PushPlan ppv = pp ? *pp : PushPlan();
@@ -2029,7 +2032,7 @@ int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int 
     if (R == PK_R && packed_ready(P, s)) return csr_part_ax_dot(P, A->variant, A->mean_row, x, y, u, yy, part, slots, s, done, nullptr, nullptr, nullptr);
     if ((R == 32 || R == 16) && long_rows_packed() && packed_ready(P, s, R)) return 0;     // (the product alone: see csr_part_ax_dot)
     const int nblk = (n + R - 1) / R;
-    static const bool run1_off = [] { const char *e = std::getenv("LCG_HIP_RUN1"); return e && atoi(e) == 0; }();
+    static const bool run1_off = [] { const char *e = lab_env("LCG_HIP_RUN1"); return e && atoi(e) == 0; }();
     if (!run1_off && (R == 256 || R == 128) && packed_build(P, s, true) && P.pk_maxrow <= 15) {
         // short-row stencils (k_spmv_run1d): eight wavefronts, one partial per workgroup of 512 rows (8 x 64 x LP doubles of
         // dynamic LDS: rows of up to 15 entries; longer ones take the plain product and the separate pass)
@@ -2054,7 +2057,7 @@ int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int 
     // latencies -- the product grows by ~0.6 us, a ~3 us pass and its launch go.  At 1M rows (3907 row blocks) the product grew by
     // 3.2 us and every block of the consuming pass re-added 3907 partials: 39.2 vs 38.5 us per PCG iteration, so from
     // LCG_HIP_AX_DOT_MAXBLK (default 2048) row blocks on the separate pass stays.
-    static const int maxblk = [] { const char *e = std::getenv("LCG_HIP_AX_DOT_MAXBLK"); const int v = e ? atoi(e) : 2048; return v < 1 ? 1 : (v > AXP_CAP ? AXP_CAP : v); }();
+    static const int maxblk = [] { const char *e = lab_env("LCG_HIP_AX_DOT_MAXBLK"); const int v = e ? atoi(e) : 2048; return v < 1 ? 1 : (v > AXP_CAP ? AXP_CAP : v); }();
     if (nblk > maxblk) return 0;
     DotPlan dp; dp.u = u; dp.part = part; dp.yy = yy;
     const int g = nblk;

@@ -406,7 +406,7 @@ int binned_ready(const CsrPart &P, hipStream_t s)
     P.bn_state = -1;
     BinnedPlan *B = nullptr;
     int rc = plan_build(P, s, &B, &P.bn_why);
-    if (std::getenv("LCG_HIP_DEBUG_BINNED"))
+    if (debug_on())
         std::fprintf(stderr, "[lcg_hip] binned plan for %d x %ld, %ld entries: %s (rc %d%s%s)\n", P.n_rows, (long)P.n_cols, (long)P.nnz, P.bn_why, rc,
                      rc ? ": " : "", rc ? ctx().err.c_str() : "");
     if (rc) { (void)hipGetLastError(); return rc; }

@@ -369,7 +369,7 @@ void tiled_free(CsrPart &P)
 // nine wavefronts per CU) or 4 (two workgroups of five per CU, twice the tile copies: 841 vs 756 us on the 10M-row row-random band).
 static int tiled_nw()
 {
-    static const int v = [] { const char *e = std::getenv("LCG_HIP_TILED_NW"); return e && atoi(e) == 4 ? 4 : 8; }();
+    static const int v = [] { const char *e = lab_env("LCG_HIP_TILED_NW"); return e && atoi(e) == 4 ? 4 : 8; }();
     return v;
 }
 
@@ -458,7 +458,7 @@ int tiled_ready(const CsrPart &P, hipStream_t s, double min_fill)
     P.tl_state = -1;
     TiledPlan *T = nullptr;
     int rc = plan_build(P, s, min_fill, &T, &P.tl_why);
-    if (std::getenv("LCG_HIP_DEBUG_BINNED"))
+    if (debug_on())
         std::fprintf(stderr, "[lcg_hip] tiled plan for %d x %ld, %ld entries: %s (rc %d)\n", P.n_rows, (long)P.n_cols, (long)P.nnz, P.tl_why, rc);
     if (rc) { (void)hipGetLastError(); return rc; }
     if (!T) return 0;
@@ -473,8 +473,8 @@ int tiled_chunks(const CsrPart &P)
     const TiledPlan *T = static_cast<const TiledPlan *>(P.tl_plan);
     return T ? T->nwg * T->nw : 0;
 }
-static int tiled_depth() { static const int v = [] { const char *e = std::getenv("LCG_HIP_TILED_DEPTH"); return e ? atoi(e) : 3; }(); return v; }
-static int tiled_nt() { static const int v = [] { const char *e = std::getenv("LCG_HIP_TILED_NT"); return e ? atoi(e) : 1; }(); return v; }
+static int tiled_depth() { static const int v = [] { const char *e = lab_env("LCG_HIP_TILED_DEPTH"); return e ? atoi(e) : 3; }(); return v; }
+static int tiled_nt() { static const int v = [] { const char *e = lab_env("LCG_HIP_TILED_NT"); return e ? atoi(e) : 1; }(); return v; }
 bool tiled_dot_ok(const CsrPart &P)
 {
     const TiledPlan *T = static_cast<const TiledPlan *>(P.tl_plan);

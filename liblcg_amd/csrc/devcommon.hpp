@@ -138,6 +138,15 @@ template <class T> __device__ __forceinline__ T ldp(const double *p, long i, boo
 __device__ __forceinline__ void stp(double *p, long i, double v, bool nt) { if (nt) stnt(p, i, v); else st_(p, i, v); }
 __device__ __forceinline__ void stp(double *p, long i, double2 v, bool nt) { if (nt) stnt(p, i, v); else st_(p, i, v); }
 
+// y of the row-block product, by cache policy (internal.hpp: y_store_policy)
+__device__ __forceinline__ void store_y(double *p, double v, int how)
+{
+    if (how == 0) *p = v;
+    else if (how == 1) __builtin_nontemporal_store(v, p);
+    else if (how == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 // real helpers on 1 or 2 packed values
 __device__ __forceinline__ double dotp(double a, double b) { return a * b; }
 __device__ __forceinline__ double dotp(double2 a, double2 b) { return a.x * b.x + a.y * b.y; }
@@ -199,23 +208,28 @@ enum { SC_FUSED = 0, SC_REDUCE = 1, SC_FIN = 2, SC_XGMI = 3 };
 // obtains the same bits -- which the lock-step loop (driver.hpp) relies on.  Two parities suffice:
 // a rank can finish call k+1 only after every peer has entered k+1, i.e. finished reading call k.
 // A contribution that does not arrive within timeout_ticks raises *fail; the call returns false.
-// 16-byte packets {value, sequence number}: one global_store_dwordx4 / global_load_dwordx4 each, system scope, uncached memory.
-// A packet is written and read whole (an aligned 16-byte access is one transaction on gfx950 -- observed untorn, the connect-time
-// self-test of 32 known-answer all-reduces and tests/test_gpu_p2p.py check it on the node; not an architectural promise), so the
-// value needs no flag behind it: the sender fires its packets and goes on, the receiver polls the packets themselves.
+// 16-byte packets, one global_store_dwordx4 / global_load_dwordx4 each, system scope, uncached memory: {value low word, tag, value high
+// word, tag} with tag = the low 32 bits of the call's sequence number.  The value needs no flag behind it -- the sender fires its
+// packets and goes on, the receiver polls the packets themselves -- and a packet is accepted only when BOTH tags are the call's:
+// an aligned 16-byte access has been one transaction on every gfx950 link observed, but that is not an architectural promise, and
+// over xGMI a packet torn between its 8-byte halves (new tag beside the value of call k - 2 of the same parity) would hand one rank
+// other bits than its peers and take the lock-step loop apart.  With a tag in each naturally aligned 8-byte half -- the
+// unit that IS written whole -- a torn packet shows one stale tag and is polled again.  (A slot is rewritten every second call, so a
+// stale tag differs from the expected one by 2: the 32-bit tag cannot be mistaken before 2^32 calls.)
 typedef unsigned int xg_v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void xg_store_packet(double *slot, double v, unsigned long long k)
 {
     const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
-    xg_v4u w; w.x = (unsigned)vb; w.y = (unsigned)(vb >> 32); w.z = (unsigned)k; w.w = (unsigned)(k >> 32);
+    xg_v4u w; w.x = (unsigned)vb; w.y = (unsigned)k; w.z = (unsigned)(vb >> 32); w.w = (unsigned)k;
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(slot), "v"(w) : "memory");
 }
-__device__ __forceinline__ void xg_load_packet(const double *slot, double *v, unsigned long long *k)
+// true when the packet in the slot is call k's, whole
+__device__ __forceinline__ bool xg_load_packet(const double *slot, double *v, unsigned long long k)
 {
     xg_v4u w;
     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(slot) : "memory");
-    *v = __longlong_as_double((long long)((unsigned long long)w.x | ((unsigned long long)w.y << 32)));
-    *k = (unsigned long long)w.z | ((unsigned long long)w.w << 32);
+    *v = __longlong_as_double((long long)((unsigned long long)w.x | ((unsigned long long)w.z << 32)));
+    return w.y == (unsigned)k && w.w == (unsigned)k;
 }
 
 // The sequence number of the exchange a one-block kernel is about to make and the failure flag, requested by thread 0 at the
@@ -252,11 +266,7 @@ __device__ __forceinline__ bool xg_exchange(const XgBox &xb, const double *sums,
         for (;;) {
             bool all = true;
 #pragma unroll
-            for (int r = 0; r < NR; r++) {
-                unsigned long long kk;
-                xg_load_packet(src + 2 * r, &tmp[r], &kk);
-                all = all && kk == k;
-            }
+            for (int r = 0; r < NR; r++) all = xg_load_packet(src + 2 * r, &tmp[r], k) && all;
             if (all) break;
             __builtin_amdgcn_s_sleep(2);
             if (wall_clock64() - t0 > xb.timeout_ticks) { ok = false; break; }
@@ -609,7 +619,7 @@ inline int grid_for(long n_items)
 {
     // 512 blocks (two per CU) keep the BLAS-1 passes at their bandwidth (measured on the 10M-row system: 2048 / 1024 / 512
     // blocks = 171 / 172 / 166 us of BLAS-1 per CG iteration) and leave a quarter of the partials to re-reduce
-    static const long cap = [] { const char *e = std::getenv("LCG_HIP_MAXGRID"); long v = e ? atol(e) : 512; return v < 1 ? 1 : (v > MAXG ? (long)MAXG : v); }();
+    static const long cap = [] { const char *e = lab_env("LCG_HIP_MAXGRID"); long v = e ? atol(e) : 512; return v < 1 ? 1 : (v > MAXG ? (long)MAXG : v); }();
     long g = (n_items + VB - 1) / VB;
     if (g < 1) g = 1;
     if (g > cap) g = cap;

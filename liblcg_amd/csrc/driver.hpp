@@ -77,7 +77,7 @@ struct Driver {
     // sums have to meet the other ranks' first, so the step stays its own kernel(s) around the all-reduce.
     template <class Fin, class Op> int vecf(Fin fin, Op op, uintptr_t align_or = 0)
     {
-        static const bool off = std::getenv("LCG_HIP_NO_FUSED_SCALAR") != nullptr;      // A/B runs
+        static const bool off = lab_env("LCG_HIP_NO_FUSED_SCALAR") != nullptr;      // A/B runs
         if (comm_active() || off) {
             int rc = scal(fin);
             return rc ? rc : vec(op, align_or);
@@ -141,7 +141,7 @@ struct Driver {
         // itself on it: every 4th body on small systems (3-5 us of a 20-35 us iteration at 1e4 rows),
         // every body where a body is long and only 6 are kept in flight
         h.pub_mask = comm_active() ? 0x3fffffff : ((cplx ? 2 * n : n) >= (1 << 20) ? 0 : 3);
-        if (const char *e = std::getenv("LCG_HIP_PUBLISH_EVERY")) h.pub_mask = std::max(1, atoi(e)) - 1;
+        if (const char *e = lab_env("LCG_HIP_PUBLISH_EVERY")) h.pub_mask = std::max(1, atoi(e)) - 1;
         c.fin_steps = 0;
         c.hstat->it = 0; c.hstat->done = 0; c.hstat->status = 0; c.hstat->t = 0; c.hstat->residual = 0.0;
         (void)lcg_hip_last_ax_mean_us();        // a previous solve's events, if nobody asked yet: they are about to be reused
@@ -217,7 +217,7 @@ struct Driver {
         // asynchronous path
         const long work = cplx ? 2 * n : n;
         int inflight = work >= (1 << 20) ? 6 : 24;
-        if (const char *e = std::getenv("LCG_HIP_INFLIGHT")) inflight = std::max(1, atoi(e));
+        if (const char *e = lab_env("LCG_HIP_INFLIGHT")) inflight = std::max(1, atoi(e));
         // (Replaying the body from a hipGraph was measured and dropped: on the launch-bound 1e4-row
         // system an iteration is six DEPENDENT ~2 us kernels, 23 us eager vs 24.6 us replayed in
         // batches of four -- the chain on the device is the limit, not the host's launch rate.)
@@ -262,7 +262,7 @@ struct Driver {
     int run_lockstep(Body &&body, int code_max_it, int code_nan)
     {
         int batch = 8;
-        if (const char *e = std::getenv("LCG_HIP_BATCH")) batch = std::max(1, atoi(e));
+        if (const char *e = lab_env("LCG_HIP_BATCH")) batch = std::max(1, atoi(e));
         int nb = 0, rc = 0;
         DevState h;
         for (;;) {

@@ -5,12 +5,42 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
 #include "lcg_hip.h"
 
 namespace lcgh {
+
+// Run-time switches.  The shipped library reads the documented ones only ("Run-time switches": LCG_HIP_PACKED,
+// _TILED, _BINNED, _RANGES, _AX_DOT, _NT_VECTORS, _PACKED_WINDOW, _P2P_TIMEOUT_MS, _FORCE_COMM, _DEBUG, _DEBUG_SYNC,
+// _TEST_WITHHOLD_PUSH).  The knobs of the closed experiments (LAB_NOTES: thresholds, ring depths, batch sizes, A/B
+// switches of single kernels) exist in a LAB BUILD only -- `make LAB=1` compiles with -DLCG_HIP_LAB -- and read as unset
+// otherwise, so that every branch they select folds away in the shipped .so.
+inline const char *lab_env(const char *name)
+{
+#ifdef LCG_HIP_LAB
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+// Cache policy of the row-block product's y stores (placement study, DESIGN 9 / profiles/r04_placement*): 0 plain, 1 non-temporal,
+// 2 write-through (sc1), 3 write-through at system scope (sc0 sc1).  LAB builds read LCG_HIP_Y_STORE.
+inline int y_store_policy()
+{
+    const char *e = lab_env("LCG_HIP_Y_STORE");      // (read at every launch: a lab program switches it between launches)
+    return e ? atoi(e) : 0;
+}
+// LCG_HIP_DEBUG=1: the plan builders and the direct exchange say on stderr what they chose and why
+inline bool debug_on()
+{
+    static const bool on = [] { const char *e = std::getenv("LCG_HIP_DEBUG"); return e && atoi(e) != 0; }();
+    return on;
+}
+
 
 constexpr int VB = 256;     // threads per block of every vector / scalar kernel
 constexpr int MAXG = 2048;  // most blocks a reducing kernel launches = stride of the partial-sum table
@@ -85,6 +115,7 @@ struct DotPlan {
     double *part = nullptr;
     int yy = 0;
     int stride = AXP_CAP;   // distance of the y.y sums from the y.u sums in `part`
+    int ystore = 0;         // how k_spmv_ldsp stores y (devcommon.hpp: store_y; set by the host from y_store_policy())
 };
 
 // The scalar step that closes an iteration body, run by the LAST block of the kernel that completes the body's last sum (the

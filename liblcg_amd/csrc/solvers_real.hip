@@ -492,7 +492,14 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
         int rc;
         // The product that closes a body only serves the NEXT body's step length: the body the iteration cap ends the solve with goes
         // without it (K iterations = K + 1 products, as in the reference's loop: lcg.cpp:168, 232).
-        auto last_body = [&]() { return p.max_iterations > 0 && k.drv.enq + 1 >= p.max_iterations; };
+        // (Its closing step then finds NO partial sums for g.w -- neither the previous body's nor an unwritten table row: the count of
+        //  that row is zero, the sum exactly 0, and the a_k, b_k the step leaves behind are a fixed function of the state; nothing
+        //  reads them after the cap.)
+        auto last_body = [&]() {
+            const bool last = p.max_iterations > 0 && k.drv.enq + 1 >= p.max_iterations;
+            if (last) { k.drv.pcnt.ax_n = 0; k.drv.pcnt.ax_row = -1; k.drv.pcnt.g[2] = 0; }
+            return last;
+        };
         if (fused && Pfp == nullptr && !comm_active()) {
             // The product carries g.w, the update pass the other sums of the body: a body is TWO launches, `[step] update + sums |
             // A.g + g.w`; the scalar step that closes body k rides in the update of body k+1, the last one is closed by the tail.
@@ -610,7 +617,11 @@ static int solve_pcg(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pf
             if (!f) TRY(k.drv.vec_rows(OpDot1{st, z, w}, 4, al(z) | al(w)));
             return 0;
         };
-        auto last_body = [&]() { return p.max_iterations > 0 && k.drv.enq + 1 >= p.max_iterations; };
+        auto last_body = [&]() {       // (as in solve_cg: the capped body's closing step finds an empty row for w.u, not a stale one)
+            const bool last = p.max_iterations > 0 && k.drv.enq + 1 >= p.max_iterations;
+            if (last) { k.drv.pcnt.ax_n = 0; k.drv.pcnt.ax_row = -1; k.drv.pcnt.g[4] = 0; }
+            return last;
+        };
         const OpPcg1UpdateSums upd{st, m, r, z, d, Ad, w, invdiag, 0.0, 0.0};
         int rc;
         if (Pfp == nullptr && !comm_active()) {

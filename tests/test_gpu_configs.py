@@ -104,6 +104,53 @@ def test_config4_nonsymmetric_bicgstab_full_size(api, port):
             assert abs(info.residual - ref["residual"]) <= 1e-9 * ref["residual"], (sid, info.residual, ref["residual"])
 
 
+@pytest.mark.parametrize("pattern,band,family", [(1, 131072, "k_spmv_ldsp (LDS-staged, run blocks"), (2, 131072, "k_tile_spmv"),
+                                                 (0, 0, "k_bin_expand + k_bin_reduce")])
+def test_config2_against_the_oracle_at_full_size(api, port, pattern, band, family):
+    """BASELINE configs[2] AT ITS OWN SIZE against the oracle (missing 3): the 10M-row, 3.3e8-entry SPD system of
+    bench.py -- the headline's constant diagonals, the row-random band and the scrambled columns, each multiplied by the kernel
+    family the library chooses for it -- (1) A.x row by row against the oracle's serial CSR product at 1e-13 |A||x| (the oracle's
+    row-wise bound), plain and as the solver runs it (carrying the dot: the first capped iterate below), and (2) four capped
+    iterations of lcg() (lcg.cpp:206-264) against the oracle's loop on the very same arrays at 1e-10 (rounding of 1e7-term inner
+    products added in another order -- a wrong coefficient shows at 1e-1), monitored residual included."""
+    from liblcg_amd import _lib
+    from oracle import pyoracle as po
+    lib = _lib.load()
+    n = 10_000_000
+    A = api.CsrMatrix.generate(n, 16, band, True, 1, 0.01, pattern=pattern)
+    assert 32.5 * n < A.nnz <= 33 * n
+    rp, ci, v = A.arrays_to_host()
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) - 0.5
+    y = torch.empty_like(x)
+    A.spmv(x, y); api.synchronize()
+    name = lib.lcg_hip_csr_last_kernel(A.h).decode()
+    assert name.startswith(family), name
+    xh = x.cpu().numpy()
+    ref = port.csr_matvec(rp, ci, v, xh)
+    bound = port.csr_matvec(rp, ci, np.abs(v), np.abs(xh))
+    worst = float(np.max(np.abs(y.cpu().numpy() - ref) / bound))
+    assert worst <= 1e-13, (name, worst)
+    del ref, bound, xh, x, y
+    xt = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 1, 0, n, xt)
+    b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
+    bh = b.cpu().numpy()
+    for ad in (1, 0):
+        ref = port.solve(po.LCG_CG, rp, ci, v, bh, para=po.default_para(epsilon=1e-300, abs_diff=ad, max_iterations=4), threads=8)
+        m = torch.zeros_like(xt)
+        ws = [torch.empty_like(xt) for _ in range(3)]
+        info = api.lcg("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=1e-300, abs_diff=ad, max_iterations=4), A, *ws)
+        xg = m.cpu().numpy()
+        rel = float(np.linalg.norm(xg - ref["x"]) / np.linalg.norm(ref["x"]))
+        assert info.ret == ref["ret"] == -1019 and info.iterations == ref["iters"] == 4, (info.ret, ref["ret"], info.iterations, ref["iters"])
+        assert rel <= 1e-10, (name, ad, rel)
+        assert abs(info.residual - ref["residual"]) <= 1e-9 * ref["residual"], (ad, info.residual, ref["residual"])
+    # the product inside the solve was the family's dot-carrying form where it has one
+    inside = lib.lcg_hip_csr_last_kernel(A.h).decode()
+    assert inside.startswith(family.split(" (")[0]), inside
+    A.destroy()
+
+
 @pytest.mark.parametrize("pattern,n,band,seed", NONSYM_SYSTEMS)
 def test_nonsymmetric_bicgstab_and_cgs_against_the_oracle(api, port, pattern, n, band, seed):
     """lbicgstab (lcg.cpp:629-794) and lcgs (lcg.cpp:437-612) exist for A != A^T: here they meet the oracle on such

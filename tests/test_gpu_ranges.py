@@ -165,6 +165,41 @@ def device_arrays(A):
     return rp, ci, v
 
 
+def test_description_does_not_outlive_the_range_plan(port):
+    """the range-by-range product's description was a pointer into the plan; dropping the plan (set_ranges, set_packed,
+    set_binned, set_tiled all do) and asking lcg_hip_csr_last_kernel / _last_traffic_model BEFORE the next product read freed
+    memory.  Now the description is reset with the plan."""
+    from liblcg_amd import _lib, api
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    n, n1p, (rp, ci, v) = mixed_system(rng, True, dims=(28, 26, 22))
+    A = api.CsrMatrix.from_csr(rp, ci, v)
+    assert lib.lcg_hip_csr_set_ranges(A.h, 1) == 0
+    x = torch.rand(n, dtype=torch.float64, device="cuda"); y = torch.empty_like(x)
+    A.spmv(x, y); api.synchronize()
+    first = (C.c_int * 8)()
+    assert lib.lcg_hip_csr_ranges(A.h, 8, first) >= 2
+    split = lib.lcg_hip_csr_last_kernel(A.h).decode()
+    assert split.startswith("rows [0, ") and " | " in split
+    assert lib.lcg_hip_csr_last_traffic_model(A.h) > 0
+    for drop in (lambda: lib.lcg_hip_csr_set_ranges(A.h, 0), lambda: lib.lcg_hip_csr_set_packed(A.h, 0),
+                 lambda: lib.lcg_hip_csr_set_binned(A.h, 0), lambda: lib.lcg_hip_csr_set_tiled(A.h, 0)):
+        assert lib.lcg_hip_csr_set_ranges(A.h, 1) == 0
+        A.spmv(x, y); api.synchronize()
+        assert " | " in lib.lcg_hip_csr_last_kernel(A.h).decode()
+        assert drop() == 0
+        junk = [torch.full((4096,), 3.0, device="cuda") for _ in range(64)]       # whatever was freed is likely overwritten by now
+        assert lib.lcg_hip_csr_last_kernel(A.h).decode() == ""                  # no product since the plan went
+        assert lib.lcg_hip_csr_last_traffic_model(A.h) == 0
+        del junk
+    assert lib.lcg_hip_csr_set_ranges(A.h, 0) == 0
+    A.spmv(x, y); api.synchronize()
+    assert " | " not in lib.lcg_hip_csr_last_kernel(A.h).decode() and lib.lcg_hip_csr_last_kernel(A.h).decode() != ""
+    yo = port.csr_matvec(rp, ci, v, x.cpu().numpy())
+    assert np.max(np.abs(y.cpu().numpy() - yo)) <= 1e-12 * np.max(np.abs(yo))
+    A.destroy()
+
+
 def test_ten_million_rows_two_classes():
     from liblcg_amd import _lib, api
     lib = _lib.load()
