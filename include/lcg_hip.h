@@ -116,8 +116,8 @@ double lcg_hip_last_residual(void);
 int    lcg_hip_set_profiling(int on);
 double lcg_hip_last_ax_mean_us(void);
 int    lcg_hip_last_ax_calls(void);
-/* Scalar steps of the latest solve that ran in the last block of a sharded product instead of in a kernel of their own
- * (opt-in: LCG_HIP_FINISHER=1, plain CG's one-reduction schedule over the mailboxes; 0 otherwise).  No reference counterpart. */
+/* Always 0.  (Round 3 counted here the scalar steps that ran in the last block of a sharded product -- an opt-in experiment that
+ * measured no gain, DESIGN 9, and was retired in round 4; the entry stays so that the library's exports do not change.) */
 int    lcg_hip_last_finisher_steps(void);
 /* The solvers keep their temporaries (the reference allocates and frees them per call, lcg.cpp:158-166,266-271) for the
  * next solve; this gives the idle ones back to the device. */
@@ -213,12 +213,12 @@ int lcg_hip_csr_set_packed(lcg_hip_csr_t A, int mode);
  * block carries row 0's columns only -- 8.06 instead of 10.3 bytes of stream per entry -- and its x gathers leave together
  * with the value stream (-22 % on the headline A.x, bit-identical y).  Returns the number of run blocks of the packed copy
  * (0 before the first product built it, or when there are none); *blocks_out (may be NULL) = all blocks of 64 rows.
- * LCG_HIP_PACKED_RUNS=0 stores every block with its own columns. */
+ * (A LAB build's LCG_HIP_PACKED_RUNS=0 stores every block with its own columns.) */
 int64_t lcg_hip_csr_packed_runs(lcg_hip_csr_t A, int64_t *blocks_out);
 /* Blocks of 64 rows the packed form stores as TEMPLATE blocks: every entry on one of <= 64 diagonals (the union of the rows'), rows of
  * <= 32 entries, and a 64-bit mask per row saying which diagonals the row has -- what a stencil's blocks look like where grid boundaries pass
  * through them.  Like run blocks they stream values only and are bit-identical to the plain row-block kernel.
- * LCG_HIP_PACKED_TEMPLATES=0 stores such blocks with packed columns (A/B runs).  No reference counterpart. */
+ * (A LAB build's LCG_HIP_PACKED_TEMPLATES=0 stores such blocks with packed columns.)  No reference counterpart. */
 int64_t lcg_hip_csr_packed_templates(lcg_hip_csr_t A);
 /* Two-pass "binned" A.x for matrices whose columns are scattered over more of x than any cache holds (the
  * arbitrary user CSR of sample8.cu:96-103 at its worst): pass 1 expands x into entry order with a 64 KB slice
@@ -226,8 +226,8 @@ int64_t lcg_hip_csr_packed_templates(lcg_hip_csr_t A);
  * 2048 rows, ds_add_f64) -- 28.5 streamed bytes per entry instead of 12 + a cache line per gather.  The plan
  * (re-ordered copy of the matrix: +26.5 B per entry) is built on the device at the first product.
  * mode: -1 automatic (real matrices of >= 4M entries and >= 1M columns whose 64-row blocks span on average
- * >= 2^20 columns -- LCG_HIP_BINNED_SPAN changes that threshold --, whose columns do not run along diagonals and
- * whose gathers mostly have a cache line of x of their own -- LCG_HIP_LINE_RATIO, default 0.5: block-structured
+ * >= 2^20 columns, whose columns do not run along diagonals and
+ * whose gathers mostly have a cache line of x of their own (share >= 0.5: block-structured
  * matrices stay with the row-block kernels), 0 never (frees the plan), 1 whenever eligible.
  * LCG_HIP_BINNED=0/1 overrides for the whole process.  y differs from the row-block kernels' y in the last
  * bits (products are rounded before the add); on gfx950 it is bit-identical from call to call and from plan to plan
@@ -242,8 +242,8 @@ int lcg_hip_csr_set_binned(lcg_hip_csr_t A, int mode);
  * eight consumer wavefronts stream the rows' entries of the current one: 2 KB per step of 192 entries = values + three
  * 21-bit (row, column) pairs per 64-bit word, 10.67 B per entry where CSR has 12).  mode: -1 automatic (real matrices of
  * >= 4M entries whose columns do not run along diagonals, whose gathers mostly have a cache line of x of their own
- * (LCG_HIP_LINE_RATIO) and whose (workgroup, tile) pairs hold >= 700 entries on average: LCG_HIP_TILED_FILL), 0 never (frees the plan), 1 whenever eligible; LCG_HIP_TILED=0/1 overrides for the
- * process.  Same last-bit deviation from the row-block kernels as the binned product; y is bit-identical from call to
+ * (share >= 0.18) and whose (workgroup, tile) pairs hold >= 700 entries on average), 0 never (frees the plan), 1 whenever eligible;
+ * LCG_HIP_TILED=0/1 overrides for the process.  Same last-bit deviation from the row-block kernels as the binned product; y is bit-identical from call to
  * call and from plan to plan ON gfx950 (a row is summed by one wavefront in stream order; lanes of one ds_add_f64 that meet
  * in a row are serialised by the LDS in lane order -- verified by tests/test_gpu_binned.py, not promised by the ISA). */
 int lcg_hip_csr_set_tiled(lcg_hip_csr_t A, int mode);

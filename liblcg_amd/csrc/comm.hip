@@ -289,9 +289,7 @@ __global__ __launch_bounds__(VB) void k_scatter_add(int nr, const int *__restric
 // carries (the local product leaves the rest: csr.hip, csr_part_ax_dot) -- one partial per block, fixed order
 // `big` (may be null): the local product's per-block sums; this block also adds its slice [blockIdx * per, + per) of them -- the
 // second stage of the local sums costs no launch of its own
-// fp.fin != 0: the block whose sum arrives last also closes the iteration body (devcommon.hpp: finish_body)
-__device__ __forceinline__ void block_dot_store(double c, double *out, const FinishPlan &fp, const double *__restrict__ big = nullptr,
-                                                int nbig = 0, int per = 0)
+__device__ __forceinline__ void block_dot_store(double c, double *out, const double *__restrict__ big = nullptr, int nbig = 0, int per = 0)
 {
     __shared__ double sh[VB / 64];
     if (big) {
@@ -301,23 +299,22 @@ __device__ __forceinline__ void block_dot_store(double c, double *out, const Fin
     const double t = wave_sum(c);
     if ((threadIdx.x & 63) == WSUM_LANE) sh[threadIdx.x >> 6] = t;
     __syncthreads();
-    double v = 0.0;
     if (threadIdx.x == 0) {
+        double v = 0.0;
 #pragma unroll
         for (int k = 0; k < VB / 64; k++) v += sh[k];
-        if (!fp.fin) out[blockIdx.x] = v;
+        out[blockIdx.x] = v;
     }
-    if (fp.fin) finish_body(fp, out + blockIdx.x, v);
 }
 __global__ __launch_bounds__(VB) void k_scatter_add_dot(int nr, const int *__restrict__ rows, const double *__restrict__ part,
                                                         double *__restrict__ y, const double *__restrict__ u, double *__restrict__ dot_out,
-                                                        const double *__restrict__ big, int nbig, int per, const int *done, FinishPlan fp)
+                                                        const double *__restrict__ big, int nbig, int per, const int *done)
 {
     if (done && *done) return;
     const int j = blockIdx.x * VB + threadIdx.x;
     double c = 0.0;
     if (j < nr) { const int i = rows[j]; const double p = part[j]; y[i] += p; c = u[i] * p; }
-    block_dot_store(c, dot_out, fp, big, nbig, per);
+    block_dot_store(c, dot_out, big, nbig, per);
 }
 
 static int alloc_cols(CsrPart &P, int n, long nnz, bool cplx)
@@ -496,28 +493,14 @@ __global__ __launch_bounds__(VB) void k_recv(WaitPlan wp, PushPlan cp, DevState 
 // row bounds, and a lane keeps four entries in flight.
 // TOY: add into y (single-stream form) or store the compact sums out[j] (two-stream form: the sums are
 // computed beside the local product and added by k_scatter_add once both are done).
-__device__ __forceinline__ double ld_land(const double *p) { return __hip_atomic_load(const_cast<double *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ double2 ld_land(const double2 *p)
-{
-    const double *q = reinterpret_cast<const double *>(p);
-    return make_double2(ld_land(q), ld_land(q + 1));
-}
-// LAND: no k_recv in front -- every block waits for the neighbours' flags itself and gathers x straight
-// from the uncached landing zone with system-scope loads (xfull then IS the landing-zone half of this call).
-template <class V, int T, bool TOY, bool LAND = false, bool DOT = false>
+template <class V, int T, bool TOY, bool DOT = false>
 __global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                const V *__restrict__ val, const int *__restrict__ rows,
                                                const V *__restrict__ xfull, V *__restrict__ y, const int *done,
-                                               WaitPlan wp = WaitPlan(), DevState *st = nullptr,
                                                const double *__restrict__ u = nullptr, double *__restrict__ dot_out = nullptr,
-                                               const double *__restrict__ big = nullptr, int nbig = 0, int per = 0,
-                                               FinishPlan fp = FinishPlan())
+                                               const double *__restrict__ big = nullptr, int nbig = 0, int per = 0)
 {
-    static_assert(!DOT || (TOY && !LAND && sizeof(V) == 8), "the remote part carries its share of y.u in the single-stream real form");
-    if (LAND && !wait_flags<false>(wp)) {
-        if (st && blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->status = ST_COMM; }
-        return;
-    }
+    static_assert(!DOT || (TOY && sizeof(V) == 8), "the remote part carries its share of y.u in the real form that adds into y");
     if (done && *done) return;
     const long gt = (long)blockIdx.x * VB + threadIdx.x;
     const long j = gt / T;
@@ -533,23 +516,23 @@ __global__ __launch_bounds__(VB) void k_remote(int nr, const int *__restrict__ r
 #pragma unroll
             for (int q = 0; q < 4; q++) { c[q] = col[k + q * T]; a[q] = val[k + q * T]; }
 #pragma unroll
-            for (int q = 0; q < 4; q++) xv[q] = LAND ? ld_land(xfull + c[q]) : xfull[c[q]];
+            for (int q = 0; q < 4; q++) xv[q] = xfull[c[q]];
 #pragma unroll
             for (int q = 0; q < 4; q++) acc = mac(a[q], xv[q], acc);
         }
         if (k + T < e) {
             const int c0 = col[k], c1 = col[k + T];
             const V a0 = val[k], a1 = val[k + T];
-            const V x0 = LAND ? ld_land(xfull + c0) : xfull[c0], x1 = LAND ? ld_land(xfull + c1) : xfull[c1];
+            const V x0 = xfull[c0], x1 = xfull[c1];
             acc = mac(a0, x0, acc); acc = mac(a1, x1, acc);
             k += 2 * T;
         }
-        if (k < e) { const int c0 = col[k]; acc = mac(val[k], LAND ? ld_land(xfull + c0) : xfull[c0], acc); }
+        if (k < e) { const int c0 = col[k]; acc = mac(val[k], xfull[c0], acc); }
     }
 #pragma unroll
     for (int off = T / 2; off > 0; off >>= 1) acc = vadd(acc, shfl_down_v(acc, off, T));
     if (j < nr && lane == 0) { if (TOY) y[i] = vadd(yold, acc); else y[j] = acc; }
-    if constexpr (DOT) block_dot_store((j < nr && lane == 0) ? u[i] * acc : 0.0, dot_out, fp, big, nbig, per);
+    if constexpr (DOT) block_dot_store((j < nr && lane == 0) ? u[i] * acc : 0.0, dot_out, big, nbig, per);
 }
 
 static void direct_free(lcg_hip_csr *A)
@@ -852,9 +835,7 @@ static int remote_sums_launch(lcg_hip_csr *A, const double *xfull, double *out, 
     const int nr = A->remc.n_rows;
     if (nr <= 0) return 0;
     const double mean_r = (double)A->remc.nnz / nr;
-    int T = mean_r <= 8.0 ? 1 : (mean_r <= 24.0 ? 2 : 4);
-    if (const char *e = lab_env("LCG_HIP_REMOTE_T")) T = atoi(e);
-    if (T != 1 && T != 2 && T != 4) return fail(hipErrorInvalidValue, "bad lanes-per-row for the remote-column product", __FILE__, __LINE__);
+    const int T = mean_r <= 8.0 ? 1 : (mean_r <= 24.0 ? 2 : 4);
     const unsigned g = (unsigned)(((long)nr * T + VB - 1) / VB);
 #define RS_LAUNCH(TT)                                                                                                \
     do {                                                                                                             \
@@ -873,15 +854,11 @@ static int remote_sums_launch(lcg_hip_csr *A, const double *xfull, double *out, 
 }
 
 // u != nullptr: the product also leaves y.u as partial sums in part[0 .. *slots) -- the local product's (folded to <= 512), then one per
-// block of the remote-column finisher.  *fused says whether it did (when not, the plain product was made).
-// fp (with fp->fin set): the kernel that completes the sum also closes the iteration body with its last block (finish_body); when the
-// product is made without it, fp->fin is cleared.
-static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const double *u, double *part, int *slots, bool *fused, FinishPlan *fp)
+// block of the remote-column kernel.  *fused says whether it did (when not, the plain product was made).
+static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const double *u, double *part, int *slots, bool *fused)
 {
     Ctx &c = ctx();
     if (fused) *fused = false;
-    FinishPlan fin;                     // what the finishing kernel is handed (fin.fin == 0: nothing)
-    if (fp) { fin = *fp; fp->fin = FIN_NONE; }
     bool dot = u != nullptr && !A->is_complex;
     int nslot = 0;
     const size_t w = A->is_complex ? 2 : 1;
@@ -900,7 +877,11 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
         return LCG_HIP_E_COMM;
     }
     if (A->dist_mode == 2 && A->direct) {
-        // one stream, no collective: [push blocks + local product] | [wait for flags + remote product]
+        // One stream, no collective, no event: [pushing blocks | local product | receiving blocks] | remote-column product.
+        // (Measured and retired, LAB_NOTES / DESIGN 9: the receiving kernels on a second stream behind a join event -- equal, 114.2 vs
+        //  114.6 us on the 8-way shard; the remote-column product gathering straight from the landing zone -- 4 us faster with one
+        //  rank per GPU, but every block of that grid spins on the neighbours' flags and ranks that share a GPU starve each other;
+        //  the scalar step in the last block of the remote-column kernel -- nothing, 101.2 vs 100.4 us per iteration.)
         if (static_cast<Direct *>(A->direct)->uses_mailbox &&
             (!g_xg.connected || static_cast<Direct *>(A->direct)->generation != g_xg_generation)) {
             c.err = "direct exchange: the mailboxes were disconnected (or connected anew) while this matrix still uses them (distribute it again)";
@@ -911,130 +892,79 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
         const double mean_l = A->n_rows ? (double)A->loc.nnz / A->n_rows : 0.0;
         // test hook (tests/test_gpu_direct.py): this rank computes but never pushes -- what a dead link looks like to its neighbours
         static const bool withhold = std::getenv("LCG_HIP_TEST_WITHHOLD_PUSH") != nullptr;
-        static const bool one_stream_ = [] { const char *e = lab_env("LCG_HIP_DIRECT_STREAMS"); return !(e && atoi(e) == 2); }();
-        static const bool land_ = [] { const char *e = lab_env("LCG_HIP_DIRECT_LAND"); return e && atoi(e) == 1; }();
         // The receiving blocks ride in the tail of the product's grid (devcommon.hpp: recv_block) instead of being a kernel of their
-        // own behind it: one launch and one kernel boundary less per product, and the copies run beside the product's last blocks.
-        // They are the LAST blocks to be dispatched and few (one per 4096 doubles received), so they cannot keep the pushing
-        // blocks of a rank that shares this GPU from running.  LCG_HIP_RECV_KERNEL=1: k_recv as its own kernel again (A/B runs).
-        static const bool recv_kernel_ = [] { const char *e = lab_env("LCG_HIP_RECV_KERNEL"); return e && atoi(e) == 1; }();
-        const bool recv_in_tail = !recv_kernel_ && !withhold && one_stream_ && !land_ && wp.n > 0;
+        // own behind it (k_recv; 84.5 -> 81.3 us per A.x on the self-loop shard): one launch and one kernel boundary less per product,
+        // and the copies run beside the product's last blocks.  FORWARD PROGRESS: a receiving block spins until the neighbours'
+        // pushing blocks have run, and pushing blocks wait for nobody -- they sit at the FRONT of their grid, receiving blocks at the
+        // END of theirs.  Work-groups are dispatched in index order (observed on every gfx9 part; HIP does not promise it), so by
+        // the time a receiving block holds a CU slot every pushing block of its own grid has been dispatched; and should dispatch
+        // ever be reordered, a wait could only become a dead-lock if the receiving blocks of ONE grid filled every slot of the GPU
+        // -- hence the bound below: at most RECV_TAIL_MAX receiving blocks (the chip holds >= 1280 work-groups of this size), the
+        // receive as a kernel of its own beyond it (as under the withhold hook, whose product has no pushing grid).  Every wait
+        // ends in a time-out in any case (LCG_HIP_P2P_TIMEOUT_MS), which stops all ranks' solves with LCG_HIP_E_COMM.
+        constexpr int RECV_TAIL_MAX = 256;
+        const bool recv_in_tail = !withhold && wp.n > 0 && cp.nblocks <= RECV_TAIL_MAX;
         if (recv_in_tail) {
             pp.nrecv = cp.nblocks; pp.rnseg = cp.nseg; pp.wp = wp; pp.rst = c.in_solve ? c.state : nullptr;
             for (int q = 0; q < cp.nseg; q++) { pp.rsrc[q] = cp.src[q]; pp.rdst[q] = cp.dst[q]; pp.rcount[q] = cp.count[q]; }
             for (int q = 0; q <= cp.nseg && q <= XG_MAXSEG; q++) pp.rfirst[q] = cp.first_block[q];
             if (pp.nrecv <= 0) pp.nrecv = 1;        // flag-only neighbours: one block awaits the flags
         }
-        // the remote part's share of the dot rides in the single-stream k_remote; its blocks must fit behind the local sums
+        // the remote part's share of the dot rides in k_remote; its blocks must fit behind the local sums
         const long rem_blocks = A->remc.n_rows > 0 ? ((long)A->remc.n_rows * 4 + VB - 1) / VB : 0;
-        dot = dot && !withhold && one_stream_ && !land_ && 512 + rem_blocks <= AXP_CAP;
+        dot = dot && !withhold && 512 + rem_blocks <= AXP_CAP;
         int rc = 0, f = 0;
-        int nbig = 0;       // per-block sums of the local product the finisher folds (0: the local product folded them itself)
+        int nbig = 0;       // per-block sums of the local product that k_remote folds (0: the local product folded them itself)
         if (dot) {
-            // (without remote columns the fold of the local sums is the kernel that completes them)
-            f = csr_part_ax_dot(A->loc, A->variant, mean_l, x, y, u, 0, part, &nslot, c.stream, done, &pp, A->remc.n_rows > 0 ? &nbig : nullptr,
-                                A->remc.n_rows > 0 ? nullptr : &fin);
+            f = csr_part_ax_dot(A->loc, A->variant, mean_l, x, y, u, 0, part, &nslot, c.stream, done, &pp, A->remc.n_rows > 0 ? &nbig : nullptr);
             if (f < 0) return f;
         }
         dot = f == 1;
-        if (!dot) fin.fin = FIN_NONE;
         if (!dot)
             rc = withhold ? spmv_launch(A->loc, A->is_complex, A->variant, mean_l, x, y, false, c.stream, done)
                           : spmv_launch_push(A->loc, A->is_complex, A->variant, mean_l, x, y, c.stream, done, pp);
         if (rc) return rc;
-        // One stream by default: product (pushing blocks in front, receiving blocks behind) | k_remote, no event at all
-        // (the receiving blocks as a kernel of their own -- k_recv -- under LCG_HIP_RECV_KERNEL=1, the two-stream form and the withhold hook).
-        // LCG_HIP_DIRECT_STREAMS=2 puts the receiving kernels on the second stream -- enqueued AFTER the
-        // pushing product (so that, even if both streams shared a hardware queue, my push is never behind
-        // my wait) and without a fork event (they depend on the neighbours' flags, not on this stream);
-        // their sums land in the half of rem_y that belongs to this call and are added to y behind one
-        // join event.  Measured equal on the 8-way shard (114.2 vs 114.6 us): the join costs what it hides.
-        static const bool one_stream = [] { const char *e = lab_env("LCG_HIP_DIRECT_STREAMS"); return !(e && atoi(e) == 2); }();
-        hipStream_t rs = one_stream ? c.stream : c.comm_stream;
         Direct *D = static_cast<Direct *>(A->direct);
-        // LCG_HIP_DIRECT_LAND=1: the remote-column product gathers straight from the landing zone (every block
-        // waits for the flags itself, system-scope loads): one launch less, 113 -> 109 us per A.x on the 8-way
-        // shard.  Opt-in, because every block of that grid then SPINS until the neighbours' data is there:
-        // with one rank per GPU that is harmless, but ranks that share a GPU (the 4-rank stress of
-        // scripts/direct_stress.py) fill every CU slot with spinning blocks and starve the product whose
-        // pushing blocks they wait for.  k_recv spins with a few dozen blocks only.
-        static const int land_env = [] { const char *e = lab_env("LCG_HIP_DIRECT_LAND"); return e ? atoi(e) : 0; }();
-        const bool sparse_halo = D->recv_total * 4 <= (long long)(A->n_global - A->n_rows);
-        const bool land = land_env == 1 && one_stream && A->remc.n_rows > 0;
         if (debug_on() && D->calls == 1)
-            std::fprintf(stderr, "[lcg_hip] direct: land=%d (env %d, sparse %d, recv %lld, n_global %lld, rows %d) one_stream=%d\n", (int)land,
-                         land_env, (int)sparse_halo, D->recv_total, (long long)A->n_global, A->n_rows, (int)one_stream);
-        const double *landing = D->recv + (size_t)(D->calls & 1) * D->half;
-        if (wp.n > 0 && !land && !recv_in_tail) {    // flags are awaited even after a stop: the neighbours' calls stay paired with mine
-            hipLaunchKernelGGL(k_recv, dim3((unsigned)cp.nblocks), dim3(VB), 0, rs, wp, cp, c.in_solve ? c.state : nullptr);
+            std::fprintf(stderr, "[lcg_hip] direct: recv %lld doubles in %d blocks (%s), n_global %lld, rows %d\n", D->recv_total, cp.nblocks,
+                         recv_in_tail ? "tail of the product's grid" : "k_recv", (long long)A->n_global, A->n_rows);
+        if (wp.n > 0 && !recv_in_tail) {    // flags are awaited even after a stop: the neighbours' calls stay paired with mine
+            hipLaunchKernelGGL(k_recv, dim3((unsigned)cp.nblocks), dim3(VB), 0, c.stream, wp, cp, c.in_solve ? c.state : nullptr);
             HIPCHK(hipGetLastError());
         }
         if (A->remc.n_rows > 0) {
             const int nr = A->remc.n_rows;
-            const size_t w = A->is_complex ? 2 : 1;
-            double *sums = A->rem_y + (size_t)(D->calls & 1) * w * (size_t)nr;
             const double mean_r = (double)A->remc.nnz / nr;
-            int T = mean_r <= 8.0 ? 1 : (mean_r <= 24.0 ? 2 : 4);
-            if (const char *e = lab_env("LCG_HIP_REMOTE_T")) T = atoi(e);
-#define REMOTE_LAUNCH(TT, TOY, OUT)                                                                                  \
+            const int T = mean_r <= 8.0 ? 1 : (mean_r <= 24.0 ? 2 : 4);
+#define REMOTE_LAUNCH(TT)                                                                                            \
     do {                                                                                                             \
         const unsigned g = (unsigned)(((long)nr * TT + VB - 1) / VB);                                                \
         if (A->is_complex)                                                                                           \
-            hipLaunchKernelGGL((k_remote<double2, TT, TOY>), dim3(g), dim3(VB), 0, rs, nr, A->remc.rowptr, A->remc.col, \
+            hipLaunchKernelGGL((k_remote<double2, TT, true>), dim3(g), dim3(VB), 0, c.stream, nr, A->remc.rowptr, A->remc.col, \
                                reinterpret_cast<const double2 *>(A->remc.val), A->rem_rows,                          \
-                               reinterpret_cast<const double2 *>(A->xfull), reinterpret_cast<double2 *>(OUT), done); \
+                               reinterpret_cast<const double2 *>(A->xfull), reinterpret_cast<double2 *>(y), done);   \
         else                                                                                                         \
-            hipLaunchKernelGGL((k_remote<double, TT, TOY>), dim3(g), dim3(VB), 0, rs, nr, A->remc.rowptr, A->remc.col, \
-                               A->remc.val, A->rem_rows, A->xfull, OUT, done);                                       \
-    } while (0)
-#define REMOTE_LAND(TT)                                                                                              \
-    do {                                                                                                             \
-        const unsigned g = (unsigned)(((long)nr * TT + VB - 1) / VB);                                                \
-        DevState *st = c.in_solve ? c.state : nullptr;                                                               \
-        if (A->is_complex)                                                                                           \
-            hipLaunchKernelGGL((k_remote<double2, TT, true, true>), dim3(g), dim3(VB), 0, rs, nr, A->remc.rowptr, A->remc.col, \
-                               reinterpret_cast<const double2 *>(A->remc.val), A->rem_rows,                          \
-                               reinterpret_cast<const double2 *>(landing), reinterpret_cast<double2 *>(y), done, wp, st); \
-        else                                                                                                         \
-            hipLaunchKernelGGL((k_remote<double, TT, true, true>), dim3(g), dim3(VB), 0, rs, nr, A->remc.rowptr, A->remc.col, \
-                               A->remc.val, A->rem_rows, landing, y, done, wp, st);                                  \
+            hipLaunchKernelGGL((k_remote<double, TT, true>), dim3(g), dim3(VB), 0, c.stream, nr, A->remc.rowptr, A->remc.col, \
+                               A->remc.val, A->rem_rows, A->xfull, y, done);                                         \
     } while (0)
 #define REMOTE_DOT(TT)                                                                                               \
     do {                                                                                                             \
         const unsigned g = (unsigned)(((long)nr * TT + VB - 1) / VB);                                                \
-        fin.pc.axp = part; fin.pc.ax_n = nslot + (int)g;                                                             \
-        hipLaunchKernelGGL((k_remote<double, TT, true, false, true>), dim3(g), dim3(VB), 0, rs, nr, A->remc.rowptr, A->remc.col, \
-                           A->remc.val, A->rem_rows, A->xfull, y, done, WaitPlan(), (DevState *)nullptr, u, part + nslot, \
-                           nbig ? A->loc.dot_part : nullptr, nbig, (int)((nbig + g - 1) / g), fin);                      \
+        hipLaunchKernelGGL((k_remote<double, TT, true, true>), dim3(g), dim3(VB), 0, c.stream, nr, A->remc.rowptr, A->remc.col, \
+                           A->remc.val, A->rem_rows, A->xfull, y, done, u, part + nslot,                             \
+                           nbig ? A->loc.dot_part : nullptr, nbig, (int)((nbig + g - 1) / g));                       \
         nslot += (int)g;                                                                                             \
     } while (0)
-#define REMOTE_CASE(TT) case TT: if (dot) REMOTE_DOT(TT); else if (land) REMOTE_LAND(TT); else if (one_stream) REMOTE_LAUNCH(TT, true, y); else REMOTE_LAUNCH(TT, false, sums); break;
+#define REMOTE_CASE(TT) case TT: if (dot) REMOTE_DOT(TT); else REMOTE_LAUNCH(TT); break;
             switch (T) {
                 REMOTE_CASE(1) REMOTE_CASE(2) REMOTE_CASE(4)
-            default: return fail(hipErrorInvalidValue, "bad lanes-per-row for the remote-column product", __FILE__, __LINE__);
             }
 #undef REMOTE_CASE
 #undef REMOTE_DOT
-#undef REMOTE_LAND
 #undef REMOTE_LAUNCH
             HIPCHK(hipGetLastError());
-            if (!one_stream) {
-                HIPCHK(hipEventRecord(c.ev_b, rs));
-                HIPCHK(hipStreamWaitEvent(c.stream, c.ev_b, 0));
-                const unsigned g = (unsigned)((nr + VB - 1) / VB);
-                if (A->is_complex)
-                    hipLaunchKernelGGL((k_scatter_add<double2>), dim3(g), dim3(VB), 0, c.stream, nr, A->rem_rows,
-                                       reinterpret_cast<const double2 *>(sums), reinterpret_cast<double2 *>(y), done);
-                else
-                    hipLaunchKernelGGL((k_scatter_add<double>), dim3(g), dim3(VB), 0, c.stream, nr, A->rem_rows, sums, y, done);
-                HIPCHK(hipGetLastError());
-            }
-        } else if (wp.n > 0 && !one_stream) {
-            // flag-only neighbours: the main stream must still not run ahead of the receive
-            HIPCHK(hipEventRecord(c.ev_b, rs));
-            HIPCHK(hipStreamWaitEvent(c.stream, c.ev_b, 0));
         }
-        if (dot) { *slots = nslot; *fused = true; if (fp) fp->fin = fin.fin; }
+        if (dot) { *slots = nslot; *fused = true; }
         return 0;
     }
     double *mine = A->xfull + w * (size_t)(A->row0);
@@ -1055,10 +985,7 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
     // ... followed there by the product of the remote columns (few rows: their sums go to rem_y) ...
     int rc = 0;
     if (A->remc.n_rows > 0) {
-        static const bool rowblocks = [] { const char *e = lab_env("LCG_HIP_REMOTE_ROWBLOCKS"); return e && atoi(e) == 1; }();     // A/B runs
-        const double mean_r = (double)A->remc.nnz / A->remc.n_rows;
-        rc = rowblocks ? spmv_launch(A->remc, A->is_complex, 0, mean_r, A->xfull, A->rem_y, false, c.comm_stream, done)
-                       : remote_sums_launch(A, A->xfull, A->rem_y, c.comm_stream, done);
+        rc = remote_sums_launch(A, A->xfull, A->rem_y, c.comm_stream, done);
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(c.ev_b, c.comm_stream));
@@ -1070,12 +997,10 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
         dot = dot && 512 + rem_blocks <= AXP_CAP;
         int f = 0;
         if (dot) {
-            f = csr_part_ax_dot(A->loc, A->variant, mean_l, x, y, u, 0, part, &nslot, c.stream, done, nullptr, A->remc.n_rows > 0 ? &nbig01 : nullptr,
-                                A->remc.n_rows > 0 ? nullptr : &fin);
+            f = csr_part_ax_dot(A->loc, A->variant, mean_l, x, y, u, 0, part, &nslot, c.stream, done, nullptr, A->remc.n_rows > 0 ? &nbig01 : nullptr);
             if (f < 0) return f;
         }
         dot = f == 1;
-        if (!dot) fin.fin = FIN_NONE;
     }
     if (!dot) rc = spmv_launch(A->loc, A->is_complex, A->variant, mean_l, x, y, false, c.stream, done);
     if (rc) return rc;
@@ -1083,13 +1008,12 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
     if (dot) {
         if (A->remc.n_rows > 0) {
             const unsigned g = (unsigned)((A->remc.n_rows + VB - 1) / VB);
-            fin.pc.axp = part; fin.pc.ax_n = nslot + (int)g;
             hipLaunchKernelGGL(k_scatter_add_dot, dim3(g), dim3(VB), 0, c.stream, A->remc.n_rows, A->rem_rows, A->rem_y, y, u, part + nslot,
-                               nbig01 ? A->loc.dot_part : nullptr, nbig01, (int)((nbig01 + g - 1) / g), done, fin);
+                               nbig01 ? A->loc.dot_part : nullptr, nbig01, (int)((nbig01 + g - 1) / g), done);
             HIPCHK(hipGetLastError());
             nslot += (int)g;
         }
-        *slots = nslot; *fused = true; if (fp) fp->fin = fin.fin;
+        *slots = nslot; *fused = true;
         return 0;
     }
     if (A->remc.n_rows > 0) {
@@ -1105,20 +1029,13 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
     return rc;
 }
 
-int dist_spmv(lcg_hip_csr *A, const double *x, double *y) { return dist_spmv_impl(A, x, y, nullptr, nullptr, nullptr, nullptr, nullptr); }
+int dist_spmv(lcg_hip_csr *A, const double *x, double *y) { return dist_spmv_impl(A, x, y, nullptr, nullptr, nullptr, nullptr); }
 
-int dist_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots, FinishPlan *fp)
+int dist_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots)
 {
-    static const bool off = [] { const char *e = lab_env("LCG_HIP_AX_DOT_SHARDED"); return e && atoi(e) == 0; }();     // A/B runs
-    // The step in the finishing kernel's last block (finish_body) is OPT-IN (LCG_HIP_FINISHER=1): measured on the one-rank rehearsal of
-    // the 8-way shard it buys nothing -- 101.2 vs 100.4 us per iteration at K = 500, 116.5 vs 114.1 at K = 20 (slow box), 101.2 vs 101.7
-    // and 112.9 vs 113.8 (fast box): what a scalar step costs is its chain of dependent memory round trips (partials, mailbox
-    // stores, their acknowledgement, the poll, the peers' sums, the state), and that chain is as long at the end of a kernel as in
-    // a kernel of its own; the launch it saves is hidden behind the previous kernel's tail anyway.
-    static const bool fin_on = [] { const char *e = std::getenv("LCG_HIP_FINISHER"); return e && atoi(e) == 1; }();
-    if (fp && !fin_on) fp->fin = FIN_NONE;
+    static const bool off = [] { const char *e = lab_env("LCG_HIP_AX_DOT_SHARDED"); return e && atoi(e) == 0; }();     // A/B runs (LAB build)
     bool fused = false;
-    const int rc = dist_spmv_impl(A, x, y, (yy || off) ? nullptr : u, part, slots, &fused, fp);
+    const int rc = dist_spmv_impl(A, x, y, (yy || off) ? nullptr : u, part, slots, &fused);
     return rc ? (rc > 0 ? -rc : rc) : (fused ? 1 : 2);
 }
 

@@ -800,10 +800,8 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
 
 // The <= 512-way second stage of a product's per-block sums: block i adds the slice [i * per, (i + 1) * per) of `big` in a
 // fixed order and leaves it in out[i] (the y.y sums, `stride` further on, in out[AXP_CAP + i]).
-// fp.fin != 0 (sharded rows without remote columns, y.u only): the block whose sum is the last to arrive also closes the body
-// (devcommon.hpp: finish_body).
 __global__ __launch_bounds__(VB) void k_axp_fold(const double *__restrict__ big, int nblk, int stride, int per, int yy, double *__restrict__ out,
-                                                 const int *done, FinishPlan fp)
+                                                 const int *done)
 {
     __shared__ double sh[2][VB / 64];
     if (done && *done) return;
@@ -825,13 +823,12 @@ __global__ __launch_bounds__(VB) void k_axp_fold(const double *__restrict__ big,
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == WSUM_LANE) { sh[0][wv] = a0; sh[1][wv] = a1; }
     __syncthreads();
-    double t = 0.0;
     if (threadIdx.x < 2 && (threadIdx.x == 0 || yy)) {
+        double t = 0.0;
 #pragma unroll
         for (int q = 0; q < VB / 64; q++) t += sh[threadIdx.x][q];
-        if (!fp.fin || threadIdx.x == 1) out[threadIdx.x * AXP_CAP + blockIdx.x] = t;
+        out[threadIdx.x * AXP_CAP + blockIdx.x] = t;
     }
-    if (fp.fin) finish_body(fp, out + blockIdx.x, t);
 }
 
 // ---- short rows (<= 17 entries on average: 5-point / 7-point stencils, the 1000 x 1000 Laplacian of BASELINE configs[1]) ---------
@@ -1922,8 +1919,6 @@ int spmv_launch_push(const CsrPart &P, bool is_complex, int variant, double mean
 // part does not take the packed kernel (nothing was launched), < 0 failure.
 // nofold != nullptr: the second stage is left to the caller (comm.hip folds the per-block sums in the kernel that finishes the
 // shard's product anyway): *nofold = number of per-block sums waiting in P.dot_part, nothing is written to `part`.
-// fp != nullptr with fp->fin set (and the fold made here, y.u only): the fold's last block also closes the iteration body
-// (devcommon.hpp: finish_body); fp->pc.ax_n is completed here.  The caller learns it from *slots as always.
 static bool ensure_dot_part(const CsrPart &P, long count)
 {   // (the packed kernel leaves a sum per 64 rows, the tiled one per 1024: a part that changes family needs the larger buffer)
     if (P.dot_part && P.dot_cap >= count) return true;
@@ -1934,7 +1929,7 @@ static bool ensure_dot_part(const CsrPart &P, long count)
 }
 
 int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double *x, double *y, const double *u, int yy, double *part,
-                    int *slots, hipStream_t s, const int *done, const PushPlan *pp, int *nofold, const FinishPlan *fp)
+                    int *slots, hipStream_t s, const int *done, const PushPlan *pp, int *nofold)
 {
     const int n = P.n_rows;
     if (n <= 0 || (variant != 0 && variant != -1)) return 0;
@@ -1955,9 +1950,7 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
         if (nofold) { *nofold = nchunk; *slots = 0; return 1; }
         const int g2 = std::min(512, (nchunk + VB - 1) / VB);
         const int per = (nchunk + g2 - 1) / g2;
-        FinishPlan fin;
-        if (fp && fp->fin && !yy) { fin = *fp; fin.pc.axp = part; fin.pc.ax_n = (nchunk + per - 1) / per; }
-        hipLaunchKernelGGL(k_axp_fold, dim3((nchunk + per - 1) / per), dim3(VB), 0, s, P.dot_part, nchunk, nchunk, per, yy, part, done, fin);
+        hipLaunchKernelGGL(k_axp_fold, dim3((nchunk + per - 1) / per), dim3(VB), 0, s, P.dot_part, nchunk, nchunk, per, yy, part, done);
         HIPCHK(hipGetLastError());
         *slots = (nchunk + per - 1) / per;
         return 1;
@@ -2001,9 +1994,7 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
     if (nofold) { *nofold = nblk; *slots = 0; return 1; }
     const int g2 = std::min(512, (nblk + VB - 1) / VB);
     const int per = (nblk + g2 - 1) / g2;
-    FinishPlan fin;
-    if (fp && fp->fin && !yy) { fin = *fp; fin.pc.axp = part; fin.pc.ax_n = (nblk + per - 1) / per; }
-    hipLaunchKernelGGL(k_axp_fold, dim3((nblk + per - 1) / per), dim3(VB), 0, s, P.dot_part, nblk, nblk, per, yy, part, done, fin);
+    hipLaunchKernelGGL(k_axp_fold, dim3((nblk + per - 1) / per), dim3(VB), 0, s, P.dot_part, nblk, nblk, per, yy, part, done);
     HIPCHK(hipGetLastError());
     P.last_kernel = ldsp_name(P, true);
     *slots = (nblk + per - 1) / per;
@@ -2013,23 +2004,22 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
 // A.x with the dot(s) that follow it in the Krylov loops carried in the product (k_spmv_lds1d / k_spmv_ldsp<DOT> / k_spmv_run1d): real
 // matrices, the LDS-staged one-window family.  Everything else answers 0 and the caller multiplies and reduces in two launches as before.
 int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots, hipStream_t s,
-               const int *done, FinishPlan *fp)
+               const int *done)
 {
     static const bool off = [] { const char *e = std::getenv("LCG_HIP_AX_DOT"); return e && atoi(e) == 0; }();
     if (off || !A || A->is_complex || A->n_rows <= 0) return 0;
-    if (A->distributed) return dist_ax_dot(A, x, y, u, yy, part, slots, fp);
-    if (fp) fp->fin = FIN_NONE;        // (one GPU: the step rides in the NEXT pass instead -- driver.hpp, vecf)
+    if (A->distributed) return dist_ax_dot(A, x, y, u, yy, part, slots);
     const CsrPart &P = A->main;
     const int n = P.n_rows;
     if (A->variant != 0 && A->variant != -1) return 0;
     if (ranges_chosen(P, s)) return 0;  // multiplied range by range: the dot keeps its own pass
     if (A->mean_row > 160.0 || ((((uintptr_t)P.val | (uintptr_t)P.col) & 15) != 0)) return 0;
     if (binned_chosen(P, s)) return 0;
-    if (tiled_chosen(P, s)) return csr_part_ax_dot(P, A->variant, A->mean_row, x, y, u, yy, part, slots, s, done, nullptr, nullptr, nullptr);
+    if (tiled_chosen(P, s)) return csr_part_ax_dot(P, A->variant, A->mean_row, x, y, u, yy, part, slots, s, done, nullptr, nullptr);
     int R = 0; bool onewin = false;
     { int rc = lds_shape<double>(P, -1, A->mean_row, s, &R, &onewin); if (rc) return rc; }
     if (!onewin) return 0;
-    if (R == PK_R && packed_ready(P, s)) return csr_part_ax_dot(P, A->variant, A->mean_row, x, y, u, yy, part, slots, s, done, nullptr, nullptr, nullptr);
+    if (R == PK_R && packed_ready(P, s)) return csr_part_ax_dot(P, A->variant, A->mean_row, x, y, u, yy, part, slots, s, done, nullptr, nullptr);
     if ((R == 32 || R == 16) && long_rows_packed() && packed_ready(P, s, R)) return 0;     // (the product alone: see csr_part_ax_dot)
     const int nblk = (n + R - 1) / R;
     static const bool run1_off = [] { const char *e = lab_env("LCG_HIP_RUN1"); return e && atoi(e) == 0; }();

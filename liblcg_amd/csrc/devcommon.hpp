@@ -478,8 +478,8 @@ __device__ __forceinline__ void reduce_partials(const double *partials, const Pa
 }
 
 template <class Fin>
-__global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, PartCount G, DevState *st, int mode, XgBox xb)
-{
+__global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, PartCount G, DevState *st, int mode, XgBox xb, DevState *snap = nullptr)
+{   // snap (host-mapped pinned memory, or null): the state this step leaves, for the sharded loop's host (driver.hpp: run_lockstep)
     constexpr int NRA = Fin::NR > 0 ? Fin::NR : 1;
     constexpr int SW = (int)(sizeof(DevState) / 8);
     __shared__ double sums[NRA];
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, Pa
     if (mode == SC_XGMI && Fin::NR > 0) {
         if (!xg_allreduce<NRA>(xb, sums, tk)) {
             // every rank sees the failure of this or a later exchange and stops the same way
-            if (threadIdx.x == 0) { st->done = 1; st->status = ST_COMM; }
+            if (threadIdx.x == 0) { st->done = 1; st->status = ST_COMM; if (snap) { snap->done = 1; snap->status = ST_COMM; } }
             return;
         }
     }
@@ -509,11 +509,14 @@ __global__ __launch_bounds__(VB) void k_scal(Fin fin, const double *partials, Pa
     __syncthreads();
     if (threadIdx.x == 0) fin(&L, sums);
     __syncthreads();
-    if ((int)threadIdx.x < SW) reinterpret_cast<double *>(st)[threadIdx.x] = reinterpret_cast<const double *>(&L)[threadIdx.x];
+    if ((int)threadIdx.x < SW) {
+        const double w = reinterpret_cast<const double *>(&L)[threadIdx.x];
+        reinterpret_cast<double *>(st)[threadIdx.x] = w;
+        if (snap) reinterpret_cast<double *>(snap)[threadIdx.x] = w;     // posted writes; the host reads behind an event on this stream
+    }
 }
 
-// ---- the body-closing step of plain CG's one-reduction schedule (solvers_real.hip), here because a sharded product's last
-// block may run it (finish_body below) ----------------------------------------------------------------------------------
+// ---- the body-closing step of plain CG's one-reduction schedule (solvers_real.hip) -------------------------------------------
 enum { S_AK = 0, S_BK, S_WK, S_RHO /* g.g | z.r | r.r0 */, S_M2, S_G2 /* residual numerator */ };   // DevState::s slots of the real solvers
 __device__ __forceinline__ double clamp1(double v) { return v < 1.0 ? 1.0 : v; }
 struct FinCg1Close {    // the only scalar step of a body: counts it, closes it, prepares the next
@@ -541,44 +544,6 @@ struct FinCg1Close {    // the only scalar step of a body: counts it, closes it,
     }
 };
 
-// Called by EVERY thread of EVERY block of a kernel whose blocks each leave one partial sum (thread 0 holds the block's: v, to be
-// stored at *slot), at a point all threads of the block reach.  The block that takes the last ticket closes the iteration body:
-// it adds up everything that waits (reduce_partials, fixed order: the bits of k_scal), lets the sums meet the other ranks'
-// (xg_allreduce) and runs the step -- the launch of k_scal and the kernel boundary in front of it are gone.
-// Hand-off between blocks (any XCD): the partial is stored write-through at agent scope and acknowledged (vmcnt) before the
-// ticket is taken; the last block invalidates its caches (agent acquire) behind its own ticket and a workgroup barrier before
-// it reads the others' sums (MI355X_MICROARCH.md, cross-workgroup hand-offs: "Consumer, always").
-__device__ __forceinline__ void finish_body(const FinishPlan &fp, double *slot, double v)
-{
-    __shared__ int last_s;
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int t = __hip_atomic_fetch_add(fp.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = t + 1u == gridDim.x ? 1 : 0;
-    }
-    __syncthreads();
-    if (!last_s) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(fp.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the next launch starts from zero
-    constexpr int NRA = 4;
-    __shared__ double fsums[NRA];
-    XgTicket tk;
-    if (fp.xg) tk = xg_begin(fp.xb);
-    reduce_partials<NRA>(fp.partials, fp.pc, fsums);
-    if (fp.xg && !xg_allreduce<NRA>(fp.xb, fsums, tk)) {
-        if (threadIdx.x == 0) { fp.st->done = 1; fp.st->status = ST_COMM; }
-        return;
-    }
-    if (threadIdx.x == 0) {
-        switch (fp.fin) {
-        case FIN_CG1_CLOSE: FinCg1Close{}(fp.st, fsums); break;
-        default: break;
-        }
-    }
-}
 
 // ---- scalar step fused into the pass that consumes it (single GPU) ------------------------------------------------
 // One CG iteration used to be six kernels, two of them one-block scalar steps on the critical path (5-8 us each plus a

@@ -112,20 +112,26 @@ struct Driver {
     }
 
     // scalar step after the most recent reducing vec()
+    // The sharded loop's host decides from the state as of the LAST body of a batch (run_lockstep).  With sharded rows only the
+    // scalar steps change DevState, so every step of that body leaves the state it produced in `snap_to` (host-mapped; the body's
+    // last step wins, in stream order): no device-to-host copy and none of its two boundaries on the stream.
+    DevState *snap_to = nullptr;
+    int snap_taken = 0;
     template <class Fin> int scal(Fin fin)
     {
         const PartCount g = pcnt;
         XgBox xb;
+        if (snap_to) snap_taken++;
         if (comm_active() && Fin::NR > 0 && xg_box(&xb)) {
             // reduce + exchange over the peer mailboxes + scalar step in one launch
-            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_XGMI, xb);
+            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_XGMI, xb, snap_to);
         } else if (comm_active() && Fin::NR > 0) {
-            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_REDUCE, xb);
+            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_REDUCE, xb, (DevState *)nullptr);
             int rc = comm_allreduce(c.state->red, Fin::NR, c.stream);
             if (rc) return rc;
-            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FIN, xb);
+            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FIN, xb, snap_to);
         } else {
-            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FUSED, xb);
+            hipLaunchKernelGGL((k_scal<Fin>), dim3(1), dim3(VB), 0, c.stream, fin, c.partials, g, c.state, SC_FUSED, xb, snap_to);
         }
         HIPCHK(hipGetLastError());
         return dbg(typeid(Fin).name());
@@ -142,7 +148,6 @@ struct Driver {
         // every body where a body is long and only 6 are kept in flight
         h.pub_mask = comm_active() ? 0x3fffffff : ((cplx ? 2 * n : n) >= (1 << 20) ? 0 : 3);
         if (const char *e = lab_env("LCG_HIP_PUBLISH_EVERY")) h.pub_mask = std::max(1, atoi(e)) - 1;
-        c.fin_steps = 0;
         c.hstat->it = 0; c.hstat->done = 0; c.hstat->status = 0; c.hstat->t = 0; c.hstat->residual = 0.0;
         (void)lcg_hip_last_ax_mean_us();        // a previous solve's events, if nobody asked yet: they are about to be reused
         // from a pinned staging slot, in stream order in front of the solve's first kernel: no synchronisation here (the
@@ -269,9 +274,16 @@ struct Driver {
             int todo = batch;
             if (max_it > 0) todo = std::min(batch, max_it - enq);
             if (todo <= 0) break;
-            for (int i = 0; i < todo; i++) { rc = body(); if (rc) return rc; enq++; }
             const int slot = nb & 1;
-            HIPCHK(hipMemcpyAsync(c.snap[slot], c.state, sizeof(DevState), hipMemcpyDeviceToHost, c.stream));
+            for (int i = 0; i < todo; i++) {
+                if (i == todo - 1) { snap_to = c.snap_dev[slot]; snap_taken = 0; }
+                rc = body();
+                if (rc) { snap_to = nullptr; return rc; }
+                enq++;
+            }
+            snap_to = nullptr;
+            // (a body without a scalar step of its own -- none of the built-in loops -- is copied the old way)
+            if (!snap_taken) HIPCHK(hipMemcpyAsync(c.snap[slot], c.state, sizeof(DevState), hipMemcpyDeviceToHost, c.stream));
             HIPCHK(hipEventRecord(c.snap_ev[slot], c.stream));
             nb++;
             if (nb >= 2) {
@@ -280,7 +292,15 @@ struct Driver {
                 if (c.snap[prev]->done) break;
             }
         }
-        rc = read_state(h); if (rc) return rc;
+        // the verdict: the snapshot behind the last batch (bodies enqueued after a stop fall through: counts, residual and status
+        // are those of the stop) -- the stream is drained by waiting for that batch's event, nothing is copied
+        if (nb > 0) {
+            HIPCHK(hipEventSynchronize(c.snap_ev[(nb - 1) & 1]));
+            HIPCHK(hipStreamSynchronize(c.stream));
+            std::memcpy(&h, c.snap[(nb - 1) & 1], sizeof h);
+        } else {
+            rc = read_state(h); if (rc) return rc;
+        }
         if (h.status == ST_COMM) return comm_lost(h);
         finish(h);
         if (h.status == ST_ALREADY) return LCG_ALREADY_OPTIMIZIED;

@@ -118,21 +118,7 @@ struct DotPlan {
     int ystore = 0;         // how k_spmv_ldsp stores y (devcommon.hpp: store_y; set by the host from y_store_policy())
 };
 
-// The scalar step that closes an iteration body, run by the LAST block of the kernel that completes the body's last sum (the
-// finisher of a sharded product: k_remote / k_scatter_add_dot / k_axp_fold) instead of by a kernel of its own: the block whose
-// ticket is the last one reduces every pending partial sum in the usual fixed order (reduce_partials: the same bits as k_scal),
-// exchanges the sums with the other ranks over the mailboxes and runs the step (devcommon.hpp: finish_body).
-enum { FIN_NONE = 0, FIN_CG1_CLOSE = 1 };
 struct DevState;
-struct FinishPlan {
-    int fin = FIN_NONE;
-    int xg = 0;                         // 1: the sums meet the other ranks' over the mailboxes first (xb)
-    unsigned int *ticket = nullptr;     // blocks of the finishing kernel that have left their sum (the last one resets it)
-    const double *partials = nullptr;   // the table of the latest reducing pass
-    PartCount pc;                       // what waits where: the pass's rows, and the product's sums (axp, ax_n, ax_row)
-    DevState *st = nullptr;
-    XgBox xb;
-};
 
 // Mirror of the stop state in host-mapped pinned memory; written by the scalar kernels,
 // polled by the host without touching the stream.
@@ -174,13 +160,12 @@ struct Ctx {
     DevState *state = nullptr;         // the state the next kernel is handed (one of state_pair: driver.hpp, vecf)
     double *partials_pair[2] = {nullptr, nullptr};
     double *ax_partials = nullptr;     // [2][AXP_CAP]: the sums an A.x kernel carried (csr.hip: k_spmv_lds1d), see PartCount
-    unsigned int *fin_ticket = nullptr; // FinishPlan::ticket (zero between launches)
-    int fin_steps = 0;                  // scalar steps of the latest solve that a product's last block ran (finish_body)
     DevState *state_pair[2] = {nullptr, nullptr};
     HostStatus *hstat = nullptr;       // pinned, mapped
     HostStatus *hstat_dev = nullptr;   // device alias of hstat
     double *scratch_host = nullptr;    // pinned, 64 doubles
-    DevState *snap[2] = {nullptr, nullptr};     // pinned: per-batch copies of DevState (sharded loop, driver.hpp)
+    DevState *snap[2] = {nullptr, nullptr};     // pinned, mapped: per-batch copies of DevState (sharded loop, driver.hpp)
+    DevState *snap_dev[2] = {nullptr, nullptr}; // their device aliases (written by the batch's last scalar step)
     hipEvent_t snap_ev[2] = {nullptr, nullptr};
     Comm *comm = nullptr;
     int last_iters = 0;
@@ -305,13 +290,11 @@ int spmv_launch_push(const CsrPart &P, bool is_complex, int variant, double mean
 int jacobi_launch(const lcg_hip_csr *A, const double *x, double *z, int n, hipStream_t s);
 // y = A.x with the sums y.u (and y.y) riding in the product: 1 = done, *slots partial sums wait in part[0 .. *slots) (and
 // part[AXP_CAP ..)); 0 = this matrix / kernel family cannot (nothing was launched: the caller multiplies and reduces as before); < 0 failure
-// fp (may be null): a step the product's last block should run once its sums are complete (sharded rows with the mailboxes);
-// on return fp->fin is still set if it will, FIN_NONE if the caller has to launch the step itself
 int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots, hipStream_t s,
-               const int *done_flag, FinishPlan *fp);
+               const int *done_flag);
 // the packed kernel of one part carrying y.u (and y.y), optionally with a shard's pushing blocks in front: 1 launched, 0 not this part
 int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double *x, double *y, const double *u, int yy, double *part,
-                    int *slots, hipStream_t s, const int *done_flag, const PushPlan *pp, int *nofold, const FinishPlan *fp);
+                    int *slots, hipStream_t s, const int *done_flag, const PushPlan *pp, int *nofold);
 // csr_binned.hip
 int binned_ready(const CsrPart &P, hipStream_t s);      // 1 plan ready, 0 not eligible, < 0 failure
 int binned_launch(const CsrPart &P, const double *x, double *y, hipStream_t s, const int *done_flag);
@@ -335,9 +318,9 @@ int comm_allreduce(double *dev, int count, hipStream_t s);
 bool comm_active();
 bool xg_box(XgBox *out);        // true when the direct all-reduce is connected and enabled
 int dist_spmv(lcg_hip_csr *A, const double *x, double *y);
-// the sharded product, carrying y.u where it can: the local product's partial sums (folded) followed by the remote-column finisher's, in
+// the sharded product, carrying y.u where it can: the local product's partial sums (folded) followed by the remote-column kernel's, in
 // part[0 .. *slots).  The product is ALWAYS made: 1 = with the sum, 2 = without it (the caller reduces in its own pass), < 0 failure
-int dist_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots, FinishPlan *fp);
+int dist_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots);
 int dist_spmv_op(lcg_hip_csr *A, const CsrPart &T, const double *x, double *y);     // y = this rank's rows of A^T.x / A^H.x (T = (A_r)^T, csr.hip: op_part)
 
 } // namespace lcgh

@@ -53,15 +53,14 @@ int ensure_init()
     }
     c.partials = c.partials_pair[0];
     HIPCHK(hipMalloc(&c.ax_partials, sizeof(double) * 2 * AXP_CAP));
-    HIPCHK(hipMalloc(&c.fin_ticket, sizeof(unsigned int)));
-    HIPCHK(hipMemset(c.fin_ticket, 0, sizeof(unsigned int)));
     c.state = c.state_pair[0];
     HIPCHK(hipHostMalloc((void **)&c.hstat, sizeof(HostStatus), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void **)&c.hstat_dev, c.hstat, 0));
     HIPCHK(hipHostMalloc((void **)&c.scratch_host, sizeof(double) * 64, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c.state_stage, sizeof(DevState), hipHostMallocDefault));
     for (int i = 0; i < 2; i++) {
-        HIPCHK(hipHostMalloc((void **)&c.snap[i], sizeof(DevState), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&c.snap[i], sizeof(DevState), hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(hipHostGetDevicePointer((void **)&c.snap_dev[i], c.snap[i], 0));
         HIPCHK(hipEventCreateWithFlags(&c.snap_ev[i], hipEventDisableTiming));
     }
     c.inited = true;
@@ -248,7 +247,7 @@ int lcg_hip_trim(void)
     return 0;
 }
 int lcg_hip_last_ax_calls(void) { return ctx().last_ax_calls; }
-int lcg_hip_last_finisher_steps(void) { return ctx().fin_steps; }
+int lcg_hip_last_finisher_steps(void) { return 0; }      // (the experiment it counted is retired: lcg_hip.h)
 
 int lcg_hip_set_cg_schedule(int schedule)
 {
@@ -294,7 +293,7 @@ int lcg_hip_spmv_dot(lcg_hip_csr_t A, const double *x, double *y, const double *
     int rc = ensure_init(); if (rc) return rc;
     Ctx &c = ctx();
     int slots = 0;
-    const int f = csr_ax_dot(A, x, y, u, 1, c.ax_partials, &slots, c.stream, nullptr, nullptr);
+    const int f = csr_ax_dot(A, x, y, u, 1, c.ax_partials, &slots, c.stream, nullptr);
     if (f < 0) return f;
     if (f == 0) {       // this matrix / kernel family keeps product and reduction apart
         rc = lcg_hip_spmv(A, x, y); if (rc) return rc;

@@ -411,27 +411,17 @@ struct RealCommon {
     // y = A.x followed by the sums y.u (and y.y): with the built-in product on a handle this process holds whole, the sums ride
     // in the product's epilogue (csr.hip: k_spmv_lds1d) and reach the next scalar step as its sum `row` (y.y: row + 1) -- *fused
     // says so; otherwise the product is made as always and the caller runs its own reducing pass
-    // fin_id / stepped: with sharded rows and the mailboxes the product's last block can also run the step that closes the body
-    // (FIN_*: devcommon.hpp, finish_body) -- *stepped says it will, and the caller then launches no scalar kernel.
-    int ax_dot(const double *x, double *y, const double *u, bool yy, int row, bool *fused, int fin_id = FIN_NONE, bool *stepped = nullptr)
+    int ax_dot(const double *x, double *y, const double *u, bool yy, int row, bool *fused)
     {
         int f = 0, slots = 0;
-        FinishPlan fp;
-        if (stepped) *stepped = false;
-        if (fin_id != FIN_NONE && stepped && !yy && comm_active() && xg_box(&fp.xb)) {
-            fp.fin = fin_id; fp.xg = 1; fp.ticket = c.fin_ticket; fp.partials = c.partials; fp.st = c.state;
-            fp.pc = drv.pcnt; fp.pc.axp = c.ax_partials; fp.pc.ax_n = 0; fp.pc.ax_row = row; fp.pc.ax_yy = 0; fp.pc.g[row] = 0;
-        }
         // (sharded rows: csr_ax_dot hands over to comm.hip, which always makes the product and answers 1 when it carried the sum, 2 when not)
         const bool builtin = Afp == lcg_hip_csr_ax && inst != nullptr;
         int rc = drv.timed_ax([&] {
-            if (builtin) f = csr_ax_dot(static_cast<lcg_hip_csr *>(inst), x, y, u, yy ? 1 : 0, c.ax_partials, &slots, c.stream, &c.state->done,
-                                        fp.fin ? &fp : nullptr);
+            if (builtin) f = csr_ax_dot(static_cast<lcg_hip_csr *>(inst), x, y, u, yy ? 1 : 0, c.ax_partials, &slots, c.stream, &c.state->done);
             if (f == 0) Afp(inst, x, y, n);
             else if (f < 0 && !c.ax_rc) c.ax_rc = f;
         });
         *fused = f == 1;
-        if (stepped) { *stepped = f == 1 && builtin && fp.fin != FIN_NONE; if (*stepped) c.fin_steps++; }
         if (f == 1) {
             PartCount &pc = drv.pcnt;
             pc.axp = c.ax_partials; pc.ax_n = slots; pc.ax_row = row; pc.ax_yy = yy ? 1 : 0;
@@ -521,13 +511,11 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
             TRY(k.drv.scal(FinCg1Start{}));
             rc = k.run_loop([&]() -> int {
                 TRY(k.drv.vec(OpCg1UpdateSums{st, m, g, d, Ad, w, 0.0, 0.0, nt}, a_upd | al(w)));
-                bool stepped = false;
                 if (!last_body()) {
-                    // (sharded rows with the mailboxes: the last block of the kernel that completes g.w reduces, exchanges and steps)
-                    bool f; TRY(k.ax_dot(g, w, g, false, 2, &f, FIN_CG1_CLOSE, &stepped));
+                    bool f; TRY(k.ax_dot(g, w, g, false, 2, &f));
                     if (!f) { c.err = "A.x stopped carrying its dot in the middle of a solve"; return LCG_HIP_E_ARG; }
                 }
-                if (!stepped) TRY(k.drv.scal(FinCg1Close{}));
+                TRY(k.drv.scal(FinCg1Close{}));
                 return 0;
             });
         } else if (Pfp == nullptr && !comm_active()) {

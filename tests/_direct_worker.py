@@ -79,8 +79,6 @@ def main(ref_path, out_path):
             info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, r1 - r0, para, A, sid)
             xt = ref[f"{tag}/x1"][r0:r1]
             res[f"{tag}/{name}"] = [int(info.ret), int(info.iterations), float(np.abs(m.cpu().numpy() - xt).max())]
-            if name == "cg":
-                res[f"{tag}/cg_finisher_steps"] = int(lib.lcg_hip_last_finisher_steps())
             say(tag, name, res[f"{tag}/{name}"])
         if sym:
             A.build_jacobi()

@@ -74,8 +74,7 @@ def _reference(path, cases=CASES, with_complex=True):
     return out
 
 
-@pytest.mark.parametrize("streams", ["1", "2"])
-def test_three_ranks_on_one_gpu_direct_exchange(tmp_path, streams):
+def test_three_ranks_on_one_gpu_direct_exchange(tmp_path):
     ref_path = str(tmp_path / "ref.npz")
     ref = _reference(ref_path)
     world = 3
@@ -83,8 +82,8 @@ def test_three_ranks_on_one_gpu_direct_exchange(tmp_path, streams):
     for r in range(world):
         out = str(tmp_path / f"direct_{r}.json")
         outs.append(out)
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29571 + int(streams)),
-                   LCG_HIP_P2P_TIMEOUT_MS="8000", LCG_HIP_DIRECT_STREAMS=streams)
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29571",
+                   LCG_HIP_P2P_TIMEOUT_MS="8000")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_direct_worker.py"), ref_path, out],
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     logs = []
