@@ -48,6 +48,8 @@ SIGNATURES = {
     "lcg_hip_last_residual": (C.c_double, []),
     "lcg_hip_set_profiling": (C.c_int, [C.c_int]),
     "lcg_hip_set_cg_schedule": (C.c_int, [C.c_int]),
+    "lcg_hip_set_placement": (C.c_int, [C.c_int]),
+    "lcg_hip_last_placement": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lcg_hip_last_ax_mean_us": (C.c_double, []),
     "lcg_hip_last_ax_calls": (C.c_int, []),
     "lcg_hip_last_finisher_steps": (C.c_int, []),

@@ -24,8 +24,6 @@
 
 namespace lcgh {
 
-int device_exclusive_scan(int n, const int *counts, int *rowptr, hipStream_t s, long *total);   // csr.hip
-void free_part(CsrPart &P);                                                                     // csr.hip
 
 struct Comm {
     void *lib = nullptr;

@@ -35,7 +35,6 @@
 
 namespace lcgh {
 
-int device_exclusive_scan(int n, const int *counts, int *rowptr, hipStream_t s, long *total);   // csr.hip
 
 constexpr int BN_C = 8192;          // columns per tile (x slice in LDS: 64 KB)
 constexpr int BN_C_LOG2 = 13;

@@ -40,7 +40,6 @@
 
 namespace lcgh {
 
-int device_exclusive_scan(int n, const int *counts, int *rowptr, hipStream_t s, long *total);   // csr.hip
 
 typedef unsigned long long u64t;
 constexpr int TL_MAXNW = 8;         // most consumer wavefronts (chunks) per workgroup

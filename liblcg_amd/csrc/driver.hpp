@@ -9,12 +9,14 @@
 // synchronisation per iteration.
 #pragma once
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <functional>
 #include <cstring>
 #include <thread>
 #include <typeinfo>
+#include <vector>
 
 #include "devcommon.hpp"
 
@@ -370,7 +372,7 @@ struct Workspace {
         if (best < 0) {
             // nothing fits: give one idle smaller vector back and allocate
             for (size_t i = 0; i < c.scratch.size(); i++)
-                if (!c.scratch[i].busy) { (void)hipFree(c.scratch[i].p); c.scratch.erase(c.scratch.begin() + i); break; }
+                if (!c.scratch[i].busy) { (void)hipFree(c.scratch[i].p); c.scratch.erase(c.scratch.begin() + i); c.place_memo.clear(); break; }
             double *p = nullptr;
             HIPCHK(hipMalloc(&p, bytes));
             c.scratch.push_back({p, bytes, false});
@@ -383,6 +385,13 @@ struct Workspace {
         return 0;
     }
     std::vector<double *> held;
+    bool owns(const double *p) const { for (double *h : held) if (h == p) return true; return false; }
+    // an idle vector of the pool joins this solve (Placement: it becomes a product's output)
+    void adopt(double *p)
+    {
+        for (auto &s : ctx().scratch) if (s.p == p) s.busy = true;
+        held.push_back(p);
+    }
     ~Workspace()
     {
         Ctx &c = ctx();
@@ -390,6 +399,151 @@ struct Workspace {
             for (auto &s : c.scratch)
                 if (s.p == p) s.busy = false;
     }
+};
+
+// ---- where the product's output lies (lcg_hip.h: lcg_hip_set_placement; profiles/r04_placement.txt) ---------------
+// The time of a large y = A.x depends on WHICH allocation y is: 520-530 us or 580-595 us for the headline system, constant for
+// the lifetime of the pair (value array, y), the same for every x -- the read stream and the written vector either share a stretch of
+// memory or do not (scripts/placement_lab6.hip: six read buffers x sixteen written buffers fall into matching groups; nothing the
+// process can see -- virtual address, size, allocation call -- tells the group, only the clock does).  The solvers allocate their
+// work vectors anyway: before the first iteration the product's OUTPUT roles go to those the product writes fastest.
+struct Placement {
+    static bool wanted(Ctx &c, int n, const void *afp, const void *inst)
+    {
+        if (c.place_mode == 0 || afp != (const void *)lcg_hip_csr_ax || inst == nullptr) return false;
+        const lcg_hip_csr *A = static_cast<const lcg_hip_csr *>(inst);
+        if (A->is_complex || n != A->n_rows || n < 4096) return false;
+        if (c.place_mode > 0) return true;
+        // the effect needs a stream that comes from memory, not from the 256 MB Infinity Cache (an 8-way shard of the 10M-row
+        // system streams 490 MB)
+        return (long)part(A).nnz * 12L >= (384L << 20);
+    }
+    // the rows this process multiplies by itself: the whole matrix, or -- sharded -- the entries with locally owned columns
+    static const CsrPart &part(const lcg_hip_csr *A) { return A->distributed ? A->loc : A->main; }
+    static float *memo(Ctx &c, const void *val, const double *y)
+    {
+        for (auto &m : c.place_memo) if (m.val == val && m.y == y) return &m.us;
+        return nullptr;
+    }
+    // what y = A.x takes into `y`: one product to warm up (the first of a matrix also builds its plan), two timed
+    static int time_output(Ctx &c, const lcg_hip_csr *A, const double *x, double *y, float *us)
+    {
+        const CsrPart &P = part(A);
+        if (float *m = memo(c, P.val, y)) { *us = *m; return 0; }
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        int rc = spmv_launch(P, false, A->variant, A->mean_row, x, y, false, c.stream, nullptr);
+        if (!rc) rc = hipEventRecord(e0, c.stream) == hipSuccess ? 0 : LCG_HIP_E_RUNTIME;
+        for (int i = 0; i < 2 && !rc; i++) rc = spmv_launch(P, false, A->variant, A->mean_row, x, y, false, c.stream, nullptr);
+        if (!rc && (hipEventRecord(e1, c.stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = LCG_HIP_E_RUNTIME;
+        float ms = 0.f;
+        if (!rc && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = LCG_HIP_E_RUNTIME;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (rc) return rc;
+        *us = ms * 500.f;
+        c.place_memo.push_back({P.val, y, *us});
+        c.place_timed++;
+        return 0;
+    }
+    // outs: the roles the solver's products write, most frequent first; rest: the other work vectors.  Roles whose vector the caller
+    // supplied stay where they are.  x: any n-vector that holds finite numbers (the right-hand side).
+    static int run(Ctx &c, int n, const void *afp, void *inst, const double *x, Workspace &ws,
+                   std::initializer_list<double **> outs, std::initializer_list<double **> rest)
+    {
+        c.place_timed = c.place_moved = 0; c.place_us_first = c.place_us_chosen = 0.0;
+        if (!wanted(c, n, afp, inst)) return 0;
+        const lcg_hip_csr *A = static_cast<const lcg_hip_csr *>(inst);
+        const size_t bytes = sizeof(double) * (size_t)n;
+        const void *val = part(A).val;
+        constexpr float SAME = 1.03f;       // the two classes lie 8-12 % apart; timings of one class within 1-2 %
+        struct Cand { double **role; double *p; float us; };
+        std::vector<Cand> cand;
+        for (double **r : outs) if (ws.owns(*r)) cand.push_back({r, *r, 0.f});
+        const size_t n_out = cand.size();
+        if (n_out == 0) return 0;
+        for (double **r : rest) if (ws.owns(*r)) cand.push_back({r, *r, 0.f});
+        for (auto &s : c.scratch) if (!s.busy && s.bytes >= bytes) cand.push_back({nullptr, s.p, 0.f});   // idle vectors of the pool
+        {   // the plan of a matrix is built by its first product: not on the clock
+            if (part(A).last_kernel[0] == 0) { int rc = spmv_launch(part(A), false, A->variant, A->mean_row, x, cand[0].p, false, c.stream, nullptr); if (rc) return rc; }
+        }
+        for (auto &k : cand) { int rc = time_output(c, A, x, k.p, &k.us); if (rc) return rc; }
+        c.place_us_first = cand[0].us;
+        auto spread = [&]() { float lo = cand[0].us, hi = cand[0].us; for (auto &k : cand) { lo = std::min(lo, k.us); hi = std::max(hi, k.us); } return hi / lo; };
+        // All alike: fast or slow?  Only a vector from elsewhere can tell.  Memory falls into three groups, each made of stretches
+        // several GiB long (scripts/placement_lab7.hip: 64 allocations of 1 GiB in a row map as AABBBCCCCCCCCCAAAAAAC...;
+        // scripts/placement_walk.py: the product into 128 such chunks is slow for the first 3-4, then fast for 16, ...), and what is
+        // allocated one after the other lies side by side.  So the library walks: chunks of 1 GiB, one after the other and all held,
+        // the product timed into the start of each, until one is clearly faster (or clearly slower: then ours are the fast kind) --
+        // at most 8 (where a faster place exists it was 3-4 chunks away; on boxes whose free memory is one long stretch of the same
+        // group nothing faster lies within 127 GiB, and allocations beyond 4 GiB cost 30 ms per GiB: profiles/r04_placement.txt),
+        // never into the last 4 GiB of free memory.  The fast chunk is given back and a vector of the right size taken in
+        // its place (the allocator hands out the nearest free memory first); should that one not be fast, the chunk itself serves.
+        // Everything else is given back at once.  One walk per matrix.
+        if (spread() < SAME && memo(c, val, nullptr) == nullptr) {
+            constexpr size_t CH = (size_t)1 << 30;
+            size_t p2 = 1; while (p2 < bytes) p2 <<= 1;
+            auto forget_y = [&](const double *y) {
+                for (size_t i = 0; i < c.place_memo.size(); i++) if (c.place_memo[i].y == y) { c.place_memo.erase(c.place_memo.begin() + i); break; }
+            };
+            std::vector<double *> chunks;
+            double *found = nullptr; float found_us = 0.f; size_t found_bytes = 0; int rc = 0;
+            for (int k = 0; k < 8 && bytes <= CH; k++) {
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 5 * CH) break;
+                double *p = nullptr;
+                if (hipMalloc(&p, CH) != hipSuccess) { (void)hipGetLastError(); break; }
+                chunks.push_back(p);
+                float us = 0.f;
+                rc = time_output(c, A, x, p, &us);
+                if (rc) break;
+                if (us * SAME < cand[0].us) { found = p; found_us = us; found_bytes = CH; break; }
+                if (cand[0].us * SAME < us) break;          // slower than ours: ours are the fast kind, nothing to find
+            }
+            if (found && !rc) {
+                chunks.pop_back(); (void)hipFree(found); forget_y(found); found = nullptr;
+                double *v = nullptr; float us = 0.f;
+                if (hipMalloc(&v, p2) == hipSuccess) {
+                    rc = time_output(c, A, x, v, &us);
+                    if (!rc && us * SAME < cand[0].us) { found = v; found_us = us; found_bytes = p2; }
+                    else { (void)hipFree(v); forget_y(v); }
+                } else (void)hipGetLastError();
+                if (!found && !rc && hipMalloc(&v, CH) == hipSuccess) {
+                    rc = time_output(c, A, x, v, &us);
+                    if (!rc && us * SAME < cand[0].us) { found = v; found_us = us; found_bytes = CH; }
+                    else { (void)hipFree(v); forget_y(v); }
+                }
+            }
+            if (debug_on()) fprintf(stderr, "[lcg_hip] placement walk: %zu chunks of 1 GiB given back, %s (%.1f us, %zu MiB kept)\n", chunks.size(),
+                                    found ? "a faster place found" : "nothing faster", found_us, found_bytes >> 20);
+            for (double *p : chunks) { (void)hipFree(p); forget_y(p); }
+            if (rc) { if (found) { (void)hipFree(found); forget_y(found); } return rc; }
+            if (found) { c.scratch.push_back({found, found_bytes, false}); cand.push_back({nullptr, found, found_us}); }
+            c.place_memo.push_back({val, nullptr, 0.f});
+        }
+        // the fastest vectors to the output roles, in order; a role keeps its vector unless another is clearly faster.  Positions
+        // trade vectors, so every role still has a vector of its own; a vector of the pool that lands in a role joins the solve
+        // (the one it displaced stays with the solve, unused, and returns to the pool with the others).
+        const size_t n_own = n_out + [&] { size_t k = 0; for (double **r : rest) if (ws.owns(*r)) k++; return k; }();
+        for (size_t o = 0; o < n_out; o++) {
+            size_t best = o;
+            for (size_t j = o + 1; j < cand.size(); j++) if (cand[j].us < cand[best].us) best = j;
+            if (best != o && cand[best].us * SAME < cand[o].us) { std::swap(cand[o].p, cand[best].p); std::swap(cand[o].us, cand[best].us); }
+        }
+        for (size_t i = 0; i < n_own; i++) {
+            if (*cand[i].role == cand[i].p) continue;
+            *cand[i].role = cand[i].p;
+            if (!ws.owns(cand[i].p)) ws.adopt(cand[i].p);
+            if (i < n_out) c.place_moved++;
+        }
+        c.place_us_chosen = cand[0].us;
+        if (debug_on()) {
+            fprintf(stderr, "[lcg_hip] placement: %d timed, %d moved; output %.1f -> %.1f us;", c.place_timed, c.place_moved, c.place_us_first, c.place_us_chosen);
+            for (auto &k : cand) fprintf(stderr, " %.1f", k.us);
+            fprintf(stderr, "\n");
+        }
+        return 0;
+    }
+    static void forget(Ctx &c) { c.place_memo.clear(); }
 };
 
 } // namespace lcgh

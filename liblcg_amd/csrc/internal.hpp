@@ -186,6 +186,14 @@ struct Ctx {
     // iterations of a small system; lcg_hip_trim() gives them back)
     struct Scratch { double *p; size_t bytes; bool busy; };
     std::vector<Scratch> scratch;
+    // where the product's output lies (driver.hpp: Placement): what y = A.x took into a given vector against a given matrix
+    // (val = the matrix's value array; y == nullptr: "no better place found for this matrix, stop looking")
+    struct PlaceMemo { const void *val; const double *y; float us; };
+    std::vector<PlaceMemo> place_memo;
+    int place_mode = -1;               // lcg_hip_set_placement: -1 auto (large products on one GPU), 0 never, 1 whenever the callback is the built-in one
+    int place_timed = 0;               // candidates timed by the latest solve (0: answered from the memo, or not tried)
+    int place_moved = 0;               // outputs the latest solve moved to another vector
+    double place_us_first = 0.0, place_us_chosen = 0.0;   // the latest solve's first output: as allocated / as placed
     unsigned shadow_seed = 1;
     std::vector<double> shadow_vec;    // explicit rbar0 for the next complex solve
     std::string err;
@@ -258,7 +266,7 @@ struct lcg_hip_csr {
     int n_cols = 0;         // columns addressed by `main` (global when sharded)
     bool is_complex = false;
     lcgh::CsrPart main;     // the whole shard (global columns)
-    lcgh::CsrPart op[4];    // [1] conj(A), [2] A^T, [3] A^H as their own CSR, built on first use (csr.hip: op_part)
+    lcgh::CsrPart op[4];    // [1] conj(A), [2] A^T, [3] A^H as their own CSR, built on first use (csr_build.hip: op_part)
     double *invdiag = nullptr;  // reciprocal diagonal (1 or 2 doubles per row)
     int variant = 0;        // SpMV kernel choice (0 auto)
     double mean_row = 0.0;
@@ -287,7 +295,7 @@ int spmv_launch(const CsrPart &P, bool is_complex, int variant, double mean_row,
 // the same product with `pp.nblocks` pushing blocks in front of the grid (comm.hip, dist mode 2)
 int spmv_launch_push(const CsrPart &P, bool is_complex, int variant, double mean_row, const double *x, double *y,
                      hipStream_t s, const int *done_flag, const PushPlan &pp);
-int jacobi_launch(const lcg_hip_csr *A, const double *x, double *z, int n, hipStream_t s);
+int jacobi_launch(const lcg_hip_csr *A, const double *x, double *z, int n, hipStream_t s);       // csr_build.hip
 // y = A.x with the sums y.u (and y.y) riding in the product: 1 = done, *slots partial sums wait in part[0 .. *slots) (and
 // part[AXP_CAP ..)); 0 = this matrix / kernel family cannot (nothing was launched: the caller multiplies and reduces as before); < 0 failure
 int csr_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots, hipStream_t s,
@@ -311,7 +319,12 @@ void tiled_free(CsrPart &P);
 long tiled_traffic_bytes(const CsrPart &P);
 long tiled_tile_copy_bytes(const CsrPart &P);
 size_t tiled_plan_bytes(const CsrPart &P);
+// csr_build.hip
 int op_part(lcg_hip_csr *A, int layout, int conjugate, const CsrPart **out);
+int alloc_part(CsrPart &P, int n_rows, long nnz, bool cplx);        // owned, padded arrays of a part
+int device_exclusive_scan(int n, const int *counts, int *rowptr, hipStream_t s, long *total);
+// csr.hip
+void free_part(CsrPart &P);                                          // a part's arrays and every plan built beside them
 
 // comm.hip
 int comm_allreduce(double *dev, int count, hipStream_t s);
@@ -321,6 +334,6 @@ int dist_spmv(lcg_hip_csr *A, const double *x, double *y);
 // the sharded product, carrying y.u where it can: the local product's partial sums (folded) followed by the remote-column kernel's, in
 // part[0 .. *slots).  The product is ALWAYS made: 1 = with the sum, 2 = without it (the caller reduces in its own pass), < 0 failure
 int dist_ax_dot(lcg_hip_csr *A, const double *x, double *y, const double *u, int yy, double *part, int *slots);
-int dist_spmv_op(lcg_hip_csr *A, const CsrPart &T, const double *x, double *y);     // y = this rank's rows of A^T.x / A^H.x (T = (A_r)^T, csr.hip: op_part)
+int dist_spmv_op(lcg_hip_csr *A, const CsrPart &T, const double *x, double *y);     // y = this rank's rows of A^T.x / A^H.x (T = (A_r)^T, csr_build.hip: op_part)
 
 } // namespace lcgh

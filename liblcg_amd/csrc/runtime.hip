@@ -63,6 +63,7 @@ int ensure_init()
         HIPCHK(hipHostGetDevicePointer((void **)&c.snap_dev[i], c.snap[i], 0));
         HIPCHK(hipEventCreateWithFlags(&c.snap_ev[i], hipEventDisableTiming));
     }
+    if (const char *e = std::getenv("LCG_HIP_PLACE")) { const int v = atoi(e); if (v >= -1 && v <= 1 && c.place_mode == -1) c.place_mode = v; }
     c.inited = true;
     return 0;
 }
@@ -244,6 +245,22 @@ int lcg_hip_trim(void)
     (void)hipDeviceSynchronize();
     for (auto it = c.scratch.begin(); it != c.scratch.end();)
         if (!it->busy) { (void)hipFree(it->p); it = c.scratch.erase(it); } else ++it;
+    c.place_memo.clear();       // (addresses may come back as other memory)
+    return 0;
+}
+int lcg_hip_set_placement(int mode)
+{
+    if (mode < -1 || mode > 1) return LCG_HIP_E_ARG;
+    ctx().place_mode = mode;
+    return 0;
+}
+int lcg_hip_last_placement(int *timed, int *moved, double *us_as_allocated, double *us_as_placed)
+{
+    Ctx &c = ctx();
+    if (timed) *timed = c.place_timed;
+    if (moved) *moved = c.place_moved;
+    if (us_as_allocated) *us_as_allocated = c.place_us_first;
+    if (us_as_placed) *us_as_placed = c.place_us_chosen;
     return 0;
 }
 int lcg_hip_last_ax_calls(void) { return ctx().last_ax_calls; }

@@ -460,6 +460,17 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
     HostBridge hb; TRY(hb.open(mem, m, B, sizeof(double) * n, c.stream));
     Workspace ws; double *g, *d, *Ad;
     TRY(ws.get(g, Gk, sizeof(double) * n)); TRY(ws.get(d, Dk, sizeof(double) * n)); TRY(ws.get(Ad, ADk, sizeof(double) * n));
+    // AUTO: the one-reduction schedule when the rows are sharded (one all-reduce per iteration) and on one GPU for systems so
+    // small that a launch costs more than a word per row (< 2^20 rows): two launches per iteration instead of three
+    // (a callback of the caller's own keeps the reference's recurrence and with it the reference's sequence of callback calls:
+    //  the one-reduction arrangement makes one product more before the first stop test)
+    const bool one_reduction = c.cg_schedule == LCG_HIP_CG_ONE_REDUCTION ||
+                               (c.cg_schedule == LCG_HIP_CG_AUTO && (comm_active() || (n < CG1_AUTO_ROWS && Afp == lcg_hip_csr_ax)));
+    double *w = nullptr;
+    if (one_reduction) TRY(ws.get(w, nullptr, sizeof(double) * n));
+    // the vector the loop's product writes (A.d; w = A.g in the one-reduction arrangement) goes where it is written fastest
+    if (one_reduction) TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&w}, {&Ad, &g, &d}));
+    else TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ad}, {&g, &d}));
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
@@ -469,14 +480,7 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
     TRY(k.drv.vec(OpCgInit{st, Ad, B, m, g, d}, al(Ad) | al(B) | al(m) | al(g) | al(d)));
     TRY(k.drv.scal(FinInit{}));
     const uintptr_t a_upd = al(m) | al(g) | al(d) | al(Ad);
-    // AUTO: the one-reduction schedule when the rows are sharded (one all-reduce per iteration) and on one GPU for systems so
-    // small that a launch costs more than a word per row (< 2^20 rows): two launches per iteration instead of three
-    // (a callback of the caller's own keeps the reference's recurrence and with it the reference's sequence of callback calls:
-    //  the one-reduction arrangement makes one product more before the first stop test)
-    const bool one_reduction = c.cg_schedule == LCG_HIP_CG_ONE_REDUCTION ||
-                               (c.cg_schedule == LCG_HIP_CG_AUTO && (comm_active() || (n < CG1_AUTO_ROWS && !k.drv.user_cb)));
     if (one_reduction) {
-        double *w; TRY(ws.get(w, nullptr, sizeof(double) * n));
         bool fused; TRY(k.ax_dot(g, w, g, false, 0, &fused));
         if (!fused) TRY(k.drv.vec(OpDot1{st, g, w}, al(g) | al(w)));
         int rc;
@@ -573,6 +577,7 @@ static int solve_pcg(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pf
     Workspace ws; double *r, *z, *d, *Ad;
     TRY(ws.get(r, nullptr, sizeof(double) * n)); TRY(ws.get(z, nullptr, sizeof(double) * n));
     TRY(ws.get(d, nullptr, sizeof(double) * n)); TRY(ws.get(Ad, nullptr, sizeof(double) * n));
+    TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ad}, {&r, &z, &d}));      // (A.d goes where it is written fastest)
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
@@ -667,6 +672,7 @@ static int solve_cgs(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const 
     const size_t nb = sizeof(double) * n;
     TRY(ws.get(r, RK, nb)); TRY(ws.get(r0, R0T, nb)); TRY(ws.get(pk, PK, nb)); TRY(ws.get(Ax, AX, nb));
     TRY(ws.get(u, UK, nb)); TRY(ws.get(q, QK, nb)); TRY(ws.get(w, WK, nb));
+    TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ax}, {&r, &r0, &pk, &u, &q, &w}));    // (both products write Ax)
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
@@ -701,6 +707,7 @@ static int solve_bicgstab(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, c
     const size_t nb = sizeof(double) * n;
     TRY(ws.get(r, nullptr, nb)); TRY(ws.get(r0, nullptr, nb)); TRY(ws.get(pk, nullptr, nb));
     TRY(ws.get(Ax, nullptr, nb)); TRY(ws.get(s, nullptr, nb)); TRY(ws.get(Ap, nullptr, nb));
+    TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ap, &Ax}, {&r, &r0, &pk, &s}));       // (A.p and A.s)
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
@@ -843,6 +850,7 @@ static int solve_bicgstab2(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, 
     const size_t nb = sizeof(double) * n;
     TRY(ws.get(r, nullptr, nb)); TRY(ws.get(r0, nullptr, nb)); TRY(ws.get(pk, nullptr, nb));
     TRY(ws.get(Ax, nullptr, nb)); TRY(ws.get(s, nullptr, nb)); TRY(ws.get(Ap, nullptr, nb));
+    TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ap, &Ax}, {&r, &r0, &pk, &s}));       // (A.p and A.s)
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
