@@ -11,6 +11,9 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "lib", "liblcg_hip.so")
+# A/B runs of scripts/ only: LCG_HIP_LAB=1 loads the LAB build (`make -C liblcg_amd/csrc LAB=1`: the closed experiments' knobs compiled in)
+if os.environ.get("LCG_HIP_LAB") == "1" and os.path.exists(os.path.join(HERE, "lib", "lab", "liblcg_hip.so")):
+    SO_PATH = os.path.join(HERE, "lib", "lab", "liblcg_hip.so")
 CSRC = os.path.join(HERE, "csrc")
 
 c_int_p = C.POINTER(C.c_int)

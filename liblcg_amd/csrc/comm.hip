@@ -801,7 +801,7 @@ int dist_spmv_op(lcg_hip_csr *A, const CsrPart &T, const double *x, double *y)
 {
     Ctx &c = ctx();
     const size_t w = A->is_complex ? 2 : 1;
-    const int *done = c.in_solve ? &c.state->done : nullptr;
+    const int *done = ax_flag(c);
     if (!g_comm.comm && world_size() > 1) {
         c.err = "op(A).x on a sharded matrix sums the ranks' contributions with RCCL: no communicator (lcg_hip_comm_init)";
         return LCG_HIP_E_COMM;
@@ -860,7 +860,7 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
     bool dot = u != nullptr && !A->is_complex;
     int nslot = 0;
     const size_t w = A->is_complex ? 2 : 1;
-    const int *done = c.in_solve ? &c.state->done : nullptr;
+    const int *done = ax_flag(c);
     if (A->dist_mode < 0) {
         c.err = "this matrix's exchange could not be set up (lcg_hip_csr_distribute failed): distribute it again under another mode";
         return LCG_HIP_E_COMM;

@@ -2316,7 +2316,7 @@ int lcg_hip_spmv_op(lcg_hip_csr_t A, const double *x, double *y, int layout, int
     if (rc) return rc;
     if (A->distributed) return dist_spmv_op(A, *P, x, y);
     return spmv_launch(*P, A->is_complex, A->variant, A->mean_row, x, y, false, c.stream,
-                       c.in_solve ? &c.state->done : nullptr);
+                       ax_flag(c));
 }
 
 
@@ -2326,7 +2326,7 @@ int lcg_hip_spmv(lcg_hip_csr_t A, const double *x, double *y)
     Ctx &c = ctx();
     if (A->distributed) return dist_spmv(A, x, y);
     return spmv_launch(A->main, A->is_complex, A->variant, A->mean_row, x, y, false, c.stream,
-                       c.in_solve ? &c.state->done : nullptr);
+                       ax_flag(c));
 }
 
 } // extern "C"

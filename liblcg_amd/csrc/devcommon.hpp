@@ -161,6 +161,13 @@ __device__ __forceinline__ double2 vmul(double2 a, double2 b) { return make_doub
 __device__ __forceinline__ double vmul(double a, double b) { return a * b; }
 __device__ __forceinline__ double2 vneg(double2 a) { return make_double2(-a.x, -a.y); }
 __device__ __forceinline__ double vneg(double a) { return -a; }
+// a vector that counts as all zeros when `zero` is set (the product of an all-zero initial guess, which was never made)
+template <class T> __device__ __forceinline__ T ldz(const double *p, long i, bool zero);
+template <> __device__ __forceinline__ double ldz<double>(const double *p, long i, bool zero) { return zero ? 0.0 : p[i]; }
+template <> __device__ __forceinline__ double2 ldz<double2>(const double *p, long i, bool zero)
+{
+    return zero ? make_double2(0.0, 0.0) : reinterpret_cast<const double2 *>(p)[i];
+}
 
 // complex helpers (double2 = re, im)
 __device__ __forceinline__ double2 cmul(double2 a, double2 b)

@@ -102,8 +102,8 @@ struct Driver {
     // closes it, once, after the last body and before the state is read.
     std::function<int()> tail;
     int run_tail() { if (!tail) return 0; auto t = std::move(tail); tail = nullptr; return t(); }
-    // LCG_HIP_DEBUG_SYNC=1: synchronise after every launch and name it on stderr (fault isolation)
-    bool debug_sync = std::getenv("LCG_HIP_DEBUG_SYNC") != nullptr;
+    // LCG_HIP_DEBUG=2: synchronise after every launch and name it on stderr (fault isolation)
+    bool debug_sync = debug_level() >= 2;
     int dbg(const char *what)
     {
         if (!debug_sync) return 0;

@@ -14,7 +14,7 @@
 namespace lcgh {
 
 // Run-time switches.  The shipped library reads the documented ones only ("Run-time switches": LCG_HIP_PACKED,
-// _TILED, _BINNED, _RANGES, _AX_DOT, _NT_VECTORS, _PACKED_WINDOW, _P2P_TIMEOUT_MS, _FORCE_COMM, _DEBUG, _DEBUG_SYNC,
+// _TILED, _BINNED, _RANGES, _AX_DOT, _NT_VECTORS, _PACKED_WINDOW, _P2P_TIMEOUT_MS, _FORCE_COMM, _DEBUG, _PLACE,
 // _TEST_WITHHOLD_PUSH).  The knobs of the closed experiments (LAB_NOTES: thresholds, ring depths, batch sizes, A/B
 // switches of single kernels) exist in a LAB BUILD only -- `make LAB=1` compiles with -DLCG_HIP_LAB -- and read as unset
 // otherwise, so that every branch they select folds away in the shipped .so.
@@ -34,12 +34,14 @@ inline int y_store_policy()
     const char *e = lab_env("LCG_HIP_Y_STORE");      // (read at every launch: a lab program switches it between launches)
     return e ? atoi(e) : 0;
 }
-// LCG_HIP_DEBUG=1: the plan builders and the direct exchange say on stderr what they chose and why
-inline bool debug_on()
+// LCG_HIP_DEBUG=1: the plan builders, the placement of the product's output and the direct exchange say on stderr what they chose and
+// why; 2: a solve also synchronises after every launch and names it (fault isolation)
+inline int debug_level()
 {
-    static const bool on = [] { const char *e = std::getenv("LCG_HIP_DEBUG"); return e && atoi(e) != 0; }();
-    return on;
+    static const int lv = [] { const char *e = std::getenv("LCG_HIP_DEBUG"); return e ? atoi(e) : 0; }();
+    return lv;
 }
+inline bool debug_on() { return debug_level() != 0; }
 
 
 constexpr int VB = 256;     // threads per block of every vector / scalar kernel
@@ -144,6 +146,7 @@ struct DevState {
     int done;           // set once: every later kernel becomes a no-op
     int status;         // ST_*
     int pub_mask;       // HostStatus is refreshed when (it & pub_mask) == 0, and at every stop
+    int zero_guess;     // the initial guess is all zeros (solvers_real.hip: ax_setup): its product is not made, A.m counts as zeros
     HostStatus *host;
 };
 
@@ -171,6 +174,7 @@ struct Ctx {
     int last_iters = 0;
     double last_residual = 0.0;
     bool in_solve = false;             // a Driver is alive: A.x may honour DevState::done
+    const int *ax_skip = nullptr;      // the flag the NEXT built-in products honour instead of DevState::done (solvers_real.hip: ax_setup)
     int ax_rc = 0;                     // first failure of a built-in callback (void by liblcg's typedef) during this solve
     int cg_schedule = 0;               // LCG_HIP_CG_*
     bool profile = false;
@@ -201,6 +205,8 @@ struct Ctx {
 
 Ctx &ctx();
 int ensure_init();
+// the flag a built-in product falls through on (null outside a solve)
+inline const int *ax_flag(Ctx &c) { return c.ax_skip ? c.ax_skip : (c.in_solve ? &c.state->done : nullptr); }
 int fail(hipError_t e, const char *what, const char *file, int line);
 
 #define HIPCHK(call)                                                        \

@@ -111,13 +111,34 @@ struct FinClose {
 };
 
 // ---- CG -------------------------------------------------------------------------------------
+// The reference multiplies the initial guess before anything else (lcg.cpp:168, 314, 476, 648).  The usual guess is all zeros, and
+// then so is that product: whether the guess is all zeros is decided ON THE DEVICE (every rank's count of non-zeros, summed like any
+// other sum of the loop, so all ranks decide alike), the product falls through on that flag the way every kernel falls through on the
+// stop flag, and the pass that consumes A.m reads zeros instead.  Same numbers as the product would have left (a sum of +-0 products).
+struct OpZeroProbe {    // how many components of the guess are not zero (NaN counts)
+    static constexpr int NR = 1, SKIP = SKIP_NEVER;
+    DevState *st; const double *m;
+    __device__ void prep() {}
+    template <class T> __device__ void apply(long i, double *acc) { acc[0] += nonzeros(ld<T>(m, i)); }
+    static __device__ double nonzeros(double v) { return v != 0.0 ? 1.0 : 0.0; }
+    static __device__ double nonzeros(double2 v) { return (v.x != 0.0 ? 1.0 : 0.0) + (v.y != 0.0 ? 1.0 : 0.0); }
+};
+struct FinZeroGuess {
+    static constexpr int NR = 1;
+    __device__ void operator()(DevState *st, const double *sum) const { st->zero_guess = sum[0] == 0.0 ? 1 : 0; }
+};
+
 struct OpCgInit {   // g = Ad - B; d = -g; m.m, g.g (x2: rho = g.g)      lcg.cpp:171-183
     static constexpr int NR = 3, SKIP = SKIP_NEVER;
     DevState *st; const double *Ad, *B, *m; double *g, *d;
-    __device__ void prep() {}
+    double *clear = nullptr;    // = Ad where the loop continues A.d by recurrence (one-reduction schedule): a product that was not made leaves no zeros behind
+    bool zg = false;
+    __device__ void prep() { zg = st->zero_guess != 0; }
     template <class T> __device__ void apply(long i, double *acc)
     {
-        const T gv = vsub(ld<T>(Ad, i), ld<T>(B, i));
+        const T av = ldz<T>(Ad, i, zg);
+        if (zg && clear) st_(clear, i, av);
+        const T gv = vsub(av, ld<T>(B, i));
         const T mv = ld<T>(m, i);
         st_(g, i, gv); st_(d, i, vneg(gv));
         acc[0] += dotp(mv, mv);
@@ -193,8 +214,15 @@ struct FinCg1Start {    // a_0 = g.g / g.A.g, b_0 = 0 (d_0 = -g, lcg.cpp:171-176
 struct OpResidual { // r = B - Ax   (also the start of CGS/BiCGStab with extra copies)
     static constexpr int NR = 0, SKIP = SKIP_NEVER;
     DevState *st; const double *Ax, *B; double *r;
-    __device__ void prep() {}
-    template <class T> __device__ void apply(long i, double *) { st_(r, i, vsub(ld<T>(B, i), ld<T>(Ax, i))); }
+    double *clear = nullptr;    // (as in OpCgInit)
+    bool zg = false;
+    __device__ void prep() { zg = st->zero_guess != 0; }
+    template <class T> __device__ void apply(long i, double *)
+    {
+        const T av = ldz<T>(Ax, i, zg);
+        if (zg && clear) st_(clear, i, av);
+        st_(r, i, vsub(ld<T>(B, i), av));
+    }
 };
 struct OpPcgInit2 { // d = z; m.m, r.r, z.r                               lcg.cpp:325-339
     static constexpr int NR = 3, SKIP = SKIP_NEVER;
@@ -300,11 +328,11 @@ struct FinPcg1Close {   // the only scalar step of a body (FinCg1Close with rho 
 template <bool WITH_U>
 struct OpShadowInit {   // p = (u =) r0 = r = B - Ax; m.m, r.r, r.r0      lcg.cpp:480-497 / 650-667
     static constexpr int NR = 3, SKIP = SKIP_NEVER;
-    DevState *st; const double *Ax, *B, *m; double *r, *r0, *p, *u;
-    __device__ void prep() {}
+    DevState *st; const double *Ax, *B, *m; double *r, *r0, *p, *u; bool zg = false;
+    __device__ void prep() { zg = st->zero_guess != 0; }
     template <class T> __device__ void apply(long i, double *acc)
     {
-        const T rv = vsub(ld<T>(B, i), ld<T>(Ax, i));
+        const T rv = vsub(ld<T>(B, i), ldz<T>(Ax, i, zg));
         const T mv = ld<T>(m, i);
         st_(r, i, rv); st_(r0, i, rv); st_(p, i, rv);
         if (WITH_U) st_(u, i, rv);
@@ -408,6 +436,24 @@ struct RealCommon {
         : c(c_), drv(c_, n_, false, p.max_iterations, p.epsilon, p.abs_diff), para(p), inst(inst_),
           Afp(A), Pfp(P), m(m_), n(n_) { drv.user_cb = A != lcg_hip_csr_ax; }
     int ax(const double *x, double *y) { return drv.timed_ax([&] { Afp(inst, x, y, n); }); }
+    // y = A.m for the initial guess (lcg.cpp:168, 314, 476, 648).  With the built-in product: the zero-guess probe in front (above),
+    // the product honouring its verdict, and no event pair around a launch that may be empty (lcg_hip_last_ax_mean_us is about products).
+    int ax_setup(const double *m0, double *y)
+    {
+        if (Afp != lcg_hip_csr_ax || inst == nullptr || !zero_guess_probe()) return ax(m0, y);
+        int rc = drv.vec(OpZeroProbe{c.state, m0}, (uintptr_t)m0);
+        if (!rc) rc = drv.scal(FinZeroGuess{});
+        if (rc) return rc;
+        c.ax_skip = &c.state->zero_guess;
+        Afp(inst, m0, y, n);
+        c.ax_skip = nullptr;
+        return c.ax_rc;
+    }
+    static bool zero_guess_probe()
+    {
+        static const bool on = [] { const char *e = lab_env("LCG_HIP_ZERO_GUESS"); return !e || atoi(e) != 0; }();     // (A/B runs)
+        return on;
+    }
     // y = A.x followed by the sums y.u (and y.y): with the built-in product on a handle this process holds whole, the sums ride
     // in the product's epilogue (csr.hip: k_spmv_lds1d) and reach the next scalar step as its sum `row` (y.y: row + 1) -- *fused
     // says so; otherwise the product is made as always and the caller runs its own reducing pass
@@ -476,8 +522,8 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
     DevState *st = c.state;
     const bool nt = stream_vectors(n, Afp, inst);      // (n: the rows THIS process holds)
 
-    TRY(k.ax(m, Ad));                                                            // lcg.cpp:168
-    TRY(k.drv.vec(OpCgInit{st, Ad, B, m, g, d}, al(Ad) | al(B) | al(m) | al(g) | al(d)));
+    TRY(k.ax_setup(m, Ad));                                                      // lcg.cpp:168
+    TRY(k.drv.vec(OpCgInit{st, Ad, B, m, g, d, one_reduction ? Ad : nullptr}, al(Ad) | al(B) | al(m) | al(g) | al(d)));
     TRY(k.drv.scal(FinInit{}));
     const uintptr_t a_upd = al(m) | al(g) | al(d) | al(Ad);
     if (one_reduction) {
@@ -590,8 +636,8 @@ static int solve_pcg(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pf
         if (!A->is_complex && A->n_rows == n) invdiag = A->invdiag;
     }
 
-    TRY(k.ax(m, Ad));                                                            // lcg.cpp:314
-    TRY(k.drv.vec(OpResidual{st, Ad, B, r}, al(Ad) | al(B) | al(r)));            // :317-321
+    TRY(k.ax_setup(m, Ad));                                                      // lcg.cpp:314
+    TRY(k.drv.vec(OpResidual{st, Ad, B, r, Ad}, al(Ad) | al(B) | al(r)));        // :317-321
     TRY(k.drv.checked_mx([&] { Mfp(inst, r, z, n); }));                          // :323
     TRY(k.drv.vec(OpPcgInit2{st, z, m, r, d}, al(z) | al(m) | al(r) | al(d)));   // :325-339
     TRY(k.drv.scal(FinInit{}));
@@ -679,7 +725,7 @@ static int solve_cgs(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const 
     const bool nt = stream_vectors(n, Afp, inst);      // (n: the rows THIS process holds)
     const uintptr_t a_all = al(m) | al(B) | al(r) | al(r0) | al(pk) | al(Ax) | al(u) | al(q) | al(w);
 
-    TRY(k.ax(m, Ax));                                                            // lcg.cpp:476
+    TRY(k.ax_setup(m, Ax));                                                      // lcg.cpp:476
     TRY(k.drv.vec(OpShadowInit<true>{st, Ax, B, m, r, r0, pk, u}, a_all));       // :480-497
     TRY(k.drv.scal(FinInit{}));
     int rc = k.run_loop([&]() -> int {
@@ -714,7 +760,7 @@ static int solve_bicgstab(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, c
     const bool nt = stream_vectors(n, Afp, inst);      // (n: the rows THIS process holds)
     const uintptr_t a_all = al(m) | al(B) | al(r) | al(r0) | al(pk) | al(Ax) | al(s) | al(Ap);
 
-    TRY(k.ax(m, Ax));                                                            // lcg.cpp:648
+    TRY(k.ax_setup(m, Ax));                                                      // lcg.cpp:648
     TRY(k.drv.vec(OpShadowInit<false>{st, Ax, B, m, r, r0, pk, nullptr}, a_all)); // :650-667
     TRY(k.drv.scal(FinInit{}));
     int rc = k.run_loop([&]() -> int {

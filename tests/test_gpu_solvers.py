@@ -415,3 +415,33 @@ def test_cache_policy_of_the_vector_passes_changes_no_bit():
         assert len(lines) == 7, r.stdout
         outs.append(lines)
     assert outs[0] == outs[1], outs
+
+
+@pytest.mark.parametrize("guess", ["zeros", "one_component", "random", "negative_zeros"])
+def test_initial_guess_and_the_product_that_is_not_made(api, port, case10k, guess):
+    """The reference multiplies the initial guess before anything else (lcg.cpp:168, 314, 476, 648).  The library probes the guess on the
+    device and does not make that product when it is all zeros (solvers_real.hip: ax_setup): capped iterates of all four solvers against
+    the oracle's loop from the same guess -- all zeros (the product is skipped), a single non-zero component and a random guess (it is
+    made), and negative zeros (skipped: -0 == 0, and A.(-0) adds up to zeros)."""
+    from oracle import pyoracle as po
+    n, rp, ci, v, b, xs = case10k
+    A = api.CsrMatrix.from_csr(rp, ci, v)
+    A.build_jacobi()
+    rng = np.random.default_rng(11)
+    m0 = {"zeros": np.zeros(n), "one_component": np.zeros(n), "random": rng.standard_normal(n), "negative_zeros": -np.zeros(n)}[guess]
+    if guess == "one_component":
+        m0[n // 3] = 1e-3
+    bd = torch.from_numpy(b).cuda()
+    for sid, jac in ((api.LCG_CG, False), (api.LCG_PCG, True), (api.LCG_CGS, False), (api.LCG_BICGSTAB, False)):
+        para = api.lcg_default_parameters(epsilon=1e-20, abs_diff=1, max_iterations=9)
+        m = torch.from_numpy(m0.copy()).cuda()
+        if jac:
+            info = api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, bd, n, para, A)
+        else:
+            info = api.lcg_solver("lcg_hip_csr_ax", None, m, bd, n, para, A, sid)
+        ref = port.solve(sid, rp, ci, v, b, m0=m0, para=po.default_para(epsilon=1e-20, abs_diff=1, max_iterations=9), jacobi=jac)
+        x = m.cpu().numpy()
+        assert info.ret == ref["ret"] and info.iterations == ref["iters"] == 9
+        assert np.linalg.norm(x - ref["x"]) <= 1e-12 * np.linalg.norm(ref["x"]), (guess, sid)
+        assert abs(info.residual - ref["residual"]) <= 1e-9 * ref["residual"]
+    A.destroy()
