@@ -352,7 +352,7 @@ def main():
             if self.placement is None:
                 t, mv = C.c_int(0), C.c_int(0); u0, u1 = C.c_double(0.0), C.c_double(0.0)
                 lib.lcg_hip_last_placement(C.byref(t), C.byref(mv), C.byref(u0), C.byref(u1))
-                self.placement = {"vectors_timed_in_first_solve": t.value, "outputs_moved": mv.value,
+                self.placement = {"vectors_timed_in_first_solve": t.value, "roles_moved": mv.value,
                                   "first_output_us_as_allocated": u0.value, "first_output_us_as_placed": u1.value}
             return info
 

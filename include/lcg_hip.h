@@ -135,18 +135,21 @@ int    lcg_hip_trim(void);
  * to the oracle's classic loop on a system of condition number 3.6e6 (iteration count, true residual, monitored = true). */
 enum { LCG_HIP_CG_AUTO = 0, LCG_HIP_CG_CLASSIC = 1, LCG_HIP_CG_ONE_REDUCTION = 2 };
 int    lcg_hip_set_cg_schedule(int schedule);
-/* Where the product's output lies.  The reference allocates its temporaries wherever malloc puts them (lcg.cpp:158-166); on an
- * MI355X the vector a large product WRITES is 8-10 % faster or slower to write depending on which stretch of memory it shares with
- * the matrix's value array (a property of the PAIR of allocations, constant for their lifetime, invisible in any address the process
- * can see: profiles/r04_placement.txt).  Before the first iteration of a real solver whose A.x is lcg_hip_csr_ax the
- * library therefore times y = A.B into each work vector of the solve that it owns itself (and into idle vectors of its pool; if all
- * behave alike, once per matrix into chunks of 1 GiB allocated one after the other until one is clearly faster -- at most 8, all
- * given back at once, never into the last 4 GiB of free memory -- and then into a vector taken where that chunk was) and gives the
- * products' output roles (A.d; A.p and A.s) to the fastest.  Roles only: no arithmetic changes, iterates are bit-identical (tests/test_gpu_placement.py).  Results are remembered per
- * (matrix, vector), so later solves time nothing.  mode: -1 automatic (real; this process's product streams >= 384 MB), 0 never,
- * 1 for every real matrix with the built-in callback.  LCG_HIP_PLACE in the environment sets the initial mode. */
+/* Where the work vectors lie.  The reference allocates its temporaries wherever malloc puts them (lcg.cpp:158-166); on an MI355X
+ * the vector a large product WRITES is 8-10 % faster or slower to write depending on whether it shares one of the device's three
+ * groups of memory with the matrix's value array (a property of the PAIR of allocations, constant for their lifetime, invisible in
+ * any address the process can see: profiles/r04_placement.txt), and the vectors the loop reads beside the matrix pay a
+ * little of the same.  Before the first iteration of a real solver whose A.x is lcg_hip_csr_ax the library therefore times y = A.B
+ * into each work vector of the solve that it owns itself (and into idle vectors of its pool) and deals the ROLES by weight -- the
+ * products' outputs (A.d; A.p and A.s), the vector the product reads, the rest -- the fastest vectors to the heaviest roles.  Where
+ * the solve has too few fast vectors, once per matrix: chunks of 1 GiB allocated one after the other until the product into one of
+ * them (every fourth is timed) is clearly faster -- at most 64, never into the last 8 GiB of free memory; that chunk is kept and cut
+ * into work vectors (lcg_hip_trim gives it back), the others are given back at once.  Roles only: no arithmetic changes, iterates
+ * are bit-identical (tests/test_gpu_placement.py).  Results are remembered per (matrix, vector), so later solves time nothing.
+ * mode: -1 automatic (real; this process's product streams >= 384 MB), 0 never, 1 for every real matrix with the built-in callback
+ * (no walk below that size).  LCG_HIP_PLACE in the environment sets the initial mode. */
 int    lcg_hip_set_placement(int mode);
-/* The latest solve's placement: vectors timed (0 = everything came from memory, or not tried), outputs moved, and what the first
+/* The latest solve's placement: vectors timed (0 = everything came from memory, or not tried), roles moved, and what the first
  * output role's product took as allocated / as placed, microseconds (0 when not tried).  Any pointer may be NULL. */
 int    lcg_hip_last_placement(int *timed, int *moved, double *us_as_allocated, double *us_as_placed);
 

@@ -372,10 +372,10 @@ struct Workspace {
         if (best < 0) {
             // nothing fits: give one idle smaller vector back and allocate
             for (size_t i = 0; i < c.scratch.size(); i++)
-                if (!c.scratch[i].busy) { (void)hipFree(c.scratch[i].p); c.scratch.erase(c.scratch.begin() + i); c.place_memo.clear(); break; }
+                if (!c.scratch[i].busy && !c.scratch[i].arena) { (void)hipFree(c.scratch[i].p); c.scratch.erase(c.scratch.begin() + i); c.place_memo.clear(); break; }
             double *p = nullptr;
             HIPCHK(hipMalloc(&p, bytes));
-            c.scratch.push_back({p, bytes, false});
+            c.scratch.push_back({p, bytes, false, nullptr});
             best = (int)c.scratch.size() - 1;
             // indices held by this workspace may have shifted by the erase above: they are re-resolved by pointer below
         }
@@ -401,31 +401,41 @@ struct Workspace {
     }
 };
 
-// ---- where the product's output lies (lcg_hip.h: lcg_hip_set_placement; profiles/r04_placement.txt) ---------------
+// ---- where the work vectors lie (lcg_hip.h: lcg_hip_set_placement; profiles/r04_placement.txt) -------------------
 // The time of a large y = A.x depends on WHICH allocation y is: 520-530 us or 580-595 us for the headline system, constant for
-// the lifetime of the pair (value array, y), the same for every x -- the read stream and the written vector either share a stretch of
-// memory or do not (scripts/placement_lab6.hip: six read buffers x sixteen written buffers fall into matching groups; nothing the
-// process can see -- virtual address, size, allocation call -- tells the group, only the clock does).  The solvers allocate their
-// work vectors anyway: before the first iteration the product's OUTPUT roles go to those the product writes fastest.
+// the lifetime of the pair (value array, y).  The device's memory falls into THREE groups of 96 GiB (the three ranks of its 12-high
+// HBM stacks, by every sign: one group a single stretch, the other two interleaved in runs of 2-8 GiB -- scripts/placement_lab7.hip
+// over 250 allocations of 1 GiB), and a vector that lies in the group of the matrix's value array is slow to write while that array
+// streams (scripts/placement_lab6.hip: six read buffers x sixteen written ones fall into matching groups).  Nothing the process can
+// see -- virtual address, size, allocation call -- tells the group; only the clock does.  Inside the CG loop
+// (scripts/placement_roles.py, every combination of classes for g, d, A.d): A.d beside the values costs 9 % of the iteration rate
+// whatever the others do, d (the product's x, and the direction pass's output) 2.6 %, g 1.3 %.  The solvers allocate their work
+// vectors anyway: before the first iteration each is classed by the product's time into it, and the roles are dealt in that order
+// of weight -- products' outputs first, then the vector the product reads, then the rest -- the vectors outside the value array's
+// group going to the heaviest roles.  No arithmetic changes.
 struct Placement {
     static bool wanted(Ctx &c, int n, const void *afp, const void *inst)
     {
         if (c.place_mode == 0 || afp != (const void *)lcg_hip_csr_ax || inst == nullptr) return false;
         const lcg_hip_csr *A = static_cast<const lcg_hip_csr *>(inst);
         if (A->is_complex || n != A->n_rows || n < 4096) return false;
-        if (c.place_mode > 0) return true;
-        // the effect needs a stream that comes from memory, not from the 256 MB Infinity Cache (an 8-way shard of the 10M-row
-        // system streams 490 MB)
-        return (long)part(A).nnz * 12L >= (384L << 20);
+        return c.place_mode > 0 || streams(A);
     }
     // the rows this process multiplies by itself: the whole matrix, or -- sharded -- the entries with locally owned columns
     static const CsrPart &part(const lcg_hip_csr *A) { return A->distributed ? A->loc : A->main; }
+    // the effect needs a stream that comes from memory, not from the 256 MB Infinity Cache (an 8-way shard of the 10M-row system
+    // streams 490 MB)
+    static bool streams(const lcg_hip_csr *A) { return (long)part(A).nnz * 12L >= (384L << 20); }
     static float *memo(Ctx &c, const void *val, const double *y)
     {
         for (auto &m : c.place_memo) if (m.val == val && m.y == y) return &m.us;
         return nullptr;
     }
-    // what y = A.x takes into `y`: one product to warm up (the first of a matrix also builds its plan), two timed
+    static void forget_y(Ctx &c, const double *y)
+    {
+        for (size_t i = 0; i < c.place_memo.size();) if (c.place_memo[i].y == y) c.place_memo.erase(c.place_memo.begin() + i); else i++;
+    }
+    // what y = A.x takes into `y`: one product to warm up, two timed (x: the right-hand side)
     static int time_output(Ctx &c, const lcg_hip_csr *A, const double *x, double *y, float *us)
     {
         const CsrPart &P = part(A);
@@ -445,10 +455,10 @@ struct Placement {
         c.place_timed++;
         return 0;
     }
-    // outs: the roles the solver's products write, most frequent first; rest: the other work vectors.  Roles whose vector the caller
-    // supplied stay where they are.  x: any n-vector that holds finite numbers (the right-hand side).
-    static int run(Ctx &c, int n, const void *afp, void *inst, const double *x, Workspace &ws,
-                   std::initializer_list<double **> outs, std::initializer_list<double **> rest)
+    // roles: the solve's work vectors by weight -- the products' outputs (n_out of them) first, then the vector the most frequent
+    // product reads, then the rest.  Roles whose vector the caller supplied stay where they are.  x: any n-vector that holds finite
+    // numbers (the right-hand side).
+    static int run(Ctx &c, int n, const void *afp, void *inst, const double *x, Workspace &ws, std::initializer_list<double **> roles, int n_out)
     {
         c.place_timed = c.place_moved = 0; c.place_us_first = c.place_us_chosen = 0.0;
         if (!wanted(c, n, afp, inst)) return 0;
@@ -458,73 +468,68 @@ struct Placement {
         constexpr float SAME = 1.03f;       // the two classes lie 8-12 % apart; timings of one class within 1-2 %
         struct Cand { double **role; double *p; float us; };
         std::vector<Cand> cand;
-        for (double **r : outs) if (ws.owns(*r)) cand.push_back({r, *r, 0.f});
-        const size_t n_out = cand.size();
-        if (n_out == 0) return 0;
-        for (double **r : rest) if (ws.owns(*r)) cand.push_back({r, *r, 0.f});
+        int k = 0, out_owned = 0;
+        for (double **r : roles) { if (ws.owns(*r)) { cand.push_back({r, *r, 0.f}); if (k < n_out) out_owned++; } k++; }
+        if (out_owned == 0) return 0;
+        const size_t n_own = cand.size();
         for (auto &s : c.scratch) if (!s.busy && s.bytes >= bytes) cand.push_back({nullptr, s.p, 0.f});   // idle vectors of the pool
-        {   // the plan of a matrix is built by its first product: not on the clock
-            if (part(A).last_kernel[0] == 0) { int rc = spmv_launch(part(A), false, A->variant, A->mean_row, x, cand[0].p, false, c.stream, nullptr); if (rc) return rc; }
-        }
-        for (auto &k : cand) { int rc = time_output(c, A, x, k.p, &k.us); if (rc) return rc; }
+        // the plan of a matrix is built by its first product: not on the clock
+        if (part(A).last_kernel[0] == 0) { int rc = spmv_launch(part(A), false, A->variant, A->mean_row, x, cand[0].p, false, c.stream, nullptr); if (rc) return rc; }
+        for (auto &q : cand) { int rc = time_output(c, A, x, q.p, &q.us); if (rc) return rc; }
         c.place_us_first = cand[0].us;
-        auto spread = [&]() { float lo = cand[0].us, hi = cand[0].us; for (auto &k : cand) { lo = std::min(lo, k.us); hi = std::max(hi, k.us); } return hi / lo; };
-        // All alike: fast or slow?  Only a vector from elsewhere can tell.  Memory falls into three groups, each made of stretches
-        // several GiB long (scripts/placement_lab7.hip: 64 allocations of 1 GiB in a row map as AABBBCCCCCCCCCAAAAAAC...;
-        // scripts/placement_walk.py: the product into 128 such chunks is slow for the first 3-4, then fast for 16, ...), and what is
-        // allocated one after the other lies side by side.  So the library walks: chunks of 1 GiB, one after the other and all held,
-        // the product timed into the start of each, until one is clearly faster (or clearly slower: then ours are the fast kind) --
-        // at most 8 (where a faster place exists it was 3-4 chunks away; on boxes whose free memory is one long stretch of the same
-        // group nothing faster lies within 127 GiB, and allocations beyond 4 GiB cost 30 ms per GiB: profiles/r04_placement.txt),
-        // never into the last 4 GiB of free memory.  The fast chunk is given back and a vector of the right size taken in
-        // its place (the allocator hands out the nearest free memory first); should that one not be fast, the chunk itself serves.
-        // Everything else is given back at once.  One walk per matrix.
-        if (spread() < SAME && memo(c, val, nullptr) == nullptr) {
+        float lo = cand[0].us, hi = cand[0].us;
+        for (auto &q : cand) { lo = std::min(lo, q.us); hi = std::max(hi, q.us); }
+        size_t n_slow = 0;
+        for (size_t i = 0; i < n_own; i++) if (cand[i].us > lo * SAME) n_slow++;
+        // Not enough vectors outside the value array's group (or all alike: then nobody knows which kind they are).  What is allocated
+        // one after the other lies side by side, so the library walks: chunks of 1 GiB, one after the other and all held, the product
+        // timed into the start of every fourth, until one is clearly faster than our slow kind (or, all alike, clearly slower: then
+        // ours are the fast kind) -- at most 64 chunks / 16 timings (30 ms), never into the last 8 GiB of free memory.  Larger steps
+        // do not get further: an allocation of 4 GiB or more costs 30 ms per GiB, and the allocator serves small requests from near-by
+        // memory whatever is held elsewhere.  The fast chunk is KEPT and cut into vectors for this and later solves (one group
+        // throughout: a 4 GiB allocation walked in steps of 64 MB never changes class); everything else is given back at once.  One
+        // walk per matrix.
+        const bool alike = hi < lo * SAME;
+        if (streams(A) && (alike || n_slow > 0) && memo(c, val, nullptr) == nullptr && bytes <= ((size_t)1 << 28)) {
             constexpr size_t CH = (size_t)1 << 30;
-            size_t p2 = 1; while (p2 < bytes) p2 <<= 1;
-            auto forget_y = [&](const double *y) {
-                for (size_t i = 0; i < c.place_memo.size(); i++) if (c.place_memo[i].y == y) { c.place_memo.erase(c.place_memo.begin() + i); break; }
-            };
+            const float ours = alike ? lo : hi;         // the kind to get away from
             std::vector<double *> chunks;
-            double *found = nullptr; float found_us = 0.f; size_t found_bytes = 0; int rc = 0;
-            for (int k = 0; k < 8 && bytes <= CH; k++) {
+            double *found = nullptr; float found_us = 0.f; int rc = 0;
+            for (int q = 0; q < 64; q++) {
                 size_t fr = 0, tot = 0;
-                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 5 * CH) break;
+                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 9 * CH) break;
                 double *p = nullptr;
                 if (hipMalloc(&p, CH) != hipSuccess) { (void)hipGetLastError(); break; }
                 chunks.push_back(p);
+                if (q % 4 != 0) continue;
                 float us = 0.f;
                 rc = time_output(c, A, x, p, &us);
                 if (rc) break;
-                if (us * SAME < cand[0].us) { found = p; found_us = us; found_bytes = CH; break; }
-                if (cand[0].us * SAME < us) break;          // slower than ours: ours are the fast kind, nothing to find
+                if (us * SAME < ours) { found = p; found_us = us; chunks.pop_back(); break; }
+                if (alike && ours * SAME < us) break;          // slower than ours: ours are the fast kind, nothing to find
             }
-            if (found && !rc) {
-                chunks.pop_back(); (void)hipFree(found); forget_y(found); found = nullptr;
-                double *v = nullptr; float us = 0.f;
-                if (hipMalloc(&v, p2) == hipSuccess) {
-                    rc = time_output(c, A, x, v, &us);
-                    if (!rc && us * SAME < cand[0].us) { found = v; found_us = us; found_bytes = p2; }
-                    else { (void)hipFree(v); forget_y(v); }
-                } else (void)hipGetLastError();
-                if (!found && !rc && hipMalloc(&v, CH) == hipSuccess) {
-                    rc = time_output(c, A, x, v, &us);
-                    if (!rc && us * SAME < cand[0].us) { found = v; found_us = us; found_bytes = CH; }
-                    else { (void)hipFree(v); forget_y(v); }
+            if (debug_on()) fprintf(stderr, "[lcg_hip] placement walk: %zu chunks of 1 GiB given back, %s (%.1f us against %.1f)\n", chunks.size(),
+                                    found ? "a faster place found and kept" : "nothing faster", found_us, ours);
+            for (double *p : chunks) { (void)hipFree(p); forget_y(c, p); }
+            if (rc) { if (found) { (void)hipFree(found); forget_y(c, found); } return rc; }
+            if (found) {
+                // the chunk as an arena of the pool: slots of the vector's size (2 MiB-aligned), as many as the solve has roles + 2
+                const size_t slot = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+                const size_t want = std::min(CH / slot, n_own + 2);
+                for (size_t i = 0; i < want; i++) {
+                    double *p = reinterpret_cast<double *>(reinterpret_cast<char *>(found) + i * slot);
+                    c.scratch.push_back({p, slot, false, found});
+                    if (i > 0) c.place_memo.push_back({val, p, found_us});
+                    cand.push_back({nullptr, p, found_us});
                 }
+                lo = std::min(lo, found_us);
             }
-            if (debug_on()) fprintf(stderr, "[lcg_hip] placement walk: %zu chunks of 1 GiB given back, %s (%.1f us, %zu MiB kept)\n", chunks.size(),
-                                    found ? "a faster place found" : "nothing faster", found_us, found_bytes >> 20);
-            for (double *p : chunks) { (void)hipFree(p); forget_y(p); }
-            if (rc) { if (found) { (void)hipFree(found); forget_y(found); } return rc; }
-            if (found) { c.scratch.push_back({found, found_bytes, false}); cand.push_back({nullptr, found, found_us}); }
             c.place_memo.push_back({val, nullptr, 0.f});
         }
-        // the fastest vectors to the output roles, in order; a role keeps its vector unless another is clearly faster.  Positions
-        // trade vectors, so every role still has a vector of its own; a vector of the pool that lands in a role joins the solve
-        // (the one it displaced stays with the solve, unused, and returns to the pool with the others).
-        const size_t n_own = n_out + [&] { size_t k = 0; for (double **r : rest) if (ws.owns(*r)) k++; return k; }();
-        for (size_t o = 0; o < n_out; o++) {
+        // Deal the roles by weight: a role keeps its vector unless one that no heavier role holds is clearly faster.  Positions trade
+        // vectors, so every role still has a vector of its own; a vector of the pool that lands in a role joins the solve (the one it
+        // displaced stays with the solve, unused, and returns to the pool with the others).
+        for (size_t o = 0; o < n_own; o++) {
             size_t best = o;
             for (size_t j = o + 1; j < cand.size(); j++) if (cand[j].us < cand[best].us) best = j;
             if (best != o && cand[best].us * SAME < cand[o].us) { std::swap(cand[o].p, cand[best].p); std::swap(cand[o].us, cand[best].us); }
@@ -533,17 +538,17 @@ struct Placement {
             if (*cand[i].role == cand[i].p) continue;
             *cand[i].role = cand[i].p;
             if (!ws.owns(cand[i].p)) ws.adopt(cand[i].p);
-            if (i < n_out) c.place_moved++;
+            c.place_moved++;
         }
         c.place_us_chosen = cand[0].us;
         if (debug_on()) {
-            fprintf(stderr, "[lcg_hip] placement: %d timed, %d moved; output %.1f -> %.1f us;", c.place_timed, c.place_moved, c.place_us_first, c.place_us_chosen);
-            for (auto &k : cand) fprintf(stderr, " %.1f", k.us);
+            fprintf(stderr, "[lcg_hip] placement: %d timed, %d roles moved; first output %.1f -> %.1f us; roles by weight:", c.place_timed, c.place_moved,
+                    c.place_us_first, c.place_us_chosen);
+            for (size_t i = 0; i < cand.size(); i++) fprintf(stderr, "%s %.1f", i == n_own ? " | idle:" : "", cand[i].us);
             fprintf(stderr, "\n");
         }
         return 0;
     }
-    static void forget(Ctx &c) { c.place_memo.clear(); }
 };
 
 } // namespace lcgh

@@ -188,15 +188,15 @@ struct Ctx {
     DevState *state_stage = nullptr;   // pinned: the initial state of a solve on its way to the device (no stream sync)
     // scratch vectors of past solves, kept for the next one (hipMalloc + hipFree cost ~0.2 ms per solve, as much as ten
     // iterations of a small system; lcg_hip_trim() gives them back)
-    struct Scratch { double *p; size_t bytes; bool busy; };
+    struct Scratch { double *p; size_t bytes; bool busy; void *arena; };   // arena: the allocation this vector is a slot of (driver.hpp: Placement), or null
     std::vector<Scratch> scratch;
     // where the product's output lies (driver.hpp: Placement): what y = A.x took into a given vector against a given matrix
-    // (val = the matrix's value array; y == nullptr: "no better place found for this matrix, stop looking")
+    // (val = the matrix's value array; y == nullptr: "this matrix has had its walk, do not look again")
     struct PlaceMemo { const void *val; const double *y; float us; };
     std::vector<PlaceMemo> place_memo;
     int place_mode = -1;               // lcg_hip_set_placement: -1 auto (large products on one GPU), 0 never, 1 whenever the callback is the built-in one
     int place_timed = 0;               // candidates timed by the latest solve (0: answered from the memo, or not tried)
-    int place_moved = 0;               // outputs the latest solve moved to another vector
+    int place_moved = 0;               // roles the latest solve moved to another vector
     double place_us_first = 0.0, place_us_chosen = 0.0;   // the latest solve's first output: as allocated / as placed
     unsigned shadow_seed = 1;
     std::vector<double> shadow_vec;    // explicit rbar0 for the next complex solve

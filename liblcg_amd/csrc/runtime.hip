@@ -243,8 +243,13 @@ int lcg_hip_trim(void)
     Ctx &c = ctx();
     if (!c.inited) return 0;
     (void)hipDeviceSynchronize();
-    for (auto it = c.scratch.begin(); it != c.scratch.end();)
-        if (!it->busy) { (void)hipFree(it->p); it = c.scratch.erase(it); } else ++it;
+    // (slots of an arena go together: the arena is given back when none of its slots is in use)
+    auto arena_busy = [&](void *a) { for (auto &s : c.scratch) if (s.arena == a && s.busy) return true; return false; };
+    for (auto it = c.scratch.begin(); it != c.scratch.end();) {
+        if (it->busy || (it->arena && arena_busy(it->arena))) { ++it; continue; }
+        if (!it->arena || it->p == it->arena) (void)hipFree(it->p);
+        it = c.scratch.erase(it);
+    }
     c.place_memo.clear();       // (addresses may come back as other memory)
     return 0;
 }

@@ -514,9 +514,10 @@ static int solve_cg(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const d
                                (c.cg_schedule == LCG_HIP_CG_AUTO && (comm_active() || (n < CG1_AUTO_ROWS && Afp == lcg_hip_csr_ax)));
     double *w = nullptr;
     if (one_reduction) TRY(ws.get(w, nullptr, sizeof(double) * n));
-    // the vector the loop's product writes (A.d; w = A.g in the one-reduction arrangement) goes where it is written fastest
-    if (one_reduction) TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&w}, {&Ad, &g, &d}));
-    else TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ad}, {&g, &d}));
+    // roles by weight (driver.hpp: Placement): what the loop's product writes (A.d; w = A.g in the one-reduction arrangement), what it
+    // reads, the rest
+    if (one_reduction) TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&w, &g, &d, &Ad}, 1));
+    else TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ad, &d, &g}, 1));
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
@@ -623,7 +624,7 @@ static int solve_pcg(lcg_axfunc_ptr Afp, lcg_axfunc_ptr Mfp, lcg_progress_ptr Pf
     Workspace ws; double *r, *z, *d, *Ad;
     TRY(ws.get(r, nullptr, sizeof(double) * n)); TRY(ws.get(z, nullptr, sizeof(double) * n));
     TRY(ws.get(d, nullptr, sizeof(double) * n)); TRY(ws.get(Ad, nullptr, sizeof(double) * n));
-    TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ad}, {&r, &z, &d}));      // (A.d goes where it is written fastest)
+    TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ad, &d, &r, &z}, 1));      // (roles by weight: A.d, the product's x, the rest)
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
@@ -718,7 +719,7 @@ static int solve_cgs(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, const 
     const size_t nb = sizeof(double) * n;
     TRY(ws.get(r, RK, nb)); TRY(ws.get(r0, R0T, nb)); TRY(ws.get(pk, PK, nb)); TRY(ws.get(Ax, AX, nb));
     TRY(ws.get(u, UK, nb)); TRY(ws.get(q, QK, nb)); TRY(ws.get(w, WK, nb));
-    TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ax}, {&r, &r0, &pk, &u, &q, &w}));    // (both products write Ax)
+    TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ax, &pk, &w, &u, &q, &r, &r0}, 1));        // (both products write Ax; they read p and w)
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
@@ -753,7 +754,7 @@ static int solve_bicgstab(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, c
     const size_t nb = sizeof(double) * n;
     TRY(ws.get(r, nullptr, nb)); TRY(ws.get(r0, nullptr, nb)); TRY(ws.get(pk, nullptr, nb));
     TRY(ws.get(Ax, nullptr, nb)); TRY(ws.get(s, nullptr, nb)); TRY(ws.get(Ap, nullptr, nb));
-    TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ap, &Ax}, {&r, &r0, &pk, &s}));       // (A.p and A.s)
+    TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ap, &Ax, &pk, &s, &r, &r0}, 2));           // (A.p and A.s; p and s are read)
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;
@@ -896,7 +897,7 @@ static int solve_bicgstab2(lcg_axfunc_ptr Afp, lcg_progress_ptr Pfp, double *m, 
     const size_t nb = sizeof(double) * n;
     TRY(ws.get(r, nullptr, nb)); TRY(ws.get(r0, nullptr, nb)); TRY(ws.get(pk, nullptr, nb));
     TRY(ws.get(Ax, nullptr, nb)); TRY(ws.get(s, nullptr, nb)); TRY(ws.get(Ap, nullptr, nb));
-    TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ap, &Ax}, {&r, &r0, &pk, &s}));       // (A.p and A.s)
+    TRY(Placement::run(c, n, (const void *)Afp, inst, B, ws, {&Ap, &Ax, &pk, &s, &r, &r0}, 2));           // (A.p and A.s; p and s are read)
     RealCommon k(c, n, p, inst, Afp, Pfp, m);
     TRY(k.drv.init_state(global_rows_of(c, n, (const void *)Afp, inst)));
     DevState *st = c.state;

@@ -9,6 +9,6 @@ for i in $(seq 1 $PAIRS); do
   for place in $ORDER; do
     LCG_HIP_PLACE=$place python3 bench.py --no-cpu-baseline --no-live-pmc --no-variants --steps 100 --warmup 10 2> >(grep -m2 "placement walk\|placement: [1-9]" >&2) | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); p=d.get('placement') or {}
-print('pair $i LCG_HIP_PLACE=$place:', round(d['value'],1), 'it/s, A.x', round(d['roofline']['avg_launch_us'],1), 'us; placement: timed', p.get('vectors_timed_in_first_solve'), 'moved', p.get('outputs_moved'), 'output', round(p.get('first_output_us_as_allocated',0),1), '->', round(p.get('first_output_us_as_placed',0),1), 'us')"
+print('pair $i LCG_HIP_PLACE=$place:', round(d['value'],1), 'it/s, A.x', round(d['roofline']['avg_launch_us'],1), 'us; placement: timed', p.get('vectors_timed_in_first_solve'), 'moved', p.get('roles_moved'), 'output', round(p.get('first_output_us_as_allocated',0),1), '->', round(p.get('first_output_us_as_placed',0),1), 'us')"
   done
 done
