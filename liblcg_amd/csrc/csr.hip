@@ -1160,6 +1160,7 @@ static double span_threshold()
 static bool diag_like_measured(const CsrPart &P, hipStream_t s);     // (below)
 static bool line_ratio_measured(const CsrPart &P, hipStream_t s);
 static double line_ratio_threshold();
+static bool tiled_chosen(const CsrPart &P, hipStream_t s);
 
 // true when P's products go through the binned format (plan built here on first use)
 static bool binned_chosen(const CsrPart &P, hipStream_t s)
@@ -1168,10 +1169,11 @@ static bool binned_chosen(const CsrPart &P, hipStream_t s)
     static const int env = [] { const char *e = std::getenv("LCG_HIP_BINNED"); return e ? atoi(e) : -1; }();
     const int mode = env >= 0 ? env : P.bn_mode;
     if (mode == 0 || P.n_cols <= 0 || P.nnz <= 0) { P.bn_state = -1; P.bn_why = mode == 0 ? "switched off" : "empty matrix or unknown column count"; return false; }
-    if (mode < 0 && (P.nnz < (1 << 22) || P.n_cols < (1 << 20))) {
+    if (mode < 0 && (P.nnz < (1 << 22) || P.n_cols < 1000000)) {
         // automatic: only where x cannot sit in a cache (>= 1M columns) and the matrix is worth a second copy
         P.bn_state = -1; P.bn_why = "automatic mode: fewer than 4M entries or 1M columns"; return false;
     }
+    if (mode < 0 && P.n_rows < (1 << 19)) { P.bn_state = -1; P.bn_why = "automatic mode: fewer than 512K rows"; return false; }
     PlanTimer timer(P, s);
     if (mode < 0) {
         if (P.mean_span < 0.0) {
@@ -1186,7 +1188,19 @@ static bool binned_chosen(const CsrPart &P, hipStream_t s)
             if (!ok) { (void)hipGetLastError(); P.bn_state = -1; return false; }
             P.mean_span = (double)h / nb;
         }
-        if (P.mean_span < span_threshold()) { P.bn_state = -1; P.bn_why = "automatic mode: the row blocks' mean column span is below the threshold"; return false; }
+        // (columns anywhere in a matrix of 1M columns span less than the threshold and are scattered all the same: 243 us binned, 347 tiled,
+        //  372 packed at 1M rows)
+        if (P.mean_span < span_threshold() && P.mean_span < 0.75 * (double)P.n_cols) {
+            P.bn_state = -1; P.bn_why = "automatic mode: the row blocks' mean column span is below the threshold"; return false;
+        }
+        // between one and two million columns of span the tiled product is still the faster one where its plan accepts the matrix
+        // (round 4, N = 1e7, 33 per row, columns drawn per row within +-W: W = 524288 / 786432 tiled 1008 / 1019 us, binned 1670;
+        //  W = 1048576 tiled 1768, binned 1683 -- profiles/r04_choice_regret.txt)
+        // (a BAND: the span a small part of the width.  Columns anywhere in a matrix of 1-1.5M columns have the same span and are the
+        //  binned product's: 226 against 328 us at 1M rows)
+        if (P.mean_span < 2.0 * span_threshold() && 4.0 * P.mean_span <= (double)P.n_cols && tiled_chosen(P, s)) {
+            P.bn_state = -1; P.bn_why = "automatic mode: the tiled product takes it (mean column span below two thresholds)"; return false;
+        }
         // wide, but along diagonals (a stencil on a grid with a million points per plane): every diagonal is a contiguous stream of
         // x for the row-block kernels, whatever the distance between the diagonals
         if (diag_like_measured(P, s) && P.diag_like > 0.5) {
@@ -1293,8 +1307,10 @@ static double tiled_line_ratio_threshold()
 }
 
 static double tiled_fill_threshold()
-{
-    static const double fill = [] { const char *e = lab_env("LCG_HIP_TILED_FILL"); return e ? atof(e) : 700.0; }();
+{   // least mean number of entries per (workgroup of 8192 rows, tile of 2048 columns) pair.  Round 3's kernel needed 700; the rewritten one
+    // (k_tile_spmv2) beats the binned product down to ~350 (W = 786432 at N = 1e7: 352 per pair, 1019 against 1669 us) and loses from
+    // ~260 (W = 1048576: 1768 against 1683)
+    static const double fill = [] { const char *e = lab_env("LCG_HIP_TILED_FILL"); return e ? atof(e) : 300.0; }();
     return fill;
 }
 
@@ -1312,12 +1328,17 @@ static bool tiled_chosen(const CsrPart &P, hipStream_t s)
         if (P.diag_like > 0.5) { P.tl_state = -1; P.tl_why = "automatic mode: the columns run along diagonals (the row-block kernels gather contiguously)"; return false; }
         const bool lr = line_ratio_measured(P, s);
         if (debug_on()) std::fprintf(stderr, "[lcg_hip] tiled choice: diag_like %.3f, line_ratio %.3f\n", P.diag_like, P.line_ratio);
-        if (lr && P.line_ratio < tiled_line_ratio_threshold()) {
+        // (below 4M rows x is small enough for the caches to help the row blocks: at 1M rows the band of 8192 columns, line ratio 0.24, is
+        //  still theirs -- 103 against 130 us --, the band of 16384, 0.43, is the tiled product's: 99 against 121)
+        const double lr_least = P.n_rows < (1 << 22) ? std::max(0.3, tiled_line_ratio_threshold()) : tiled_line_ratio_threshold();
+        if (lr && P.line_ratio < lr_least) {
             P.tl_state = -1; P.tl_why = "automatic mode: neighbouring rows share their cache lines of x (block-structured: the row-block kernels fetch few lines per entry)";
             return false;
         }
         // least mean number of entries per (workgroup of 8192 rows, tile of 2048 columns) pair.  Measured at N = 1e7, 33 per row (round 3):
         // W = 524288, 1052 per pair: tiled 1.01-1.17 ms, binned 1.70; W = 1048576, 527 per pair: tiled 1.96 ms, binned 1.72
+        // (a workgroup per 8192 rows: a stretch of 200,000 rows would run on 25 of the 256 CUs)
+        if (P.n_rows < (1 << 19)) { P.tl_state = -1; P.tl_why = "automatic mode: fewer than 512K rows"; return false; }
         min_fill = tiled_fill_threshold();
     }
     const int rc = tiled_ready(P, s, min_fill);
@@ -1471,7 +1492,7 @@ static bool ranges_chosen(const CsrPart &P, hipStream_t s)
         if (ent <= 0.0 || blocks <= 0.0) return -1;
         if (only_long || dl / ent > 0.5) return 0;
         const double span = span_sum / blocks;
-        if (span >= span_threshold()) return 2;
+        if (span >= 2.0 * span_threshold()) return 2;
         const double fill = 128.0 * (ent / blocks) / ((span + 8192.0) / 2048.0);
         return fill < tiled_fill_threshold() && span >= (double)(1 << 19) ? 2 : 1;
     };
@@ -1582,7 +1603,9 @@ static bool ranges_chosen(const CsrPart &P, hipStream_t s)
         V.pk_mode = P.pk_mode; V.bn_mode = P.bn_mode; V.tl_mode = P.tl_mode; V.rg_mode = 0; V.rg_state = -1;
         // a stretch classed as scattered takes the binned product where it is eligible at all (its own mean span may sit just
         // under the whole-matrix threshold: the class was decided chunk by chunk)
-        if (runs[i].k == 2 && P.bn_mode < 0 && V.nnz >= (1 << 22)) V.bn_mode = 1;
+        // (not for a short stretch: 200,000 scattered rows of a 1M-row matrix went from 86 to 176 us per product that way -- the binned
+        //  passes launch a workgroup per 8192 columns and a wavefront per 2048 rows)
+        if (runs[i].k == 2 && P.bn_mode < 0 && V.nnz >= (1 << 22) && V.n_rows >= (1 << 20)) V.bn_mode = 1;
         if (runs[i].k == 3) V.lr_mode = 1;
         R->parts.push_back(V); R->r0.push_back(r0); R->seen.push_back(nullptr);
     }

@@ -161,10 +161,11 @@ def test_automatic_choice_and_solvers(api, lib, port):
     from oracle import pyoracle as po
     n = 1_500_000
     # (row-random bands: the tiled product from a line ratio of 0.18 on -- bands of >= 8192 columns at 33 entries per row; narrower ones
-    #  keep the packed row blocks, whose gathers then share their cache lines: profiles/r03_band_sweep.txt)
+    #  keep the packed row blocks, whose gathers then share their cache lines: profiles/r03_band_sweep.txt; below 4M rows the caches help the
+        #  row blocks and the tiled product starts at a line ratio of 0.3, the band of 16384 columns: profiles/r04_choice_regret.txt)
     for pattern, band, want in ((api.GEN_SCRAMBLED, 0, b"k_bin_expand"), (api.GEN_DIAGONALS, 40000, b"k_spmv_ldsp"),
                                 (api.GEN_ROW_RANDOM_BAND, 40000, b"k_tile_spmv"), (api.GEN_ROW_RANDOM_BAND, 16384, b"k_tile_spmv"),
-                                (api.GEN_ROW_RANDOM_BAND, 8192, b"k_tile_spmv"), (api.GEN_ROW_RANDOM_BAND, 2048, b"k_spmv_ldsp")):
+                                (api.GEN_ROW_RANDOM_BAND, 8192, b"k_spmv_ldsp"), (api.GEN_ROW_RANDOM_BAND, 2048, b"k_spmv_ldsp")):
         A = api.CsrMatrix.generate(n, 16, band, True, 3, 0.01, pattern=pattern)
         x = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 3, 0, n, x)
         y = torch.empty_like(x); y2 = torch.empty_like(x)
