@@ -461,8 +461,26 @@ template <> __device__ __forceinline__ int pk_field<18>(u64 lo, u64 hi, int j)
     return (int)(v & 0x3ffff);
 }
 
+// Several unknowns per grid point (a 27-point stencil x 3: 81 entries per row): every row's entries come in groups of g consecutive
+// columns -- the g x g coupling block of two points.  ok[g - 2] stays 1 when EVERY row is made of such groups (g = 2, 3, 4): the packed
+// form of the long-row blocks then keeps one column field per group (18 bits for three entries: 8.75 instead of 10.3 B per entry).
+__global__ __launch_bounds__(VB) void k_pk_dof(int n, const int *__restrict__ rowptr, const int *__restrict__ col, int *ok)
+{
+    const int i = blockIdx.x * VB + threadIdx.x;
+    unsigned bad = 0;       // bit g - 2
+    if (i < n) {
+        const int s = rowptr[i], len = rowptr[i + 1] - s;
+        for (int g = 2; g <= 4; g++) {
+            bool b = len % g != 0;
+            for (int k = 0; k < len && !b; k++) b = (k % g) != 0 && col[s + k] != col[s + k - 1] + 1;
+            if (b) bad |= 1u << (g - 2);
+        }
+    }
+    for (int g = 0; g < 3; g++) if (__ballot((bad >> g) & 1u) != 0ull && (threadIdx.x & 63) == 0) ok[g] = 0;
+}
+
 template <int BITS>
-__global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const int *col, const int *base, const int *pofs, v4i *packed, int R)
+__global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const int *col, const int *base, const int *pofs, v4i *packed, int R, int dof)
 {
     constexpr int PER = BITS > 0 ? 128 / BITS : 1;
     const int b = blockIdx.x;
@@ -490,11 +508,11 @@ __global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const 
         for (int k = threadIdx.x; k < ((L + 3) & ~3); k += VB) dst[k] = k < L ? col[s + k] : 0;
         return;
     }
-    const int ng = (e - s + PER - 1) / PER;
+    const int ng = (e - s + PER * dof - 1) / (PER * dof);       // (dof > 1: a field is the first column of a group of dof entries)
     for (int g = threadIdx.x; g < ng; g += VB) {
         u64 lo = 0, hi = 0;
         for (int j = 0; j < PER; j++) {
-            const int k = s + PER * g + j;
+            const int k = s + (PER * g + j) * dof;
             const u64 c = k < e ? (u64)(col[k] - bs) : 0;
             if (BITS == 21) { if (j < 3) lo |= c << (21 * j); else hi |= c << (21 * (j - 3)); }
             else if (BITS > 0) {
@@ -572,7 +590,8 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     const int nrows = min(R, n - row0);
     const int rl = tid % R, j0 = tid / R;
     const int s = rowptr[row0], e = rowptr[row0 + nrows];
-    const int cnt = e - s, ng = (cnt + PER - 1) / PER;
+    const int dof = RR == 64 ? 1 : dp.dof;             // (uniform; groups of consecutive columns are a shape of the long-row blocks)
+    const int cnt = e - s, ng = (cnt + PER * dof - 1) / (PER * dof);
     const int po = pofs[bid], bs = pbase[bid];
     const int bv = s & ~1, cntv = e - bv;
     double uv = 0.0;
@@ -717,9 +736,15 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     int rs = rowptr[row0 + rsafe], re = rowptr[row0 + rsafe + 1];
     if (rl >= nrows) { rs = 0; re = 0; }
     v4i pg[GR]; v2d pv[VR];
+    // (dof > 1: a group's fields are spread over dof lanes -- lane t takes group t / dof and, of each of its fields' dof consecutive
+    //  columns, the (t % dof)-th: as many LDS stores per lane as with a field per column.  With the group's lanes taking all dof
+    //  columns of a field each, a third of the lanes did three times the stores and the product got SLOWER: 1296 against 1166 us on
+    //  the 27-point stencil x 3.)
+    const unsigned dmul = dof == 3 ? 0x5556u : 0u;       // t / 3 = (t * 0x5556) >> 16 for t < 2^15
 #pragma unroll
     for (int r = 0; r < GR; r++) {
-        const int gi = tid + r * VB;
+        const int t = tid + r * VB;
+        const int gi = dof == 1 ? t : (dof == 2 ? t >> 1 : (dof == 4 ? t >> 2 : (int)(((unsigned)t * dmul) >> 16)));
         pg[r] = packed[po + (gi < ng ? gi : 0)];
     }
 #pragma unroll
@@ -730,11 +755,20 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < GR; r++) {
-        const int gi = tid + r * VB;
+        const int t = tid + r * VB;
+        const int gi = dof == 1 ? t : (dof == 2 ? t >> 1 : (dof == 4 ? t >> 2 : (int)(((unsigned)t * dmul) >> 16)));
         if (gi < ng) {
             const u64 lo = (u64)(unsigned)pg[r].x | ((u64)(unsigned)pg[r].y << 32);
             const u64 hi = (u64)(unsigned)pg[r].z | ((u64)(unsigned)pg[r].w << 32);
-            if (BITS == 21) {
+            if (dof > 1) {
+                // one field per group of dof consecutive columns: the staged columns are what they would be with a field each
+                const int d = t - gi * dof;
+#pragma unroll
+                for (int j = 0; j < PER; j++) {
+                    const int i0 = (PER * gi + j) * dof + d;
+                    if (i0 < cnt) scol[i0] = bs + pk_field<BITS>(lo, hi, j) + d;      // (fields past the block's end stay out: scol holds CH entries)
+                }
+            } else if (BITS == 21) {
                 v2i a, b, c;
                 a.x = bs + (int)(lo & 0x1fffff); a.y = bs + (int)((lo >> 21) & 0x1fffff);
                 b.x = bs + (int)((lo >> 42) & 0x1fffff); b.y = bs + (int)(hi & 0x1fffff);
@@ -1090,6 +1124,19 @@ static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only, int R 
     long total = 0;
     int hspan[4] = {0, 0, 0, 0};
     static const int runs = [] { const char *e = lab_env("LCG_HIP_PACKED_RUNS"); return e ? atoi(e) : 1; }();    // 0: A/B runs without run blocks
+    int dof = 1;
+    if (R != PK_R && !runs_only) {      // long rows: do all rows consist of groups of 2 / 3 / 4 consecutive columns?
+        static const int dof_off = [] { const char *e = lab_env("LCG_HIP_PACKED_DOF"); return e && atoi(e) == 0; }();     // (A/B runs)
+        int *d = nullptr, h[3] = {1, 1, 1};
+        bool okd = !dof_off && hipMalloc(&d, sizeof h) == hipSuccess && hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, s) == hipSuccess;
+        if (okd) {
+            hipLaunchKernelGGL(k_pk_dof, dim3((n + VB - 1) / VB), dim3(VB), 0, s, n, P.rowptr, P.col, d);
+            okd = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        }
+        if (d) hipFree(d);
+        if (okd) dof = h[2] ? 4 : (h[1] ? 3 : (h[0] ? 2 : 1));
+        else (void)hipGetLastError();
+    }
     bool ok = hipMalloc(&P.pk_base, sizeof(int) * (size_t)nb) == hipSuccess && hipMalloc(&P.pk_ofs, sizeof(int) * ((size_t)nb + 1)) == hipSuccess &&
               hipMalloc(&ngr, sizeof(int) * (size_t)nb) == hipSuccess && hipMalloc(&span, 4 * sizeof(int)) == hipSuccess &&
               hipMemsetAsync(span, 0, 4 * sizeof(int), s) == hipSuccess;
@@ -1103,18 +1150,18 @@ static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only, int R 
     static const int force_bits = [] { const char *e = lab_env("LCG_HIP_PACKED_BITS"); return e ? atoi(e) : 0; }();   // 21: A/B runs
     const int bits = runs_only ? 0 : ((hspan[0] < (1 << 18) && force_bits != 21) ? 18 : 21);     // seven 18-bit columns per group where the blocks are narrow enough
     if (ok) {
-        hipLaunchKernelGGL(k_pk_groups, dim3((nb + VB - 1) / VB), dim3(VB), 0, s, nb, runs_only ? 0 : 128 / bits, ngr);
+        hipLaunchKernelGGL(k_pk_groups, dim3((nb + VB - 1) / VB), dim3(VB), 0, s, nb, runs_only ? 0 : (128 / bits) * dof, ngr);
         ok = device_exclusive_scan(nb, ngr, P.pk_ofs, s, &total) == 0;
     }
     if (ok) ok = total > 0 && total < 0x7fffffffL;
     if (ok) ok = hipMalloc(&P.pk_data, 16 * ((size_t)total + 4)) == hipSuccess;
     if (ok) {
         if (runs_only)
-            hipLaunchKernelGGL(k_pk_pack<0>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data), R);
+            hipLaunchKernelGGL(k_pk_pack<0>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data), R, 1);
         else if (bits == 18)
-            hipLaunchKernelGGL(k_pk_pack<18>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data), R);
+            hipLaunchKernelGGL(k_pk_pack<18>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data), R, dof);
         else
-            hipLaunchKernelGGL(k_pk_pack<21>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data), R);
+            hipLaunchKernelGGL(k_pk_pack<21>, dim3(nb), dim3(VB), 0, s, n, P.rowptr, P.col, P.pk_base, P.pk_ofs, static_cast<v4i *>(P.pk_data), R, dof);
         ok = hipGetLastError() == hipSuccess;
     }
     if (ngr) hipFree(ngr);
@@ -1133,6 +1180,7 @@ static bool packed_build(const CsrPart &P, hipStream_t s, bool runs_only, int R 
     P.pk_groups = total;
     P.pk_bits = bits;
     P.pk_R = R;
+    P.pk_dof = dof;
     P.pk_state = runs_only ? 2 : 1;
     return true;
 }
@@ -1849,10 +1897,11 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
                     const int T = VB / R;
                     const int per_lane = (P.pk_maxrow + T - 1) / T;
                     const int win = pk_window(P.max_slice);
+                    DotPlan pkl_plan = ldsp_plain_plan(); pkl_plan.dof = P.pk_dof;
 #define PKL_LAUNCH(NSS, BB, CC, RRR)                                                                                \
         hipLaunchKernelGGL((k_spmv_ldsp<false, NSS, BB, false, CC, RRR>), dim3((n + RRR - 1) / RRR), dim3(VB), 0, s, n, P.rowptr, \
                            static_cast<const v4i *>(P.pk_data), P.pk_ofs, P.pk_base, reinterpret_cast<const double *>(val), \
-                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, PushPlan(), ldsp_plain_plan())
+                           reinterpret_cast<const double *>(x), reinterpret_cast<double *>(y), done, PushPlan(), pkl_plan)
 #define PKL_WIN(NSS, BB, RRR)                                                                                       \
         do { if (win == PK_CH_8) PKL_LAUNCH(NSS, BB, PK_CH_8, RRR); else if (win == PK_CH_7) PKL_LAUNCH(NSS, BB, PK_CH_7, RRR);   \
              else if (win == PK_CH_SMALL) PKL_LAUNCH(NSS, BB, PK_CH_SMALL, RRR); else PKL_LAUNCH(NSS, BB, LdsCfg<double>::CH, RRR); } while (0)
@@ -1863,7 +1912,9 @@ static int spmv_dispatch(const CsrPart &P, int variant, double mean_row, const V
 #undef PKL_WIN
 #undef PKL_BITS
                     HIPCHK(hipGetLastError());
-                    P.last_kernel = P.pk_bits == 18 ? "k_spmv_ldsp (LDS-staged, long rows: 18-bit packed columns)" : "k_spmv_ldsp (LDS-staged, long rows: 21-bit packed columns)";
+                    P.last_kernel = P.pk_dof > 1 ? (P.pk_bits == 18 ? "k_spmv_ldsp (LDS-staged, long rows: one 18-bit packed column per group of consecutive columns)"
+                                                                   : "k_spmv_ldsp (LDS-staged, long rows: one 21-bit packed column per group of consecutive columns)")
+                                                 : (P.pk_bits == 18 ? "k_spmv_ldsp (LDS-staged, long rows: 18-bit packed columns)" : "k_spmv_ldsp (LDS-staged, long rows: 21-bit packed columns)");
                     return 0;
                 }
             }

@@ -118,6 +118,7 @@ struct DotPlan {
     int yy = 0;
     int stride = AXP_CAP;   // distance of the y.y sums from the y.u sums in `part`
     int ystore = 0;         // how k_spmv_ldsp stores y (devcommon.hpp: store_y; set by the host from y_store_policy())
+    int dof = 1;            // k_spmv_ldsp, long rows: a packed column field stands for `dof` consecutive columns (csr.hip: k_pk_dof)
 };
 
 struct DevState;
@@ -234,6 +235,7 @@ struct CsrPart {
     mutable int pk_maxrow = 0;                              // longest row (chooses the gather batch of the kernel)
     mutable int pk_bits = 21;                               // width of a packed column: 18 (seven per group) or 21 (six)
     mutable int pk_R = 64;                                  // rows per block of the packed form (64; 32 / 16 for long rows)
+    mutable int pk_dof = 1;                                 // long rows: every row's entries come in groups of pk_dof consecutive columns (one packed field per group)
     mutable int pk_runs = 0;                                // blocks stored as runs (row 0's columns only; csr.hip: k_pk_meta)
     mutable int pk_tpls = 0;                                // blocks stored as templates (<= 32 diagonals + a mask per row)
     mutable long pk_groups = 0;                             // 16-byte groups of the packed columns

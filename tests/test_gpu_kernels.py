@@ -798,6 +798,12 @@ def test_long_rows_take_packed_columns(api, port):
         n0, rp0, ci0 = _stencil(dims, 1, False)
         B = sp.kron(sp.csr_matrix((np.ones(len(ci0)), ci0, rp0), shape=(n0, n0)), np.ones((dof, dof)), format="csr"); B.sort_indices()
         cases.append((f"27-point x {dof}", B.indptr.astype(np.int32), B.indices.astype(np.int32)))
+        if dof == 3:    # the same with ONE row that breaks the groups of three consecutive columns (its last entry moved one column on)
+            rpb, cib = B.indptr.astype(np.int32), B.indices.astype(np.int32).copy()
+            r = len(rpb) // 2
+            if cib[rpb[r + 1] - 1] + 1 < len(rpb) - 1:
+                cib[rpb[r + 1] - 1] += 1
+            cases.append(("27-point x 3, one row out of step", rpb, cib))
     # ragged rows, columns drawn inside a band, some rows empty; the last system has a few rows beyond the one predicated batch of a lane
     # (9 x 16 = 144 entries at 16 rows per block): the batched loop and the serial tail behind it
     for lo, hi, nrow in ((40, 56, 9000), (40, 68, 9001), (70, 96, 7001), (70, 130, 7002), (60, 80, 5003)):
@@ -824,6 +830,9 @@ def test_long_rows_take_packed_columns(api, port):
         A.spmv(xd, y1); api.synchronize()
         k1 = lib.lcg_hip_csr_last_kernel(A.h).decode()
         assert "long rows" in k1, (name, k1)
+        # several unknowns per point: one packed column per group of consecutive columns -- and only where EVERY row is made of such groups
+        grouped = name.startswith("27-point x") and not name.endswith("out of step")
+        assert ("per group of consecutive columns" in k1) == grouped, (name, k1)
         assert torch.equal(y0, y1), name
         sums = (C.c_double * 2)()
         assert lib.lcg_hip_spmv_dot(A.h, xd.data_ptr(), y2.data_ptr(), ud.data_ptr(), sums) == 0
