@@ -139,7 +139,7 @@ struct OpCgInit {   // g = Ad - B; d = -g; m.m, g.g (x2: rho = g.g)      lcg.cpp
         const T av = ldz<T>(Ad, i, zg);
         if (zg && clear) st_(clear, i, av);
         const T gv = vsub(av, ld<T>(B, i));
-        const T mv = ld<T>(m, i);
+        const T mv = ldz<T>(m, i, zg);         // (an all-zero guess is not read a second time)
         st_(g, i, gv); st_(d, i, vneg(gv));
         acc[0] += dotp(mv, mv);
         const double gg = dotp(gv, gv);
@@ -333,7 +333,7 @@ struct OpShadowInit {   // p = (u =) r0 = r = B - Ax; m.m, r.r, r.r0      lcg.cp
     template <class T> __device__ void apply(long i, double *acc)
     {
         const T rv = vsub(ld<T>(B, i), ldz<T>(Ax, i, zg));
-        const T mv = ld<T>(m, i);
+        const T mv = ldz<T>(m, i, zg);         // (an all-zero guess is not read a second time)
         st_(r, i, rv); st_(r0, i, rv); st_(p, i, rv);
         if (WITH_U) st_(u, i, rv);
         acc[0] += dotp(mv, mv);
