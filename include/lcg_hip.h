@@ -152,6 +152,12 @@ int    lcg_hip_set_placement(int mode);
 /* The latest solve's placement: vectors timed (0 = everything came from memory, or not tried), roles moved, and what the first
  * output role's product took as allocated / as placed, microseconds (0 when not tried).  Any pointer may be NULL. */
 int    lcg_hip_last_placement(int *timed, int *moved, double *us_as_allocated, double *us_as_placed);
+/* The pool of work vectors the solvers keep between solves (lcg_hip_trim gives the idle ones back): how many vectors, their bytes, and how
+ * many of them are slots of an arena (a 1 GiB chunk the placement kept and cut up).  Any pointer may be NULL. */
+int    lcg_hip_pool_info(int *vectors, int64_t *bytes, int *arena_slots);
+/* Test hook: one allocation of slots x slot_bytes joins the pool as an arena of `slots` idle vectors -- what the placement's walk leaves
+ * behind, without the walk (tests/test_gpu_placement.py: solves take their vectors from it, lcg_hip_trim gives it back as a whole). */
+int    lcg_hip_pool_add_arena_for_test(uint64_t slot_bytes, int slots);
 
 /* ----------------------------------------------------------- solver entry */
 /* lcg.h:71-72 lcg_solver() -> lcg.cpp:59-82.  solver_id: LCG_CG, LCG_CGS, LCG_BICGSTAB,

@@ -253,6 +253,27 @@ int lcg_hip_trim(void)
     c.place_memo.clear();       // (addresses may come back as other memory)
     return 0;
 }
+int lcg_hip_pool_info(int *vectors, int64_t *bytes, int *arena_slots)
+{
+    Ctx &c = ctx();
+    int64_t b = 0; int a = 0;
+    for (auto &s : c.scratch) { b += (int64_t)s.bytes; a += s.arena != nullptr; }
+    if (vectors) *vectors = (int)c.scratch.size();
+    if (bytes) *bytes = b;
+    if (arena_slots) *arena_slots = a;
+    return 0;
+}
+int lcg_hip_pool_add_arena_for_test(uint64_t slot_bytes, int slots)
+{
+    if (slot_bytes == 0 || slots <= 0) return LCG_HIP_E_ARG;
+    int rc = ensure_init(); if (rc) return rc;
+    Ctx &c = ctx();
+    const size_t slot = ((size_t)slot_bytes + 255) & ~(size_t)255;
+    void *base = nullptr;
+    HIPCHK(hipMalloc(&base, slot * (size_t)slots));
+    for (int i = 0; i < slots; i++) c.scratch.push_back({reinterpret_cast<double *>(static_cast<char *>(base) + (size_t)i * slot), slot, false, base});
+    return 0;
+}
 int lcg_hip_set_placement(int mode)
 {
     if (mode < -1 || mode > 1) return LCG_HIP_E_ARG;

@@ -105,3 +105,48 @@ def test_placement_is_off_for_what_it_was_not_measured_on(api, lib, case10k):
     info = api.lcg_solver("lcg_hip_csr_ax", None, m, torch.from_numpy(b).cuda(), n, api.lcg_default_parameters(epsilon=1e-12, abs_diff=1), A, api.LCG_CG)
     assert info.ret == 0 and _last(lib) == (0, 0, 0.0, 0.0)
     A.destroy()
+
+
+def _pool(lib):
+    v, b, a = C.c_int(-1), C.c_int64(-1), C.c_int(-1)
+    assert lib.lcg_hip_pool_info(C.byref(v), C.byref(b), C.byref(a)) == 0
+    return v.value, b.value, a.value
+
+
+def test_arena_slots_serve_solves_and_leave_together(api, lib):
+    """What the placement's walk leaves behind -- one allocation cut into idle work vectors (an arena of the pool) -- without the walk:
+    solves take their vectors from it (same bits), a slot in use keeps the whole arena through lcg_hip_trim, and an idle arena leaves
+    as one allocation."""
+    n = 200_000
+    A = api.CsrMatrix.generate(n, 16, 4096, True, 5, 0.01, pattern=api.GEN_DIAGONALS)
+    xt = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 5, 0, n, xt)
+    b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
+    para = api.lcg_default_parameters(epsilon=1e-20, abs_diff=1, max_iterations=10)
+    api.set_cg_schedule(1)
+    try:
+        assert lib.lcg_hip_set_placement(0) == 0 and lib.lcg_hip_trim() == 0
+        assert _pool(lib) == (0, 0, 0)
+        m = torch.zeros(n, dtype=torch.float64, device="cuda")
+        api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, para, A, api.LCG_CG)
+        ref = _sha(m)
+        own = _pool(lib)
+        assert own[0] == 3 and own[2] == 0                  # g, d, A.d: three vectors of the library's own
+        assert lib.lcg_hip_trim() == 0 and _pool(lib) == (0, 0, 0)
+        # an arena of five slots: CG's three vectors come out of it (nothing else is allocated), bits unchanged, with and without placement
+        assert lib.lcg_hip_pool_add_arena_for_test(8 * n, 5) == 0
+        assert _pool(lib)[0] == 5 and _pool(lib)[2] == 5
+        for mode in (0, 1):
+            assert lib.lcg_hip_set_placement(mode) == 0
+            m = torch.zeros(n, dtype=torch.float64, device="cuda")
+            api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, para, A, api.LCG_CG)
+            assert _sha(m) == ref and _pool(lib)[0] == 5 and _pool(lib)[2] == 5
+        # BiCGStab needs six: the sixth is allocated beside the arena; after the solve everything is idle and trim takes all of it
+        m = torch.zeros(n, dtype=torch.float64, device="cuda")
+        api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, para, A, api.LCG_BICGSTAB)
+        assert _pool(lib)[0] == 6 and _pool(lib)[2] == 5
+        assert lib.lcg_hip_trim() == 0 and _pool(lib) == (0, 0, 0)
+        assert lib.lcg_hip_pool_add_arena_for_test(0, 3) != 0
+    finally:
+        lib.lcg_hip_set_placement(-1)
+        api.set_cg_schedule(0)
+        A.destroy()
