@@ -465,22 +465,36 @@ struct Placement {
         const lcg_hip_csr *A = static_cast<const lcg_hip_csr *>(inst);
         const size_t bytes = sizeof(double) * (size_t)n;
         const void *val = part(A).val;
-        constexpr float SAME = 1.03f;       // the two classes lie 8-12 % apart; timings of one class within 1-2 %
+        constexpr float SAME = 1.03f;       // a role changes hands for 3 %
+        constexpr float CLASS = 1.06f;      // two KINDS of places lie 8-12 % apart (timings of one kind spread by up to 4 %): what starts a walk and ends it
         struct Cand { double **role; double *p; float us; };
         std::vector<Cand> cand;
         int k = 0, out_owned = 0;
         for (double **r : roles) { if (ws.owns(*r)) { cand.push_back({r, *r, 0.f}); if (k < n_out) out_owned++; } k++; }
         if (out_owned == 0) return 0;
         const size_t n_own = cand.size();
-        for (auto &s : c.scratch) if (!s.busy && s.bytes >= bytes) cand.push_back({nullptr, s.p, 0.f});   // idle vectors of the pool
+        // idle vectors of the pool: the slots of arenas first (each was the fast place of SOME matrix), six at most -- a process that has
+        // multiplied many matrices must not time its whole history against the next one
+        for (int pass = 0; pass < 2; pass++)
+            for (auto &s : c.scratch)
+                if (!s.busy && s.bytes >= bytes && (s.arena != nullptr) == (pass == 0) && cand.size() < n_own + 6) cand.push_back({nullptr, s.p, 0.f});
         // the plan of a matrix is built by its first product: not on the clock
         if (part(A).last_kernel[0] == 0) { int rc = spmv_launch(part(A), false, A->variant, A->mean_row, x, cand[0].p, false, c.stream, nullptr); if (rc) return rc; }
+        {   // What a better place can give is what the written vector costs in the worse one: 60 us per 80 MB (0.75 us per MiB).  Where that is
+            // less than 4 % of the product -- the two-pass binned product at 1.75 ms, bands a million columns wide -- the kinds cannot be
+            // told apart by the clock and nothing is tried (39 vectors timed and 64 chunks walked for nothing, 0.3 s, before this line).
+            int rc = time_output(c, A, x, cand[0].p, &cand[0].us); if (rc) return rc;
+            c.place_us_first = c.place_us_chosen = cand[0].us;
+            if (0.75 * ((double)bytes / 1048576.0) < 0.04 * cand[0].us) {
+                if (debug_on()) fprintf(stderr, "[lcg_hip] placement: not tried (a product of %.0f us writes %.0f MiB: nothing a place could give shows on the clock)\n", cand[0].us, bytes / 1048576.0);
+                return 0;
+            }
+        }
         for (auto &q : cand) { int rc = time_output(c, A, x, q.p, &q.us); if (rc) return rc; }
-        c.place_us_first = cand[0].us;
         float lo = cand[0].us, hi = cand[0].us;
         for (auto &q : cand) { lo = std::min(lo, q.us); hi = std::max(hi, q.us); }
         size_t n_slow = 0;
-        for (size_t i = 0; i < n_own; i++) if (cand[i].us > lo * SAME) n_slow++;
+        for (size_t i = 0; i < n_own; i++) if (cand[i].us > lo * CLASS) n_slow++;
         // Not enough vectors outside the value array's group (or all alike: then nobody knows which kind they are).  What is allocated
         // one after the other lies side by side, so the library walks: chunks of 1 GiB, one after the other and all held, the product
         // timed into the start of every fourth, until one is clearly faster than our slow kind (or, all alike, clearly slower: then
@@ -489,13 +503,13 @@ struct Placement {
         // memory whatever is held elsewhere.  The fast chunk is KEPT and cut into vectors for this and later solves (one group
         // throughout: a 4 GiB allocation walked in steps of 64 MB never changes class); everything else is given back at once.  One
         // walk per matrix.
-        const bool alike = hi < lo * SAME;
+        const bool alike = hi < lo * CLASS;
         if (streams(A) && (alike || n_slow > 0) && memo(c, val, nullptr) == nullptr && bytes <= ((size_t)1 << 28)) {
             constexpr size_t CH = (size_t)1 << 30;
             const float ours = alike ? lo : hi;         // the kind to get away from
             std::vector<double *> chunks;
             double *found = nullptr; float found_us = 0.f; int rc = 0;
-            for (int q = 0; q < 64; q++) {
+            for (int q = 0; q < (alike ? 32 : 64); q++) {       // (all alike: there may be nothing to find -- half the way)
                 size_t fr = 0, tot = 0;
                 if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 9 * CH) break;
                 double *p = nullptr;
@@ -505,14 +519,35 @@ struct Placement {
                 float us = 0.f;
                 rc = time_output(c, A, x, p, &us);
                 if (rc) break;
-                if (us * SAME < ours) { found = p; found_us = us; chunks.pop_back(); break; }
-                if (alike && ours * SAME < us) break;          // slower than ours: ours are the fast kind, nothing to find
+                if (us * CLASS < ours) { found = p; found_us = us; chunks.pop_back(); break; }
+                if (alike && ours * CLASS < us) break;         // slower than ours: ours are the fast kind, nothing to find
             }
             if (debug_on()) fprintf(stderr, "[lcg_hip] placement walk: %zu chunks of 1 GiB given back, %s (%.1f us against %.1f)\n", chunks.size(),
                                     found ? "a faster place found and kept" : "nothing faster", found_us, ours);
             for (double *p : chunks) { (void)hipFree(p); forget_y(c, p); }
             if (rc) { if (found) { (void)hipFree(found); forget_y(c, found); } return rc; }
             if (found) {
+                // (two arenas at most: an older one that nobody uses goes first)
+                for (;;) {
+                    std::vector<void *> arenas;
+                    for (auto &s : c.scratch) if (s.arena && std::find(arenas.begin(), arenas.end(), s.arena) == arenas.end()) arenas.push_back(s.arena);
+                    if (arenas.size() < 2) break;
+                    void *victim = nullptr;
+                    for (void *a : arenas) {
+                        bool busy = false;
+                        for (auto &s : c.scratch) if (s.arena == a && s.busy) busy = true;
+                        if (!busy) { victim = a; break; }
+                    }
+                    if (!victim) break;
+                    for (size_t i = 0; i < c.scratch.size();)
+                        if (c.scratch[i].arena == victim) { forget_y(c, c.scratch[i].p); c.scratch.erase(c.scratch.begin() + (long)i); } else i++;
+                    for (size_t i = 0; i < cand.size();) {      // (its slots may stand among the candidates)
+                        bool gone = true;
+                        for (auto &s : c.scratch) if (s.p == cand[i].p) gone = false;
+                        if (cand[i].role == nullptr && gone) cand.erase(cand.begin() + (long)i); else i++;
+                    }
+                    (void)hipFree(victim);
+                }
                 // the chunk as an arena of the pool: slots of the vector's size (2 MiB-aligned), as many as the solve has roles + 2
                 const size_t slot = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
                 const size_t want = std::min(CH / slot, n_own + 2);
