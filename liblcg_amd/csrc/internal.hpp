@@ -248,20 +248,20 @@ struct CsrPart {
     mutable void *bn_plan = nullptr;
     mutable const char *bn_why = "not tried";   // why the plan is (not) there
     mutable double mean_span = -1.0;    // mean column span of a 64-row block (-1 = not measured)
-    mutable double line_ratio = -1.0;   // distinct 128-byte lines of x per entry of a 64-row block (-1 = not measured; csr.hip: k_line_ratio)
+    mutable double line_ratio = -1.0;   // distinct 128-byte lines of x per entry of a 64-row block (-1 = not measured; csr_choice.hip: k_line_ratio)
     mutable double diag_like = -1.0;    // fraction of entries whose column is one more than the entry above them (-1 = not measured)
     // one-pass "tiled" product for row-random bands (csr_tiled.hip), plan built on first use
     mutable int tl_mode = -1;      // -1 auto, 0 never, 1 whenever eligible
     mutable int tl_state = 0;      // 0 not tried, 1 plan ready, -1 not eligible / not chosen
     mutable void *tl_plan = nullptr;
     mutable const char *tl_why = "not tried";
-    // row ranges (csr.hip, "row ranges"): a matrix whose row blocks fall into different column-pattern classes is multiplied range by
+    // row ranges (csr_choice.hip, "row ranges"): a matrix whose row blocks fall into different column-pattern classes is multiplied range by
     // range, each range -- a view of this part's arrays -- choosing its own kernel family
     int64_t end_abs = -1;          // a view only: offset one past its last entry in the shared col / val (-1: this part owns offsets 0 .. nnz)
     mutable int rg_mode = -1;      // -1 auto (>= 4M entries), 0 never, 1 whenever two classes are found
     mutable int rg_state = 0;      // 0 not tried, 1 split, -1 one range
     mutable void *rg_plan = nullptr;
-    int lr_mode = 0;               // a view only: 1 = rows far longer than an LDS window live here (csr.hip: long_rows_launch)
+    int lr_mode = 0;               // a view only: 1 = rows far longer than an LDS window live here (csr_choice.hip: long_rows_launch)
     mutable void *lr_plan = nullptr;
     mutable const char *last_kernel = "";   // name of the kernel family the latest product used
     mutable double plan_ms = 0.0;           // host time spent choosing a kernel family and building its copy of the matrix (first product)

@@ -1,4 +1,4 @@
-"""-m gpu: row ranges (csr.hip, "row ranges"; lcg_hip_csr_set_ranges) -- matrices whose rows fall into different column-pattern
+"""-m gpu: row ranges (csr_choice.hip, "row ranges"; lcg_hip_csr_set_ranges) -- matrices whose rows fall into different column-pattern
 classes: a 27-point stencil in 90 % of the rows, long-range random couplings in the rest.
 
   * <= 60,000 rows, built on the host, ranges forced: A.x row by row against the oracle's product (1e-13 |A||x|), the cut where
