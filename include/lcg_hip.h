@@ -143,7 +143,8 @@ int    lcg_hip_set_cg_schedule(int schedule);
  * into each work vector of the solve that it owns itself (and into idle vectors of its pool) and deals the ROLES by weight -- the
  * products' outputs (A.d; A.p and A.s), the vector the product reads, the rest -- the fastest vectors to the heaviest roles.  Where
  * the solve has too few fast vectors, once per matrix: chunks of 1 GiB allocated one after the other until the product into one of
- * them (every fourth is timed) is clearly faster -- at most 64, never into the last 8 GiB of free memory; that chunk is kept and cut
+ * them (every fourth, later every eighth, is timed) is clearly faster -- at most 128 chunks and 60 ms, never into the last 8 GiB of
+ * free memory; that chunk is kept and cut
  * into work vectors (lcg_hip_trim gives it back), the others are given back at once.  Roles only: no arithmetic changes, iterates
  * are bit-identical (tests/test_gpu_placement.py).  Results are remembered per (matrix, vector), so later solves time nothing.
  * mode: -1 automatic (real; this process's product streams >= 384 MB), 0 never, 1 for every real matrix with the built-in callback

@@ -1645,7 +1645,7 @@ int lcg_hip_csr_create(lcg_hip_csr_t *out, int n_rows, int n_cols, int64_t nnz, 
 int lcg_hip_csr_destroy(lcg_hip_csr_t A)
 {
     if (!A) return 0;
-    ctx().place_memo.clear();       // (driver.hpp: Placement remembers timings by the value array's address)
+    ctx().forget_places();       // (driver.hpp: Placement remembers timings by the value array's address)
     dist_free(A);
     free_part(A->main);
     for (int i = 1; i < 4; i++) free_part(A->op[i]);

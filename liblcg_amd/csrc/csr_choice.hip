@@ -541,7 +541,7 @@ void ranges_free(const CsrPart &P)
     // (lcg_hip_csr_last_kernel / _last_traffic_model between this call and the next product)
     if (R) { for (CsrPart &V : R->parts) free_part(V); delete R; P.last_kernel = ""; }
     P.rg_plan = nullptr; P.rg_state = 0;
-    ctx().place_memo.clear();       // another kernel family may stream another copy of the matrix (driver.hpp: Placement)
+    ctx().forget_places();       // another kernel family may stream another copy of the matrix (driver.hpp: Placement)
 }
 
 } // namespace lcgh

@@ -372,7 +372,7 @@ struct Workspace {
         if (best < 0) {
             // nothing fits: give one idle smaller vector back and allocate
             for (size_t i = 0; i < c.scratch.size(); i++)
-                if (!c.scratch[i].busy && !c.scratch[i].arena) { (void)hipFree(c.scratch[i].p); c.scratch.erase(c.scratch.begin() + i); c.place_memo.clear(); break; }
+                if (!c.scratch[i].busy && !c.scratch[i].arena) { (void)hipFree(c.scratch[i].p); c.scratch.erase(c.scratch.begin() + i); c.forget_places(); break; }
             double *p = nullptr;
             HIPCHK(hipMalloc(&p, bytes));
             c.scratch.push_back({p, bytes, false, nullptr});
@@ -460,7 +460,7 @@ struct Placement {
     // numbers (the right-hand side).
     static int run(Ctx &c, int n, const void *afp, void *inst, const double *x, Workspace &ws, std::initializer_list<double **> roles, int n_out)
     {
-        c.place_timed = c.place_moved = 0; c.place_us_first = c.place_us_chosen = 0.0;
+        c.place_timed = c.place_moved = 0; c.place_us_first = c.place_us_chosen = 0.0; c.place_gated = false;
         if (!wanted(c, n, afp, inst)) return 0;
         const lcg_hip_csr *A = static_cast<const lcg_hip_csr *>(inst);
         const size_t bytes = sizeof(double) * (size_t)n;
@@ -487,18 +487,25 @@ struct Placement {
             c.place_us_first = c.place_us_chosen = cand[0].us;
             if (0.75 * ((double)bytes / 1048576.0) < 0.04 * cand[0].us) {
                 if (debug_on()) fprintf(stderr, "[lcg_hip] placement: not tried (a product of %.0f us writes %.0f MiB: nothing a place could give shows on the clock)\n", cand[0].us, bytes / 1048576.0);
+                c.place_gated = true;
                 return 0;
             }
         }
         for (auto &q : cand) { int rc = time_output(c, A, x, q.p, &q.us); if (rc) return rc; }
         float lo = cand[0].us, hi = cand[0].us;
         for (auto &q : cand) { lo = std::min(lo, q.us); hi = std::max(hi, q.us); }
+        // Every role is dealt, the heaviest first.  (Outputs only -- the vector the product reads pays less beside the values than the output
+        // does, and the clock of one product cannot tell the two other groups apart -- was tried after one process in fifteen came out 2.5 %
+        // slower placed than as allocated: on a box where nothing allocated is fast it gave 1488-1504 it/s where all roles out of the
+        // found arena give 1524-1553; and trial SOLVES of six iterations per assignment, to let the loop itself choose, differ by less
+        // than their own order effect.  Both are in profiles/r04_placement.txt; neither is in the code.)
+        const size_t n_deal = n_own;
         size_t n_slow = 0;
-        for (size_t i = 0; i < n_own; i++) if (cand[i].us > lo * CLASS) n_slow++;
+        for (size_t i = 0; i < n_deal; i++) if (cand[i].us > lo * CLASS) n_slow++;
         // Not enough vectors outside the value array's group (or all alike: then nobody knows which kind they are).  What is allocated
         // one after the other lies side by side, so the library walks: chunks of 1 GiB, one after the other and all held, the product
         // timed into the start of every fourth, until one is clearly faster than our slow kind (or, all alike, clearly slower: then
-        // ours are the fast kind) -- at most 64 chunks / 16 timings (30 ms), never into the last 8 GiB of free memory.  Larger steps
+        // ours are the fast kind) -- at most 128 chunks / 20 timings (50 ms), never into the last 8 GiB of free memory.  Larger steps
         // do not get further: an allocation of 4 GiB or more costs 30 ms per GiB, and the allocator serves small requests from near-by
         // memory whatever is held elsewhere.  The fast chunk is KEPT and cut into vectors for this and later solves (one group
         // throughout: a 4 GiB allocation walked in steps of 64 MB never changes class); everything else is given back at once.  One
@@ -509,21 +516,29 @@ struct Placement {
             const float ours = alike ? lo : hi;         // the kind to get away from
             std::vector<double *> chunks;
             double *found = nullptr; float found_us = 0.f; int rc = 0;
-            for (int q = 0; q < (alike ? 32 : 64); q++) {       // (all alike: there may be nothing to find -- half the way)
+            // (one of the three groups is a single stretch of 96 GiB: a matrix whose stream lies in it -- a fresh box hands out that
+            //  stretch first -- has its nearest better place up to 96 chunks away.  Allocating a chunk costs 0.1 ms, timing one 2 ms: every
+            //  fourth chunk is timed up to the 32nd, every eighth beyond, 128 at most.)
+            const auto w0 = std::chrono::steady_clock::now();
+            for (int q = 0; q < 128; q++) {
                 size_t fr = 0, tot = 0;
                 if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 9 * CH) break;
                 double *p = nullptr;
                 if (hipMalloc(&p, CH) != hipSuccess) { (void)hipGetLastError(); break; }
                 chunks.push_back(p);
-                if (q % 4 != 0) continue;
+                if (q % (q < 32 ? 4 : 8) != 0) continue;
+                // (the first chunks cost 0.5 ms each, those beyond the first few dozen 20 ms -- the driver clears what it hands out:
+                //  56 chunks took 0.95 s, 128 took 2.6 s.  The walk ends after 60 ms wherever it stands.)
+                if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count() > 60.0) break;
                 float us = 0.f;
                 rc = time_output(c, A, x, p, &us);
                 if (rc) break;
                 if (us * CLASS < ours) { found = p; found_us = us; chunks.pop_back(); break; }
                 if (alike && ours * CLASS < us) break;         // slower than ours: ours are the fast kind, nothing to find
             }
-            if (debug_on()) fprintf(stderr, "[lcg_hip] placement walk: %zu chunks of 1 GiB given back, %s (%.1f us against %.1f)\n", chunks.size(),
-                                    found ? "a faster place found and kept" : "nothing faster", found_us, ours);
+            if (debug_on()) fprintf(stderr, "[lcg_hip] placement walk: %zu chunks of 1 GiB given back, %s (%.1f us against %.1f), %.1f ms\n", chunks.size(),
+                                    found ? "a faster place found and kept" : "nothing faster", found_us, ours,
+                                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
             for (double *p : chunks) { (void)hipFree(p); forget_y(c, p); }
             if (rc) { if (found) { (void)hipFree(found); forget_y(c, found); } return rc; }
             if (found) {
@@ -564,7 +579,7 @@ struct Placement {
         // Deal the roles by weight: a role keeps its vector unless one that no heavier role holds is clearly faster.  Positions trade
         // vectors, so every role still has a vector of its own; a vector of the pool that lands in a role joins the solve (the one it
         // displaced stays with the solve, unused, and returns to the pool with the others).
-        for (size_t o = 0; o < n_own; o++) {
+        for (size_t o = 0; o < n_deal; o++) {
             size_t best = o;
             for (size_t j = o + 1; j < cand.size(); j++) if (cand[j].us < cand[best].us) best = j;
             if (best != o && cand[best].us * SAME < cand[o].us) { std::swap(cand[o].p, cand[best].p); std::swap(cand[o].us, cand[best].us); }

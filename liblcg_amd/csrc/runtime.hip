@@ -250,7 +250,7 @@ int lcg_hip_trim(void)
         if (!it->arena || it->p == it->arena) (void)hipFree(it->p);
         it = c.scratch.erase(it);
     }
-    c.place_memo.clear();       // (addresses may come back as other memory)
+    c.forget_places();       // (addresses may come back as other memory)
     return 0;
 }
 int lcg_hip_pool_info(int *vectors, int64_t *bytes, int *arena_slots)
