@@ -485,7 +485,7 @@ struct Placement {
             // told apart by the clock and nothing is tried (39 vectors timed and 64 chunks walked for nothing, 0.3 s, before this line).
             int rc = time_output(c, A, x, cand[0].p, &cand[0].us); if (rc) return rc;
             c.place_us_first = c.place_us_chosen = cand[0].us;
-            if (0.75 * ((double)bytes / 1048576.0) < 0.04 * cand[0].us) {
+            if (c.place_mode < 0 && 0.75 * ((double)bytes / 1048576.0) < 0.04 * cand[0].us) {      // (automatic mode: a forced placement always tries)
                 if (debug_on()) fprintf(stderr, "[lcg_hip] placement: not tried (a product of %.0f us writes %.0f MiB: nothing a place could give shows on the clock)\n", cand[0].us, bytes / 1048576.0);
                 c.place_gated = true;
                 return 0;
