@@ -460,7 +460,7 @@ struct Placement {
     // numbers (the right-hand side).
     static int run(Ctx &c, int n, const void *afp, void *inst, const double *x, Workspace &ws, std::initializer_list<double **> roles, int n_out)
     {
-        c.place_timed = c.place_moved = 0; c.place_us_first = c.place_us_chosen = 0.0; c.place_gated = false;
+        c.place_timed = c.place_moved = 0; c.place_us_first = c.place_us_chosen = 0.0;
         if (!wanted(c, n, afp, inst)) return 0;
         const lcg_hip_csr *A = static_cast<const lcg_hip_csr *>(inst);
         const size_t bytes = sizeof(double) * (size_t)n;
@@ -487,7 +487,6 @@ struct Placement {
             c.place_us_first = c.place_us_chosen = cand[0].us;
             if (c.place_mode < 0 && 0.75 * ((double)bytes / 1048576.0) < 0.04 * cand[0].us) {      // (automatic mode: a forced placement always tries)
                 if (debug_on()) fprintf(stderr, "[lcg_hip] placement: not tried (a product of %.0f us writes %.0f MiB: nothing a place could give shows on the clock)\n", cand[0].us, bytes / 1048576.0);
-                c.place_gated = true;
                 return 0;
             }
         }
@@ -505,7 +504,7 @@ struct Placement {
         // Not enough vectors outside the value array's group (or all alike: then nobody knows which kind they are).  What is allocated
         // one after the other lies side by side, so the library walks: chunks of 1 GiB, one after the other and all held, the product
         // timed into the start of every fourth, until one is clearly faster than our slow kind (or, all alike, clearly slower: then
-        // ours are the fast kind) -- at most 128 chunks / 20 timings (50 ms), never into the last 8 GiB of free memory.  Larger steps
+        // ours are the fast kind) -- at most 128 chunks and 60 ms, never into the last 8 GiB of free memory.  Larger steps
         // do not get further: an allocation of 4 GiB or more costs 30 ms per GiB, and the allocator serves small requests from near-by
         // memory whatever is held elsewhere.  The fast chunk is KEPT and cut into vectors for this and later solves (one group
         // throughout: a 4 GiB allocation walked in steps of 64 MB never changes class); everything else is given back at once.  One
@@ -517,8 +516,8 @@ struct Placement {
             std::vector<double *> chunks;
             double *found = nullptr; float found_us = 0.f; int rc = 0;
             // (one of the three groups is a single stretch of 96 GiB: a matrix whose stream lies in it -- a fresh box hands out that
-            //  stretch first -- has its nearest better place up to 96 chunks away.  Allocating a chunk costs 0.1 ms, timing one 2 ms: every
-            //  fourth chunk is timed up to the 32nd, every eighth beyond, 128 at most.)
+            //  stretch first -- has its nearest better place up to 96 chunks away.  Timing a chunk costs 2 ms: every fourth is timed up to
+            //  the 32nd, every eighth beyond, 128 at most -- and 60 ms, see below.)
             const auto w0 = std::chrono::steady_clock::now();
             for (int q = 0; q < 128; q++) {
                 size_t fr = 0, tot = 0;

@@ -198,7 +198,6 @@ struct Ctx {
     void forget_places() { place_memo.clear(); }
     int place_mode = -1;               // lcg_hip_set_placement: -1 auto (large products on one GPU), 0 never, 1 whenever the callback is the built-in one
     int place_timed = 0;               // candidates timed by the latest solve (0: answered from the memo, or not tried)
-    bool place_gated = false;          // the latest placement was not tried: a better place could not show on the clock (driver.hpp)
     int place_moved = 0;               // roles the latest solve moved to another vector
     double place_us_first = 0.0, place_us_chosen = 0.0;   // the latest solve's first output: as allocated / as placed
     unsigned shadow_seed = 1;
