@@ -446,8 +446,9 @@ __global__ void k_pk_groups(int nb, int per, int *ngroups)
     if (b < nb) {
         const int g = ngroups[b];
         // (a template block: its D offsets, then a mask per row -- 32 bits wide up to 32 diagonals, 64 beyond)
+        // (a run block: row 0's L columns and, behind them, the slot of the block's own diagonal)
         ngroups[b] = g <= -TPL_GRP ? (-g - TPL_GRP + 3) / 4 + (-g - TPL_GRP <= 32 ? PK_R / 4 : PK_R / 2)
-                                   : (g < 0 ? (-g + 3) / 4 : (per > 0 ? (g + per - 1) / per : 0));
+                                   : (g < 0 ? (-g + 1 + 3) / 4 : (per > 0 ? (g + per - 1) / per : 0));
     }
 }
 
@@ -509,7 +510,9 @@ __global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const 
     if (bs < 0) {       // run block: row 0's columns as they are
         const int L = -1 - bs;
         int *dst = reinterpret_cast<int *>(packed + pofs[b]);
-        for (int k = threadIdx.x; k < ((L + 3) & ~3); k += VB) dst[k] = k < L ? col[s + k] : 0;
+        int kd = -1;        // the slot whose column is the block's first row (every row's diagonal, then): k_spmv_ldsp<DOT> takes u = x from it
+        for (int k = 0; k < L; k++) if (col[s + k] == (int)row0) kd = k;
+        for (int k = threadIdx.x; k < ((L + 1 + 3) & ~3); k += VB) dst[k] = k < L ? col[s + k] : (k == L ? kd : 0);
         return;
     }
     const int ng = (e - s + PER * dof - 1) / (PER * dof);       // (dof > 1: a field is the first column of a group of dof entries)
@@ -599,7 +602,14 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     const int po = pofs[bid], bs = pbase[bid];
     const int bv = s & ~1, cntv = e - bv;
     double uv = 0.0;
-    if (DOT) uv = dp.u[(j0 == 0 && rl < nrows) ? row0 + rl : 0];     // requested ahead of the stream: hidden behind it
+    // (u == x and a run block that holds its own diagonal: u of row r IS one of the block's gathers, x[column(0, kd) + r] with
+    //  column(0, kd) = the block's first row -- 80 MB less to read per product of the headline system.  kd comes with the block's columns:
+    //  searching row 0's columns here, 33 dependent scalar loads in front of the stream's requests, made the product 22 % SLOWER.)
+    int kd = -1;
+    if (DOT && RR == 64 && dp.ux && bs < 0 && bs > -TPL_CODE) {
+        kd = reinterpret_cast<const int *>(packed + po)[-1 - bs];      // (k_pk_pack left it behind row 0's columns: -1 = the block does not hold its diagonal)
+    }
+    if (DOT && kd < 0) uv = dp.u[(j0 == 0 && rl < nrows) ? row0 + rl : 0];     // requested ahead of the stream: hidden behind it
 
     if (RR == 64 && bs <= -TPL_CODE) {     // (run and template blocks are shapes of 64 rows: the builder marks none at 32 / 16 rows per block)
         // TEMPLATE block (k_pk_meta): every entry lies on one of D <= 64 diagonals and every row says by a mask which of them it
@@ -713,17 +723,24 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
         __syncthreads();
         double acc = 0.0;
         const int rs = s + rl * L - bv;                    // first entry of this lane's row in the staged values
+        double *sud = reinterpret_cast<double *>(scol);     // (a run block stages no columns: its u, where the diagonal is among the gathers)
         if (live) {
 #pragma unroll
             for (int q = 0; q < UNR; q++) {
                 const int k = w + q * T;
                 acc = k < L ? fma(sval[rs + k], xv[q], acc) : acc;
+                if (DOT && k == kd) sud[rl] = xv[q];        // (uniform: one wavefront, one q)
             }
-            for (int k = w + UNR * T; k < L; k += T) acc = fma(sval[rs + k], x[bcol[k] + rl], acc);
+            for (int k = w + UNR * T; k < L; k += T) {
+                const double xk = x[bcol[k] + rl];
+                acc = fma(sval[rs + k], xk, acc);
+                if (DOT && k == kd) sud[rl] = xk;
+            }
         }
         __syncthreads();
         sred[j0][rl] = acc;
         __syncthreads();
+        if (DOT && kd >= 0 && j0 == 0 && live) uv = sud[rl];
         double vfin = 0.0;
         if (j0 == 0 && live) {
             double v = sred[0][rl];
@@ -1494,6 +1511,8 @@ int csr_part_ax_dot(const CsrPart &P, int variant, double mean_row, const double
     const int nblk = (n + PK_R - 1) / PK_R;
     if (!ensure_dot_part(P, nblk)) return 0;
     DotPlan dp; dp.u = u; dp.part = P.dot_part; dp.yy = yy; dp.stride = nblk; dp.ystore = y_store_policy();
+    {   static const bool ux_off = [] { const char *e = lab_env("LCG_HIP_DOT_UX"); return e && atoi(e) == 0; }();      // (A/B runs)
+        dp.ux = (u == x && !ux_off) ? 1 : 0; }
     const int per_lane = (P.pk_maxrow + VB / PK_R - 1) / (VB / PK_R);
     const int ns = per_lane <= 6 ? 6 : per_lane <= 7 ? 7 : per_lane <= 8 ? 8 : per_lane <= 9 ? 9 : per_lane <= 10 ? 10 : per_lane <= 12 ? 12 : 8;
     const PushPlan ppv = pp ? *pp : PushPlan();

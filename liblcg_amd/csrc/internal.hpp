@@ -118,6 +118,7 @@ struct DotPlan {
     int yy = 0;
     int stride = AXP_CAP;   // distance of the y.y sums from the y.u sums in `part`
     int ystore = 0;         // how k_spmv_ldsp stores y (devcommon.hpp: store_y; set by the host from y_store_policy())
+    int ux = 0;             // u is the product's own x (CG, PCG: d.Ad): a run block that holds its diagonal takes u from its gathers
     int dof = 1;            // k_spmv_ldsp, long rows: a packed column field stands for `dof` consecutive columns (csr.hip: k_pk_dof)
 };
 

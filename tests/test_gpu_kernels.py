@@ -885,3 +885,38 @@ def test_odd_shapes_against_the_oracle(api, port):
         scale = port.csr_matvec(rp, ci, np.abs(v), np.abs(xh))
         assert float(np.max(np.abs(y.cpu().numpy() - ref) / np.maximum(scale, 1e-300))) <= 1e-13, (name, k)
         A.destroy()
+
+
+def test_the_dot_takes_u_from_the_gathers_where_u_is_x(api):
+    """k_spmv_ldsp<DOT> with u == x (CG / PCG: d.Ad): a run block that holds its own diagonal takes u of row r from its gathers --
+    x[column(0, kd) + r], kd left behind row 0's columns by k_pk_pack -- instead of reading it.  The sums must be the SAME BITS as with u
+    = a copy of x at another address (which is read), on generated systems with the diagonal (symmetric family), on one whose rows do NOT
+    hold their diagonal (the diagonals shifted by one column: kd = -1 everywhere), and at the matrix edges (no run blocks there)."""
+    from liblcg_amd import _lib
+    lib = _lib.load()
+    import scipy.sparse as sp
+    n = 300_000
+    cases = []
+    A0 = api.CsrMatrix.generate(n, 16, 4096, True, 4, 0.01, pattern=api.GEN_DIAGONALS)
+    cases.append(("with its diagonal", A0, True))
+    offs = np.array([-3000, -517, -64, -2, 1, 2, 77, 900, 2500, 4000, 4001, 4002, 5000, 6000, 7000, 8000, 9000, 9100, 9200, 9300, 9400, 9500], np.int64)   # no 0
+    i = np.arange(n, dtype=np.int64)[:, None] + offs[None, :]
+    ok = (i >= 0) & (i < n)
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum(ok.sum(1))
+    ci = i[ok]
+    rng = np.random.default_rng(5)
+    A1 = api.CsrMatrix.from_csr(rp.astype(np.int32), ci.astype(np.int32), rng.standard_normal(len(ci)))
+    cases.append(("without a diagonal", A1, False))
+    res = (C.c_double * 2)(); res2 = (C.c_double * 2)()
+    for name, A, has_diag in cases:
+        assert lib.lcg_hip_csr_set_packed(A.h, 1) == 0
+        x = torch.from_numpy(rng.standard_normal(n)).cuda(); xc = x.clone()
+        y = torch.empty_like(x); y2 = torch.empty_like(x)
+        assert lib.lcg_hip_spmv_dot(A.h, x.data_ptr(), y.data_ptr(), x.data_ptr(), res) == 0           # u IS x
+        kern = lib.lcg_hip_csr_last_kernel(A.h).decode()
+        assert "k_spmv_ldsp" in kern and "run blocks" in kern and "carrying the dot" in kern, (name, kern)
+        assert lib.lcg_hip_spmv_dot(A.h, x.data_ptr(), y2.data_ptr(), xc.data_ptr(), res2) == 0       # u = the same numbers elsewhere
+        assert torch.equal(y, y2) and res[0] == res2[0] and res[1] == res2[1], (name, res[0], res2[0])
+        yh = y.cpu().numpy(); xh = x.cpu().numpy()
+        assert abs(res[0] - float(yh @ xh)) <= 1e-12 * float(np.abs(yh) @ np.abs(xh)), name
+        A.destroy()
