@@ -447,7 +447,7 @@ __global__ void k_pk_groups(int nb, int per, int *ngroups)
         const int g = ngroups[b];
         // (a template block: its D offsets, then a mask per row -- 32 bits wide up to 32 diagonals, 64 beyond)
         // (a run block: row 0's L columns and, behind them, the slot of the block's own diagonal)
-        ngroups[b] = g <= -TPL_GRP ? (-g - TPL_GRP + 3) / 4 + (-g - TPL_GRP <= 32 ? PK_R / 4 : PK_R / 2)
+        ngroups[b] = g <= -TPL_GRP ? (-g - TPL_GRP + 1 + 3) / 4 + (-g - TPL_GRP <= 32 ? PK_R / 4 : PK_R / 2)
                                    : (g < 0 ? (-g + 1 + 3) / 4 : (per > 0 ? (g + per - 1) / per : 0));
     }
 }
@@ -500,8 +500,15 @@ __global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const 
             int D; bool bad;
             const unsigned long long m = tpl_row_mask(row0, r1, rowptr, col, tpl, &dcount, &D, &bad);
             int *dst = reinterpret_cast<int *>(packed + pofs[b]);
-            const int Dp = (D + 3) & ~3;
-            if ((int)threadIdx.x < Dp) dst[threadIdx.x] = (int)threadIdx.x < D ? tpl[threadIdx.x] : 0;
+            const int Dp = (D + 1 + 3) & ~3;
+            // behind the D offsets: which of them is the block's own diagonal (offset = the block's first row) when EVERY row of the block
+            // has it, else -1 -- k_spmv_ldsp<DOT> then takes u = x from the gathers (as for run blocks)
+            int idg = -1;
+            for (int i = 0; i < D; i++) if (tpl[i] == (int)row0) idg = i;
+            const bool lacks = idg < 0 || (row0 + (long)threadIdx.x < r1 && !((m >> idg) & 1ull));
+            if (__ballot(lacks)) idg = -1;
+            if ((int)threadIdx.x < D) dst[threadIdx.x] = tpl[threadIdx.x];
+            if (threadIdx.x == 0) { dst[D] = idg; for (int i = D + 1; i < Dp; i++) dst[i] = 0; }      // (D may be 64: one lane writes the tail)
             if (D <= 32) reinterpret_cast<unsigned *>(dst + Dp)[threadIdx.x] = (unsigned)m;
             else reinterpret_cast<unsigned long long *>(dst + Dp)[threadIdx.x] = m;      // (Dp ints = whole 16-byte groups: aligned)
         }
@@ -606,9 +613,8 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
     //  column(0, kd) = the block's first row -- 80 MB less to read per product of the headline system.  kd comes with the block's columns:
     //  searching row 0's columns here, 33 dependent scalar loads in front of the stream's requests, made the product 22 % SLOWER.)
     int kd = -1;
-    if (DOT && RR == 64 && dp.ux && bs < 0 && bs > -TPL_CODE) {
-        kd = reinterpret_cast<const int *>(packed + po)[-1 - bs];      // (k_pk_pack left it behind row 0's columns: -1 = the block does not hold its diagonal)
-    }
+    if (DOT && RR == 64 && dp.ux && bs < 0)     // (k_pk_pack left it behind row 0's L columns / the template's D offsets: -1 = not every row of the block holds its diagonal)
+        kd = reinterpret_cast<const int *>(packed + po)[bs > -TPL_CODE ? -1 - bs : -bs - TPL_CODE];
     if (DOT && kd < 0) uv = dp.u[(j0 == 0 && rl < nrows) ? row0 + rl : 0];     // requested ahead of the stream: hidden behind it
 
     if (RR == 64 && bs <= -TPL_CODE) {     // (run and template blocks are shapes of 64 rows: the builder marks none at 32 / 16 rows per block)
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
         static_assert(UNR * T >= TPL_MAXROW || NS < 8, "one predicated batch covers the longest row of a template block");
         const int D = -bs - TPL_CODE;
         const int *tplp = reinterpret_cast<const int *>(packed + po);
-        const int *mskp = tplp + ((D + 3) & ~3);           // 64 masks: 32 bits wide up to 32 diagonals, 64 beyond
+        const int *mskp = tplp + ((D + 1 + 3) & ~3);       // 64 masks: 32 bits wide up to 32 diagonals, 64 beyond (tplp[D]: the diagonal's index)
         const bool live = rl < nrows;
         double vfin = 0.0;
         // two instances of the same code, chosen by a scalar branch: WIDE (33 .. 64 diagonals) works on 64-bit masks, the other --
@@ -670,14 +676,20 @@ __global__ __launch_bounds__(VB) void k_spmv_ldsp(int n, const int *__restrict__
             }
             __syncthreads();
             double acc = 0.0;
+            // (the diagonal is entry e_d of this row -- the set bits of its mask below the diagonal's -- and lives in lane e_d mod T, batch e_d / T)
+            double *sud = reinterpret_cast<double *>(scol);
+            const int ed = (DOT && kd >= 0) ? (WIDE ? __popcll((unsigned long long)(mask & (((M)1 << kd) - (M)1))) : __popc((unsigned)(mask & (((M)1 << kd) - (M)1)))) : -1;
+            const int qd = (ed >= 0 && ed % T == j0) ? ed / T : -1;
 #pragma unroll
             for (int q = 0; q < UNR; q++) {
                 const int e = j0 + q * T;
                 acc = (live && e < len) ? fma(sval[rs + e], xv[q], acc) : acc;
+                if (DOT && q == qd && live) sud[rl] = xv[q];
             }
             __syncthreads();
             sred[j0][rl] = acc;
             __syncthreads();
+            if (DOT && kd >= 0 && j0 == 0 && live) uv = sud[rl];
             if (j0 == 0 && live) {
                 double v = sred[0][rl];
 #pragma unroll
@@ -921,8 +933,8 @@ __device__ __forceinline__ double run1_block(int b, int wv, int n, int LP, const
         const int *tplp = pcols + 4 * (long)po;
         const bool wide = D > 32;       // uniform: 64-bit masks beyond 32 diagonals
         unsigned long long mask = 0ull;
-        if (live) mask = wide ? reinterpret_cast<const unsigned long long *>(tplp + ((D + 3) & ~3))[lane]
-                              : (unsigned long long)reinterpret_cast<const unsigned *>(tplp + ((D + 3) & ~3))[lane];
+        if (live) mask = wide ? reinterpret_cast<const unsigned long long *>(tplp + ((D + 1 + 3) & ~3))[lane]
+                              : (unsigned long long)reinterpret_cast<const unsigned *>(tplp + ((D + 1 + 3) & ~3))[lane];
         const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
         const int rs = live ? rowptr[row0 + lane] - s : 0;     // this lane's row in the block's values
         // the block's values, coalesced, into the wavefront's piece of LDS as they lie in memory (64 x LP doubles hold them: LP >= the

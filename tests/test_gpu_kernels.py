@@ -907,14 +907,19 @@ def test_the_dot_takes_u_from_the_gathers_where_u_is_x(api):
     rng = np.random.default_rng(5)
     A1 = api.CsrMatrix.from_csr(rp.astype(np.int32), ci.astype(np.int32), rng.standard_normal(len(ci)))
     cases.append(("without a diagonal", A1, False))
+    # a 27-point stencil: template blocks (every block holds boundary rows at this grid), the diagonal among their diagonals
+    ns, rps, cis = _stencil((24, 40, 64), 1, False)
+    A2 = api.CsrMatrix.from_csr(rps, cis, rng.standard_normal(len(cis)))
+    cases.append(("template blocks", A2, True))
     res = (C.c_double * 2)(); res2 = (C.c_double * 2)()
     for name, A, has_diag in cases:
+        n = A.n
         assert lib.lcg_hip_csr_set_packed(A.h, 1) == 0
         x = torch.from_numpy(rng.standard_normal(n)).cuda(); xc = x.clone()
         y = torch.empty_like(x); y2 = torch.empty_like(x)
         assert lib.lcg_hip_spmv_dot(A.h, x.data_ptr(), y.data_ptr(), x.data_ptr(), res) == 0           # u IS x
         kern = lib.lcg_hip_csr_last_kernel(A.h).decode()
-        assert "k_spmv_ldsp" in kern and "run blocks" in kern and "carrying the dot" in kern, (name, kern)
+        assert "k_spmv_ldsp" in kern and ("template blocks" if name == "template blocks" else "run blocks") in kern and "carrying the dot" in kern, (name, kern)
         assert lib.lcg_hip_spmv_dot(A.h, x.data_ptr(), y2.data_ptr(), xc.data_ptr(), res2) == 0       # u = the same numbers elsewhere
         assert torch.equal(y, y2) and res[0] == res2[0] and res[1] == res2[1], (name, res[0], res2[0])
         yh = y.cpu().numpy(); xh = x.cpu().numpy()
