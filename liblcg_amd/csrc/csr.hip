@@ -517,8 +517,12 @@ __global__ __launch_bounds__(VB) void k_pk_pack(int n, const int *rowptr, const 
     if (bs < 0) {       // run block: row 0's columns as they are
         const int L = -1 - bs;
         int *dst = reinterpret_cast<int *>(packed + pofs[b]);
-        int kd = -1;        // the slot whose column is the block's first row (every row's diagonal, then): k_spmv_ldsp<DOT> takes u = x from it
-        for (int k = 0; k < L; k++) if (col[s + k] == (int)row0) kd = k;
+        // behind them: the slot whose column is the block's first row (every row's diagonal, then), or -1: k_spmv_ldsp<DOT> takes u = x from it
+        __shared__ int kd;
+        if (threadIdx.x == 0) kd = -1;
+        __syncthreads();
+        for (int k = threadIdx.x; k < L; k += VB) if (col[s + k] == (int)row0) kd = k;       // (columns ascend: one match at most)
+        __syncthreads();
         for (int k = threadIdx.x; k < ((L + 1 + 3) & ~3); k += VB) dst[k] = k < L ? col[s + k] : (k == L ? kd : 0);
         return;
     }
