@@ -475,10 +475,12 @@ __global__ __launch_bounds__(VB) void k_pk_dof(int n, const int *__restrict__ ro
     unsigned bad = 0;       // bit g - 2
     if (i < n) {
         const int s = rowptr[i], len = rowptr[i + 1] - s;
-        for (int g = 2; g <= 4; g++) {
-            bool b = len % g != 0;
-            for (int k = 0; k < len && !b; k++) b = (k % g) != 0 && col[s + k] != col[s + k - 1] + 1;
-            if (b) bad |= 1u << (g - 2);
+        bad = (len % 2 != 0 ? 1u : 0u) | (len % 3 != 0 ? 2u : 0u) | (len % 4 != 0 ? 4u : 0u);
+        int prev = len > 0 ? col[s] : 0;
+        for (int k = 1; k < len && bad != 7u; k++) {        // one walk for the three group sizes
+            const int c = col[s + k];
+            if (c != prev + 1) bad |= (k % 2 != 0 ? 1u : 0u) | (k % 3 != 0 ? 2u : 0u) | (k % 4 != 0 ? 4u : 0u);
+            prev = c;
         }
     }
     for (int g = 0; g < 3; g++) if (__ballot((bad >> g) & 1u) != 0ull && (threadIdx.x & 63) == 0) ok[g] = 0;
