@@ -147,7 +147,7 @@ int    lcg_hip_set_cg_schedule(int schedule);
  * free memory; that chunk is kept and cut
  * into work vectors (lcg_hip_trim gives it back), the others are given back at once.  Roles only: no arithmetic changes, iterates
  * are bit-identical (tests/test_gpu_placement.py).  Results are remembered per (matrix, vector), so later solves time nothing.
- * mode: -1 automatic (real; this process's product streams >= 384 MB), 0 never, 1 for every real matrix with the built-in callback
+ * mode: -1 automatic (real; this process's product streams >= 768 MB), 0 never, 1 for every real matrix with the built-in callback
  * (no walk below that size).  LCG_HIP_PLACE in the environment sets the initial mode. */
 int    lcg_hip_set_placement(int mode);
 /* The latest solve's placement: vectors timed (0 = everything came from memory, or not tried), roles moved, and what the first

@@ -423,9 +423,9 @@ struct Placement {
     }
     // the rows this process multiplies by itself: the whole matrix, or -- sharded -- the entries with locally owned columns
     static const CsrPart &part(const lcg_hip_csr *A) { return A->distributed ? A->loc : A->main; }
-    // the effect needs a stream that comes from memory, not from the 256 MB Infinity Cache (an 8-way shard of the 10M-row system
-    // streams 490 MB)
-    static bool streams(const lcg_hip_csr *A) { return (long)part(A).nnz * 12L >= (384L << 20); }
+    // the effect needs a stream far larger than the 256 MB Infinity Cache: at the 8-way shard size of the 10M-row system (490 MB streamed,
+    // 10 MB written) eighteen candidates and a whole walk showed ONE kind of place, 69.9-71.8 us (profiles/r04_placement.txt, section 10)
+    static bool streams(const lcg_hip_csr *A) { return (long)part(A).nnz * 12L >= (768L << 20); }
     static float *memo(Ctx &c, const void *val, const double *y)
     {
         for (auto &m : c.place_memo) if (m.val == val && m.y == y) return &m.us;
