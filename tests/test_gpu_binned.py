@@ -243,3 +243,25 @@ def test_tiled_product_carries_the_dot():
         assert i1.ret == i2.ret == 0 and abs(i1.iterations - i2.iterations) <= 3
         assert ((m1 - x).norm() / x.norm()).item() <= 1e-8 and ((m2 - x).norm() / x.norm()).item() <= 1e-8
         A.destroy()
+
+
+def test_wide_bands_at_full_size_take_the_tiled_product(api, lib):
+    """The rule scripts/choice_regret.py moved (profiles/r04_choice_regret.txt): at 10M rows a band of +-524288 columns drawn per row -- a mean
+    block span of 2^20, "scattered" by round 3's rule, which cut the matrix into ranges with a binned middle (1828 us) -- is ONE tiled
+    product (1027 us); at +-2097152 the binned product has long taken over (1599 against 3115 us; around +-1048576 the two are within 5 % of
+    each other and either may be chosen); y against the plain row-block kernel's."""
+    n = 10_000_000
+    for band, want in ((524288, b"k_tile_spmv"), (2097152, b"k_bin_expand")):
+        A = api.CsrMatrix.generate(n, 16, band, True, 1, 0.01, pattern=api.GEN_ROW_RANDOM_BAND)
+        x = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 1, 0, n, x)
+        y = torch.empty_like(x); y2 = torch.empty_like(x)
+        A.spmv(x, y); api.synchronize()
+        kern = lib.lcg_hip_csr_last_kernel(A.h)
+        assert kern.startswith(want), (band, kern)
+        assert lib.lcg_hip_csr_set_tiled(A.h, 0) == 0 and lib.lcg_hip_csr_set_binned(A.h, 0) == 0 and lib.lcg_hip_csr_set_ranges(A.h, 0) == 0
+        A.spmv(x, y2); api.synchronize()
+        assert b"k_spmv" in lib.lcg_hip_csr_last_kernel(A.h)
+        assert ((y - y2).abs().max() <= 1e-13 * y2.abs().max()).item(), band
+        A.destroy()
+        del x, y, y2
+        torch.cuda.empty_cache()
