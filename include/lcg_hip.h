@@ -369,6 +369,10 @@ int lcg_hip_comm_init(int nranks, int rank, const void *id128);
 int lcg_hip_comm_destroy(void);
 int lcg_hip_comm_rank(void);
 int lcg_hip_comm_size(void);
+/* Path of the shared object the collectives were bound from ("" before the first lcg_hip_comm_* call).  By default the copy of
+ * librccl already mapped into the process (the host program's), else librccl.so from the loader's path; LCG_HIP_RCCL_LIB=<path>
+ * binds exactly that file instead, privately (a site's own RCCL build; tests/fake_rccl for several ranks on one GPU). */
+const char *lcg_hip_comm_library(void);
 /* Bind a row shard (created with GLOBAL column indices over n_global columns) to the
  * communicator: splits it into local-column and remote-column parts and sizes the gather
  * buffer.  rows_per_rank = ceil(n_global / nranks); rank r owns rows

@@ -115,6 +115,7 @@ SIGNATURES = {
     "lcg_hip_comm_destroy": (C.c_int, []),
     "lcg_hip_comm_rank": (C.c_int, []),
     "lcg_hip_comm_size": (C.c_int, []),
+    "lcg_hip_comm_library": (C.c_char_p, []),
     "lcg_hip_csr_distribute": (C.c_int, [vp, C.c_int64, C.c_int]),
     "lcg_hip_allreduce_sum": (C.c_int, [vp, C.c_int]),
     "lcg_hip_barrier": (C.c_int, []),

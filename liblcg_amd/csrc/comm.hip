@@ -41,6 +41,7 @@ struct Comm {
     ncclResult_t (*GroupEnd)() = nullptr;
     bool force = false;     // LCG_HIP_FORCE_COMM: run the collectives even with one rank (tests)
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string path;       // the shared object ncclAllGather was bound from
 };
 
 static Comm g_comm;     // function table (valid once lib != nullptr)
@@ -58,7 +59,15 @@ static int load_rccl()
     if (g_comm.lib) return 0;
     const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", nullptr};
     void *h = nullptr;
-    // prefer a copy that is already mapped (RTLD_NOLOAD), then a fresh load
+    // LCG_HIP_RCCL_LIB = path: exactly that build of the collectives library, privately (RTLD_LOCAL: the host program's own
+    // copy, e.g. PyTorch's, keeps its symbols) -- a site's tuned RCCL, or tests/fake_rccl (several ranks on one GPU)
+    if (const char *path = std::getenv("LCG_HIP_RCCL_LIB")) {
+        if (*path) {
+            h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+            if (!h) { ctx().err = std::string("LCG_HIP_RCCL_LIB: cannot load ") + path + ": " + dlerror(); return LCG_HIP_E_COMM; }
+        }
+    }
+    // otherwise prefer a copy that is already mapped (RTLD_NOLOAD), then a fresh load
     for (int pass = 0; pass < 2 && !h; pass++)
         for (int i = 0; names[i] && !h; i++)
             h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
@@ -79,6 +88,8 @@ static int load_rccl()
     SYM(GroupEnd, "ncclGroupEnd")
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+    Dl_info info;
+    g_comm.path = (dladdr(reinterpret_cast<void *>(g_comm.AllGather), &info) && info.dli_fname) ? info.dli_fname : "?";
     return 0;
 }
 
@@ -1076,6 +1087,7 @@ int lcg_hip_comm_destroy(void)
 }
 
 int lcg_hip_comm_rank(void) { return g_comm.rank; }
+const char *lcg_hip_comm_library(void) { return g_comm.lib ? g_comm.path.c_str() : ""; }
 int lcg_hip_comm_size(void) { return g_comm.nranks; }
 
 int lcg_hip_csr_distribute(lcg_hip_csr_t A, int64_t n_global, int mode)
