@@ -55,6 +55,8 @@ SIGNATURES = {
     "lcg_hip_last_placement": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lcg_hip_pool_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "lcg_hip_pool_add_arena_for_test": (C.c_int, [C.c_uint64, C.c_int]),
+    "lcg_hip_placement_tune_for_test": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.c_uint64, C.c_int, C.c_int]),
+    "lcg_hip_last_placement_walk": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
     "lcg_hip_last_ax_mean_us": (C.c_double, []),
     "lcg_hip_last_ax_calls": (C.c_int, []),
     "lcg_hip_last_finisher_steps": (C.c_int, []),

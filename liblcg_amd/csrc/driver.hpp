@@ -372,7 +372,7 @@ struct Workspace {
         if (best < 0) {
             // nothing fits: give one idle smaller vector back and allocate
             for (size_t i = 0; i < c.scratch.size(); i++)
-                if (!c.scratch[i].busy && !c.scratch[i].arena) { (void)hipFree(c.scratch[i].p); c.scratch.erase(c.scratch.begin() + i); c.forget_places(); break; }
+                if (!c.scratch[i].busy && !c.scratch[i].arena) { c.forget_vector(c.scratch[i].p); (void)hipFree(c.scratch[i].p); c.scratch.erase(c.scratch.begin() + i); break; }
             double *p = nullptr;
             HIPCHK(hipMalloc(&p, bytes));
             c.scratch.push_back({p, bytes, false, nullptr});
@@ -419,13 +419,16 @@ struct Placement {
         if (c.place_mode == 0 || afp != (const void *)lcg_hip_csr_ax || inst == nullptr) return false;
         const lcg_hip_csr *A = static_cast<const lcg_hip_csr *>(inst);
         if (A->is_complex || n != A->n_rows || n < 4096) return false;
-        return c.place_mode > 0 || streams(A);
+        return c.place_mode > 0 || streams(c, A);
     }
     // the rows this process multiplies by itself: the whole matrix, or -- sharded -- the entries with locally owned columns
     static const CsrPart &part(const lcg_hip_csr *A) { return A->distributed ? A->loc : A->main; }
     // the effect needs a stream far larger than the 256 MB Infinity Cache: at the 8-way shard size of the 10M-row system (490 MB streamed,
     // 10 MB written) eighteen candidates and a whole walk showed ONE kind of place, 69.9-71.8 us (profiles/r04_placement.txt, section 10)
-    static bool streams(const lcg_hip_csr *A) { return (long)part(A).nnz * 12L >= (768L << 20); }
+    static bool streams(Ctx &c, const lcg_hip_csr *A) { return (size_t)part(A).nnz * 12 >= c.place_tune.stream_min; }
+    // the mean row length the solver's loop hands the product (a shard's local-column part has its own: comm.hip) -- the kernel
+    // shape that is timed here must be the one the loop runs
+    static double mean_of(const lcg_hip_csr *A) { return A->distributed ? (A->n_rows ? (double)A->loc.nnz / A->n_rows : 0.0) : A->mean_row; }
     static float *memo(Ctx &c, const void *val, const double *y)
     {
         for (auto &m : c.place_memo) if (m.val == val && m.y == y) return &m.us;
@@ -441,10 +444,11 @@ struct Placement {
         const CsrPart &P = part(A);
         if (float *m = memo(c, P.val, y)) { *us = *m; return 0; }
         hipEvent_t e0, e1;
-        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-        int rc = spmv_launch(P, false, A->variant, A->mean_row, x, y, false, c.stream, nullptr);
+        if (hipEventCreate(&e0) != hipSuccess) { (void)hipGetLastError(); return LCG_HIP_E_RUNTIME; }
+        if (hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(e0); return LCG_HIP_E_RUNTIME; }
+        int rc = spmv_launch(P, false, A->variant, mean_of(A), x, y, false, c.stream, nullptr);
         if (!rc) rc = hipEventRecord(e0, c.stream) == hipSuccess ? 0 : LCG_HIP_E_RUNTIME;
-        for (int i = 0; i < 2 && !rc; i++) rc = spmv_launch(P, false, A->variant, A->mean_row, x, y, false, c.stream, nullptr);
+        for (int i = 0; i < 2 && !rc; i++) rc = spmv_launch(P, false, A->variant, mean_of(A), x, y, false, c.stream, nullptr);
         if (!rc && (hipEventRecord(e1, c.stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = LCG_HIP_E_RUNTIME;
         float ms = 0.f;
         if (!rc && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = LCG_HIP_E_RUNTIME;
@@ -458,7 +462,19 @@ struct Placement {
     // roles: the solve's work vectors by weight -- the products' outputs (n_out of them) first, then the vector the most frequent
     // product reads, then the rest.  Roles whose vector the caller supplied stay where they are.  x: any n-vector that holds finite
     // numbers (the right-hand side).
+    // Placement is an optimisation: a timing that fails (an event that cannot be made, a trial product that errors) means
+    // "not tried" -- the roles stay as allocated (they are dealt only after the last timing) and the solve goes on.
     static int run(Ctx &c, int n, const void *afp, void *inst, const double *x, Workspace &ws, std::initializer_list<double **> roles, int n_out)
+    {
+        const int rc = run_impl(c, n, afp, inst, x, ws, roles, n_out);
+        if (rc) {
+            if (debug_on()) fprintf(stderr, "[lcg_hip] placement: a timing failed (rc %d: %s): not tried, the vectors stay as allocated\n", rc, c.err.c_str());
+            (void)hipGetLastError();
+            c.place_timed = c.place_moved = 0;
+        }
+        return 0;
+    }
+    static int run_impl(Ctx &c, int n, const void *afp, void *inst, const double *x, Workspace &ws, std::initializer_list<double **> roles, int n_out)
     {
         c.place_timed = c.place_moved = 0; c.place_us_first = c.place_us_chosen = 0.0;
         if (!wanted(c, n, afp, inst)) return 0;
@@ -479,7 +495,7 @@ struct Placement {
             for (auto &s : c.scratch)
                 if (!s.busy && s.bytes >= bytes && (s.arena != nullptr) == (pass == 0) && cand.size() < n_own + 6) cand.push_back({nullptr, s.p, 0.f});
         // the plan of a matrix is built by its first product: not on the clock
-        if (part(A).last_kernel[0] == 0) { int rc = spmv_launch(part(A), false, A->variant, A->mean_row, x, cand[0].p, false, c.stream, nullptr); if (rc) return rc; }
+        if (part(A).last_kernel[0] == 0) { int rc = spmv_launch(part(A), false, A->variant, mean_of(A), x, cand[0].p, false, c.stream, nullptr); if (rc) return rc; }
         {   // What a better place can give is what the written vector costs in the worse one: 60 us per 80 MB (0.75 us per MiB).  Where that is
             // less than 4 % of the product -- the two-pass binned product at 1.75 ms, bands a million columns wide -- the kinds cannot be
             // told apart by the clock and nothing is tried (39 vectors timed and 64 chunks walked for nothing, 0.3 s, before this line).
@@ -504,40 +520,65 @@ struct Placement {
         // Not enough vectors outside the value array's group (or all alike: then nobody knows which kind they are).  What is allocated
         // one after the other lies side by side, so the library walks: chunks of 1 GiB, one after the other and all held, the product
         // timed into the start of every fourth, until one is clearly faster than our slow kind (or, all alike, clearly slower: then
-        // ours are the fast kind) -- at most 128 chunks and 60 ms, never into the last 8 GiB of free memory.  Larger steps
+        // ours are the fast kind) -- within hard bounds (Ctx::PlaceTune: 128 chunks, 60 ms looked at after every allocation, 64 GiB and a quarter
+        // of the free memory held at once, never into the last 8 GiB, not at all on a device somebody else uses).  Larger steps
         // do not get further: an allocation of 4 GiB or more costs 30 ms per GiB, and the allocator serves small requests from near-by
         // memory whatever is held elsewhere.  The fast chunk is KEPT and cut into vectors for this and later solves (one group
         // throughout: a 4 GiB allocation walked in steps of 64 MB never changes class); everything else is given back at once.  One
         // walk per matrix.
         const bool alike = hi < lo * CLASS;
-        if (streams(A) && (alike || n_slow > 0) && memo(c, val, nullptr) == nullptr && bytes <= ((size_t)1 << 28)) {
-            constexpr size_t CH = (size_t)1 << 30;
+        const Ctx::PlaceTune &T = c.place_tune;
+        const size_t CH = T.chunk;
+        bool walk = streams(c, A) && (alike || n_slow > 0 || T.force_find_at >= 0) && memo(c, val, nullptr) == nullptr && bytes <= CH / 4;
+        if (walk && c.mem_total > 0 && c.mem_total - c.mem_free_at_init > T.shared_min) {
+            // somebody else lives on this device (other ranks, another framework's pool): what the walk holds, they cannot have
+            if (debug_on()) fprintf(stderr, "[lcg_hip] placement walk: not made, the device is shared (%.1f GiB were in use when the library was initialised)\n",
+                                    (double)(c.mem_total - c.mem_free_at_init) / 1073741824.0);
+            walk = false;
+        }
+        if (walk) {
             const float ours = alike ? lo : hi;         // the kind to get away from
             std::vector<double *> chunks;
             double *found = nullptr; float found_us = 0.f; int rc = 0;
             // (one of the three groups is a single stretch of 96 GiB: a matrix whose stream lies in it -- a fresh box hands out that
             //  stretch first -- has its nearest better place up to 96 chunks away.  Timing a chunk costs 2 ms: every fourth is timed up to
-            //  the 32nd, every eighth beyond, 128 at most -- and 60 ms, see below.)
+            //  the 32nd, every eighth beyond.)
+            // HARD BOUNDS, each looked at after every single allocation: T.max_chunks chunks; T.wall_ms on the clock (the first chunks
+            // cost 0.5 ms each, those beyond the first few dozen 20 ms -- the driver clears what it hands out); what is held at once --
+            // min(T.hold_max, T.hold_frac x the memory free at the start); never into the last T.keep_free bytes.
             const auto w0 = std::chrono::steady_clock::now();
-            for (int q = 0; q < 128; q++) {
-                size_t fr = 0, tot = 0;
-                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 9 * CH) break;
+            auto elapsed = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count(); };
+            size_t fr0 = 0, tot = 0;
+            c.walks_made++;
+            c.walk_chunks = 0; c.walk_found = 0; c.walk_held = 0; c.walk_end = "chunk limit";
+            if (hipMemGetInfo(&fr0, &tot) != hipSuccess) { (void)hipGetLastError(); fr0 = 0; }
+            const size_t hold_cap = std::min(T.hold_max, (size_t)(T.hold_frac * (double)fr0));
+            int timed_chunks = 0;
+            for (int q = 0; q < T.max_chunks; q++) {
+                if ((chunks.size() + 1) * CH > hold_cap) { c.walk_end = "hold limit"; break; }
+                size_t fr = 0;
+                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < T.keep_free + CH) { (void)hipGetLastError(); c.walk_end = "free-memory floor"; break; }
                 double *p = nullptr;
-                if (hipMalloc(&p, CH) != hipSuccess) { (void)hipGetLastError(); break; }
+                if (hipMalloc(&p, CH) != hipSuccess) { (void)hipGetLastError(); c.walk_end = "allocation refused"; break; }
                 chunks.push_back(p);
+                c.walk_chunks++;
+                c.walk_held = std::max(c.walk_held, chunks.size() * CH);
+                if (elapsed() > T.wall_ms) { c.walk_end = "wall clock"; break; }
                 if (q % (q < 32 ? 4 : 8) != 0) continue;
-                // (the first chunks cost 0.5 ms each, those beyond the first few dozen 20 ms -- the driver clears what it hands out:
-                //  56 chunks took 0.95 s, 128 took 2.6 s.  The walk ends after 60 ms wherever it stands.)
-                if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count() > 60.0) break;
                 float us = 0.f;
                 rc = time_output(c, A, x, p, &us);
-                if (rc) break;
-                if (us * CLASS < ours) { found = p; found_us = us; chunks.pop_back(); break; }
-                if (alike && ours * CLASS < us) break;         // slower than ours: ours are the fast kind, nothing to find
+                if (rc) { c.walk_end = "timing failed"; break; }
+                const bool forced = T.force_find_at >= 0 && timed_chunks == T.force_find_at;
+                timed_chunks++;
+                if (forced || (T.force_find_at < 0 && us * CLASS < ours)) { found = p; found_us = forced ? 0.9f * std::min(us, lo) : us; chunks.pop_back(); c.walk_end = "found"; break; }
+                if (T.force_find_at < 0 && alike && ours * CLASS < us) { c.walk_end = "ours are the fast kind"; break; }     // slower than ours: nothing to find
+                if (elapsed() > T.wall_ms) { c.walk_end = "wall clock"; break; }
             }
-            if (debug_on()) fprintf(stderr, "[lcg_hip] placement walk: %zu chunks of 1 GiB given back, %s (%.1f us against %.1f), %.1f ms\n", chunks.size(),
-                                    found ? "a faster place found and kept" : "nothing faster", found_us, ours,
-                                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+            c.walk_ms = elapsed();
+            c.walk_found = found ? 1 : 0;
+            if (debug_on()) fprintf(stderr, "[lcg_hip] placement walk: %d chunks of %.0f MiB (%zu given back, %.1f GiB held at most), %s (%.1f us against %.1f), "
+                                    "%.1f ms of %.0f allowed, ended by: %s\n", c.walk_chunks, (double)CH / 1048576.0, chunks.size(), (double)c.walk_held / 1073741824.0,
+                                    found ? "a faster place found and kept" : "nothing faster", found_us, ours, c.walk_ms, T.wall_ms, c.walk_end);
             for (double *p : chunks) { (void)hipFree(p); forget_y(c, p); }
             if (rc) { if (found) { (void)hipFree(found); forget_y(c, found); } return rc; }
             if (found) {

@@ -197,6 +197,29 @@ struct Ctx {
     struct PlaceMemo { const void *val; const double *y; float us; };
     std::vector<PlaceMemo> place_memo;
     void forget_places() { place_memo.clear(); }
+    // one vector left the pool: its timings go, the per-matrix "has had its walk" markers (y == nullptr) stay
+    void forget_vector(const double *y)
+    {
+        if (!y) return;
+        for (size_t i = 0; i < place_memo.size();) if (place_memo[i].y == y) place_memo.erase(place_memo.begin() + (long)i); else i++;
+    }
+    // Bounds of the placement's walk (driver.hpp: Placement::run).  Production values; lcg_hip_placement_tune_for_test lowers them so
+    // that the walk, the arenas and their eviction run under -m gpu at a few million rows.
+    struct PlaceTune {
+        size_t stream_min = (size_t)768 << 20;     // a product that streams less shows one kind of place only: nothing is timed
+        size_t chunk = (size_t)1 << 30;            // the walk's step
+        int max_chunks = 128;
+        double wall_ms = 60.0;                     // looked at after EVERY allocation of the walk
+        size_t hold_max = (size_t)64 << 30;        // what a walk may hold at once: this many bytes ...
+        double hold_frac = 0.25;                   // ... and this fraction of the memory that was free when it started
+        size_t keep_free = (size_t)8 << 30;        // never into the last bytes of free memory
+        size_t shared_min = (size_t)4 << 30;       // others held more than this when the library was initialised: the device is shared, no walk
+        int force_find_at = -1;                    // test hook: the k-th TIMED chunk is taken as the faster place whatever the clock says
+    } place_tune;
+    size_t mem_total = 0, mem_free_at_init = 0;    // hipMemGetInfo at ensure_init: total - free = what others (and the host program) held
+    // the latest walk: chunks allocated, wall time, most bytes held at once, 1 = a faster place was kept, why it ended
+    int walks_made = 0;
+    int walk_chunks = 0, walk_found = 0; double walk_ms = 0.0; size_t walk_held = 0; const char *walk_end = "";
     int place_mode = -1;               // lcg_hip_set_placement: -1 auto (large products on one GPU), 0 never, 1 whenever the callback is the built-in one
     int place_timed = 0;               // candidates timed by the latest solve (0: answered from the memo, or not tried)
     int place_moved = 0;               // roles the latest solve moved to another vector

@@ -63,6 +63,7 @@ int ensure_init()
         HIPCHK(hipHostGetDevicePointer((void **)&c.snap_dev[i], c.snap[i], 0));
         HIPCHK(hipEventCreateWithFlags(&c.snap_ev[i], hipEventDisableTiming));
     }
+    if (hipMemGetInfo(&c.mem_free_at_init, &c.mem_total) != hipSuccess) { (void)hipGetLastError(); c.mem_free_at_init = c.mem_total = 0; }
     if (const char *e = std::getenv("LCG_HIP_PLACE")) { const int v = atoi(e); if (v >= -1 && v <= 1 && c.place_mode == -1) c.place_mode = v; }
     c.inited = true;
     return 0;
@@ -273,6 +274,31 @@ int lcg_hip_pool_add_arena_for_test(uint64_t slot_bytes, int slots)
     HIPCHK(hipMalloc(&base, slot * (size_t)slots));
     for (int i = 0; i < slots; i++) c.scratch.push_back({reinterpret_cast<double *>(static_cast<char *>(base) + (size_t)i * slot), slot, false, base});
     return 0;
+}
+int lcg_hip_placement_tune_for_test(uint64_t stream_min_bytes, uint64_t chunk_bytes, int max_chunks, double wall_ms, uint64_t hold_max_bytes,
+                                    int force_find_at, int allow_shared)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    Ctx::PlaceTune t;       // zeros / negatives: the production value
+    if (stream_min_bytes) t.stream_min = (size_t)stream_min_bytes;
+    if (chunk_bytes) t.chunk = ((size_t)chunk_bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    if (max_chunks > 0) t.max_chunks = max_chunks;
+    if (wall_ms > 0.0) t.wall_ms = wall_ms;
+    if (hold_max_bytes) t.hold_max = (size_t)hold_max_bytes;
+    t.force_find_at = force_find_at;
+    if (allow_shared) t.shared_min = ~(size_t)0;
+    ctx().place_tune = t;
+    return 0;
+}
+int lcg_hip_last_placement_walk(int *chunks, double *wall_ms, int64_t *held_bytes, int *found, const char **ended)
+{
+    Ctx &c = ctx();
+    if (chunks) *chunks = c.walk_chunks;
+    if (wall_ms) *wall_ms = c.walk_ms;
+    if (held_bytes) *held_bytes = (int64_t)c.walk_held;
+    if (found) *found = c.walk_found;
+    if (ended) *ended = c.walk_end;
+    return c.walks_made;
 }
 int lcg_hip_set_placement(int mode)
 {

@@ -145,6 +145,14 @@ def test_config2_against_the_oracle_at_full_size(api, port, pattern, band, famil
         assert info.ret == ref["ret"] == -1019 and info.iterations == ref["iters"] == 4, (info.ret, ref["ret"], info.iterations, ref["iters"])
         assert rel <= 1e-10, (name, ad, rel)
         assert abs(info.residual - ref["residual"]) <= 1e-9 * ref["residual"], (ad, info.residual, ref["residual"])
+        # ... and once more the way bench.py times it: the reference's plain call, workspaces left at nullptr (lcg.h:135-137) -- the
+        # library's own vectors, placement AUTOMATIC (roles dealt by the clock, a walk where the box asks for one), the zero-guess skip
+        m2 = torch.zeros_like(xt)
+        info2 = api.lcg("lcg_hip_csr_ax", None, m2, b, n, api.lcg_default_parameters(epsilon=1e-300, abs_diff=ad, max_iterations=4), A)
+        assert info2.ret == -1019 and info2.iterations == 4
+        assert torch.equal(m2, m), (name, ad)           # placement and the pool change no bit
+        assert abs(info2.residual - ref["residual"]) <= 1e-9 * ref["residual"]
+        del m2
     # the product inside the solve was the family's dot-carrying form where it has one
     inside = lib.lcg_hip_csr_last_kernel(A.h).decode()
     assert inside.startswith(family.split(" (")[0]), inside

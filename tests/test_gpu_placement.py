@@ -150,3 +150,135 @@ def test_arena_slots_serve_solves_and_leave_together(api, lib):
         lib.lcg_hip_set_placement(-1)
         api.set_cg_schedule(0)
         A.destroy()
+
+
+def _walk(lib):
+    ch, ms, held, found, why = C.c_int(-1), C.c_double(-1.0), C.c_int64(-1), C.c_int(-1), C.c_char_p()
+    made = lib.lcg_hip_last_placement_walk(C.byref(ch), C.byref(ms), C.byref(held), C.byref(found), C.byref(why))
+    return made, ch.value, ms.value, held.value, found.value, (why.value or b"").decode()
+
+
+MB = 1 << 20
+
+
+def test_the_walk_its_arenas_and_its_bounds(api, lib, port):
+    """driver.hpp: Placement::run, the part automatic mode reaches only from 768 MB of stream: chunks allocated one after the other,
+    the product timed into every fourth, the chunk found kept as an arena and cut into work vectors, a second and a third matrix,
+    the idle arena evicted, lcg_hip_trim.  The test hook lowers the thresholds (64 MB chunks, 256 MB of stream) and takes the second
+    timed chunk as the faster place, so the whole path runs at 2M rows whatever this box's memory looks like.  Iterates: bit-identical
+    (SHA-256) to placement off, and those are the oracle's (lcg.cpp:206-264 restated) at 1e-10.  Then the hard bounds, one by one."""
+    from oracle import pyoracle as po
+    n, cap = 2_000_000, 6
+    para = api.lcg_default_parameters(epsilon=1e-300, abs_diff=1, max_iterations=cap)
+    systems = []
+    api.set_cg_schedule(1)
+    try:
+        assert lib.lcg_hip_set_placement(0) == 0 and lib.lcg_hip_trim() == 0
+        for seed in (3, 4, 5):
+            A = api.CsrMatrix.generate(n, 16, 65536, True, seed, 0.01, pattern=api.GEN_DIAGONALS)
+            assert A.nnz * 12 > 700 * MB
+            xt = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, seed, 0, n, xt)
+            b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
+            m = torch.zeros(n, dtype=torch.float64, device="cuda")
+            info = api.lcg("lcg_hip_csr_ax", None, m, b, n, para, A)          # the reference's plain call: library-owned work vectors
+            assert (info.ret, info.iterations) == (-1019, cap) and _last(lib)[:2] == (0, 0)
+            systems.append((A, b, _sha(m)))
+            if seed == 3:
+                rp, ci, v = A.arrays_to_host()
+                o = port.solve(po.LCG_CG, rp, ci, v, b.cpu().numpy(), para=po.default_para(epsilon=1e-300, abs_diff=1, max_iterations=cap), threads=8)
+                assert o["iters"] == cap and np.linalg.norm(m.cpu().numpy() - o["x"]) <= 1e-10 * np.linalg.norm(o["x"])
+                del rp, ci, v
+
+        def solve(k):
+            A, b, _ = systems[k]
+            m = torch.zeros(n, dtype=torch.float64, device="cuda")
+            info = api.lcg("lcg_hip_csr_ax", None, m, b, n, para, A)
+            assert (info.ret, info.iterations) == (-1019, cap)
+            return _sha(m)
+
+        assert lib.lcg_hip_trim() == 0 and _pool(lib) == (0, 0, 0)
+        walks0 = _walk(lib)[0]
+        # automatic mode, thresholds lowered: stream >= 256 MB, chunks of 64 MB, <= 24 of them, 2 s, <= 1 GiB held, 2nd timed chunk = found
+        assert lib.lcg_hip_placement_tune_for_test(256 * MB, 64 * MB, 24, 2000.0, 1024 * MB, 1, 1) == 0
+        assert lib.lcg_hip_set_placement(-1) == 0
+        assert solve(0) == systems[0][2]
+        made, chunks, ms, held, found, why = _walk(lib)
+        assert made == walks0 + 1 and found == 1 and why == "found", (made, chunks, found, why)
+        assert chunks == 5 and held == 5 * 64 * MB and 0 < ms <= 2000.0      # chunks 0 and 4 are timed; 0..4 were held at once
+        timed, moved, us0, us1 = _last(lib)
+        assert timed >= 5 and moved >= 1 and us1 < us0          # three own vectors + two chunks; the roles moved into the arena
+        vecs, _, slots = _pool(lib)
+        assert slots == 4 and vecs == 3 + 4                     # a 64 MB chunk holds four 16 MB vectors
+        # the same matrix again: from memory, no second walk
+        assert solve(0) == systems[0][2]
+        assert _last(lib)[0] == 0 and _walk(lib)[0] == walks0 + 1
+        # a second matrix walks for itself: a second arena
+        assert solve(1) == systems[1][2]
+        assert _walk(lib)[0] == walks0 + 2 and _walk(lib)[4] == 1 and _pool(lib)[2] == 8
+        # a third: two arenas at most -- the older idle one is evicted (its slots leave the pool and the memory)
+        assert solve(2) == systems[2][2]
+        assert _walk(lib)[0] == walks0 + 3 and _pool(lib)[2] == 8
+        # every system still solves to the same bits, whichever arena its memory pointed into
+        for k in (0, 1, 2, 0):
+            assert solve(k) == systems[k][2]
+        assert _pool(lib)[2] <= 8
+        assert lib.lcg_hip_trim() == 0 and _pool(lib) == (0, 0, 0)
+        # ---- the bounds, one at a time (the clock decides what is "found" here: force off) ----
+        for tune, check in (
+            ((256 * MB, 64 * MB, 6, 2000.0, 1024 * MB, -1, 1), lambda ch, ms, held, why: ch <= 6 and held <= 6 * 64 * MB),
+            ((256 * MB, 64 * MB, 24, 2000.0, 128 * MB, -1, 1), lambda ch, ms, held, why: ch <= 2 and held <= 128 * MB and why in ("hold limit", "found", "ours are the fast kind")),
+            ((256 * MB, 64 * MB, 24, 0.001, 1024 * MB, -1, 1), lambda ch, ms, held, why: ch == 1 and why == "wall clock"),
+        ):
+            assert lib.lcg_hip_trim() == 0      # (forgets the "has had its walk" marks too)
+            assert lib.lcg_hip_placement_tune_for_test(*tune) == 0
+            before = _walk(lib)[0]
+            assert solve(0) == systems[0][2]
+            made, chunks, ms, held, found, why = _walk(lib)
+            assert made == before + 1 and check(chunks, ms, held, why), (tune, chunks, ms, held, found, why)
+        # production thresholds again: 792 MB streamed is above 768 MB, but a vector of 16 MB shows nothing on the clock of a ~100 us
+        # product ... whatever the rules decide, the bits stay
+        assert lib.lcg_hip_trim() == 0
+        assert lib.lcg_hip_placement_tune_for_test(0, 0, 0, 0.0, 0, -1, 0) == 0
+        assert solve(0) == systems[0][2]
+    finally:
+        lib.lcg_hip_placement_tune_for_test(0, 0, 0, 0.0, 0, -1, 0)
+        lib.lcg_hip_set_placement(-1)
+        api.set_cg_schedule(0)
+        lib.lcg_hip_trim()
+        for A, _, _ in systems:
+            A.destroy()
+
+
+def test_no_walk_on_a_shared_device(tmp_path):
+    """A process that finds the device in use when it initialises the library (here: 6 GiB of the host program's own tensors; in
+    the field: other ranks on the same GPU) times and deals its own vectors but never walks -- what a walk holds, the others cannot have."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import ctypes as C, json, sys, torch
+sys.path.insert(0, %r)
+held = torch.empty(6 << 30, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+from liblcg_amd import _lib, api
+lib = _lib.load()
+MB = 1 << 20
+n = 2_000_000
+assert lib.lcg_hip_placement_tune_for_test(256 * MB, 64 * MB, 24, 2000.0, 1024 * MB, 1, int(sys.argv[1])) == 0
+A = api.CsrMatrix.generate(n, 16, 65536, True, 3, 0.01, pattern=api.GEN_DIAGONALS)
+xt = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 3, 0, n, xt)
+b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
+m = torch.zeros_like(xt)
+api.set_cg_schedule(1)
+info = api.lcg("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=1e-300, abs_diff=1, max_iterations=6), A)
+t = C.c_int(); lib.lcg_hip_last_placement(C.byref(t), None, None, None)
+print(json.dumps({"walks": lib.lcg_hip_last_placement_walk(None, None, None, None, None), "timed": t.value, "its": info.iterations}))
+''' % ROOT
+    out = {}
+    for allow in (0, 1):
+        p = subprocess.run([sys.executable, "-c", code, str(allow)], capture_output=True, text=True, timeout=280, env=dict(os.environ, LCG_HIP_DEBUG="1"))
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+        out[allow] = (json.loads(p.stdout.strip().splitlines()[-1]), p.stderr)
+    assert out[0][0] == {"walks": 0, "timed": out[0][0]["timed"], "its": 6} and out[0][0]["timed"] >= 3 and "the device is shared" in out[0][1]
+    assert out[1][0]["walks"] == 1 and "placement walk: 5 chunks" in out[1][1]
