@@ -86,6 +86,9 @@ def launch_ranks(args, argv):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL and the peer-mapped mailboxes need it on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
     env["LCG_BENCH_T0"] = repr(time.time())                # the children's budget clock starts with the launcher's
+    if args.one_gpu_rehearsal:
+        env["LCG_HIP_RCCL_LIB"] = fake_rccl_path()
+        env.setdefault("FAKE_RCCL_TIMEOUT_S", "30")
     print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     t0 = time.time()
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True, text=True)      # stderr: inherited
@@ -146,6 +149,17 @@ def launch_ranks(args, argv):
     return rc
 
 
+def fake_rccl_path():
+    """tests/fake_rccl/librccl_fake.so (built here if the toolchain is at hand): the stand-in for librccl that lets several ranks share
+    ONE GPU.  Test infrastructure -- only --one-gpu-rehearsal ever points the library at it."""
+    import subprocess
+    d = os.path.join(ROOT, "tests", "fake_rccl")
+    so = os.path.join(d, "librccl_fake.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-C", d])
+    return so
+
+
 def dry_launch(args):
     """The launch rehearsed on CPUs (tests/test_bench_launch.py): every rank joins a gloo group under the launcher's environment and
     rank 0 reports who came.  No GPU call, no library load."""
@@ -196,6 +210,10 @@ def main():
     ap.add_argument("--budget-seconds", type=float, default=540.0,
                     help="wall-clock budget of the whole run: optional parts (exchange configurations beyond the RCCL baseline, variants, "
                          "live counters) are skipped when the clock says they no longer fit; the self-launcher ends its children 60 s after it")
+    ap.add_argument("--one-gpu-rehearsal", action="store_true",
+                    help="REHEARSAL, not a measurement: all N ranks on GPU 0, torch side on gloo, the library's collectives from tests/fake_rccl "
+                         "(the real RCCL refuses two ranks on one device) -- launch_ranks, run_sharded, votes, budget, fallbacks and the line's "
+                         "fields run end to end with N > 1 before an N-GPU node has to")
     ap.add_argument("--dry-launch", action="store_true",
                     help="rehearse the launch only: every rank reports its RANK / LOCAL_RANK / WORLD_SIZE over gloo, no GPU is touched")
     args = ap.parse_args()
@@ -215,11 +233,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     args.gpus = world       # inside a launcher its environment decides
+    one_gpu = args.one_gpu_rehearsal
+    if one_gpu:             # every rank on GPU 0; the library binds the stand-in collectives (also when somebody else's launcher started us)
+        local_rank = 0
+        os.environ.setdefault("LCG_HIP_RCCL_LIB", fake_rccl_path())
+    if os.environ.get("LCG_HIP_LAB") == "1":
+        # the LAB build (closed experiments' knobs compiled in) is for scripts/ only: a bench line must come from the shipped library
+        emit(json.dumps({"metric": "cg_iterations_per_sec", "unit": "iter/s", "value": 0.0, "n_gpus": world,
+                         "error": "LCG_HIP_LAB=1 selects the LAB build of the library: bench.py measures the shipped one only"}))
+        raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     lib = _lib.load()
     rc = lib.lcg_hip_init(local_rank)
     if rc:
         raise SystemExit(f"lcg_hip_init failed: {lib.lcg_hip_last_error().decode()}")
+    tdev = "cpu" if one_gpu else "cuda"        # where the torch-side collectives of this program live (gloo in the rehearsal)
 
     dist = None
     p2p, p2p_why = False, "disabled"
@@ -228,7 +256,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         partition.init_comm_from_torch(lib)
 
     n = args.rows
@@ -247,12 +278,12 @@ def main():
     def allmax(v):
         if dist is None:
             return v
-        t = torch.tensor([v], dtype=torch.float64, device="cuda")
+        t = torch.tensor([v], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def allsum(vals):
-        t = torch.tensor(vals, dtype=torch.float64, device="cuda")
+        t = torch.tensor(vals, dtype=torch.float64, device=tdev if dist is not None else "cuda")
         if dist is not None:
             dist.all_reduce(t)
         return [float(v) for v in t.tolist()]
@@ -363,6 +394,10 @@ def main():
                 lib.lcg_hip_set_profiling(events)
                 self.m.zero_()          # input of the solve (the initial guess), resident before the timed region starts
                 barrier()
+                if os.environ.get("LCG_BENCH_TEST_DIE_RANK") == str(rank):
+                    # test hook (tests/test_gpu_rehearsal.py): this rank dies in the middle of a timed solve -- the others must not hang
+                    import threading
+                    threading.Timer(0.02, lambda: os._exit(17)).start()
                 t0 = time.perf_counter()
                 info = self.solve(steps, fresh=False)
                 api.synchronize()       # this rank's K steps are done (stream drained) ...
@@ -428,7 +463,7 @@ def main():
             times, ax_us, ax_calls = S.timed(args.steps, args.reps, 1)
         else:
             times, ax_us, ax_calls, check, exchange, comm_probe, p2p = run_sharded(args, S, lib, api, partition, dist, torch, n, rank,
-                                                                                  barrier, allmax, allsum, out)
+                                                                                  barrier, allmax, allsum, out, tdev)
     except Exception as exc:        # every rank still leaves a JSON line behind (rank 0 prints it)
         out.update({"value": 0.0, "ms_per_step": None, "error": f"{type(exc).__name__}: {exc}",
                     "config": {"workload": workload_name(args.pattern, args.band, args.npairs, args.solver)}})
@@ -487,7 +522,24 @@ def main():
         out["comm_probe"] = comm_probe
     if sharded:
         out["rccl_ranks"] = int(lib.lcg_hip_comm_size())       # what the library's RCCL communicator spans (not torch's)
+        out["rccl_library"] = lib.lcg_hip_comm_library().decode()
         out["torch_world_size"] = dist.get_world_size()
+    out["library"] = os.path.relpath(_lib.SO_PATH, ROOT)
+    if one_gpu:
+        out["rehearsal"] = (f"{world} ranks on ONE GPU, torch side on gloo, the library's collectives from tests/fake_rccl (HIP-IPC staging buffers + host "
+                            "shared memory): the code path of an N-GPU run end to end -- NO number in this line is a measurement of anything")
+    if not sharded and args.solver == "cg":
+        # the other CG schedule on one GPU too, so that a scaling ratio can be formed schedule by schedule (N > 1 reports both as well)
+        by = {"classic" if not one_red else "one_reduction": round(args.steps / med, 1)}
+        other = "one_reduction" if not one_red else "classic"
+        api.set_cg_schedule(api.CG_ONE_REDUCTION if other == "one_reduction" else api.CG_CLASSIC)
+        try:
+            S.solve(max(1, min(args.warmup, 5)))
+            t_o = S.timed(args.steps, 3, 0)[0]
+            by[other] = round(args.steps / sorted(t_o)[len(t_o) // 2], 1)
+        finally:
+            api.set_cg_schedule({"auto": api.CG_AUTO, "classic": api.CG_CLASSIC, "one-reduction": api.CG_ONE_REDUCTION}[args.cg_schedule])
+        out["value_by_cg_schedule"] = by
 
     if rank == 0 and world == 1 and "roofline" in out:
         # what THIS box's memory system sustains on a plain device copy (1 GiB read + 1 GiB written),
@@ -529,6 +581,10 @@ def main():
             S.solve(k); api.synchronize()
             return S.m.cpu().numpy()
         out["cpu_baseline"] = cpu_baseline(S.A, S.b, n, args, np, gpu_iterate)
+        if out["cpu_baseline"].get("parity_ok") is False:
+            out["error"] = ("the GPU path's iterate differs from the reference's on the same arrays by more than 1e-9 (cpu_baseline.rel_diff_vs_gpu_after_k / "
+                            "_after_4): the throughput below is not a result")
+            out["value_unverified"], out["value"] = out["value"], 0.0
 
     if rank == 0:
         emit(json.dumps(out))
@@ -670,12 +726,33 @@ def pmc_traffic(pattern, kernel, nnz=None):
     return ent.get("hbm_bytes_per_launch"), f"profiles/pmc_summary.json ({summ.get('tag')}, {ent.get('collected', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes')})"
 
 
-def run_sharded(args, S, lib, api, partition, dist, torch, n, rank, barrier, allmax, allsum, out):
+def run_sharded(args, S, lib, api, partition, dist, torch, n, rank, barrier, allmax, allsum, out, tdev="cuda"):
     """N > 1 (or the one-rank rehearsal): baseline first, then every cheaper exchange that reproduces its product."""
+    import ctypes as C
     world = dist.get_world_size()
     A, xt, b = S.A, S.xt, S.b
     labels = {0: "all-gather", 1: "neighbour ranges", 2: "direct peer writes"}
-    bad = torch.zeros(1, dtype=torch.float64, device="cuda")
+    bad = torch.zeros(1, dtype=torch.float64, device=tdev)
+    sched_codes = {"classic": api.CG_CLASSIC, "one_reduction": api.CG_ONE_REDUCTION}
+    sched_now = {"auto": "one_reduction", "classic": "classic", "one-reduction": "one_reduction"}[args.cg_schedule]     # (sharded: auto = one reduction)
+
+    def both_schedules(known_value):
+        """it/s of the CURRENT exchange configuration under both CG schedules (the one the line's value ran is known already): the
+        1 -> N ratio can then be read classic / classic and one-reduction / one-reduction as well as best / best."""
+        res = {sched_now: known_value}
+        if args.solver != "cg":
+            return None
+        for label, code in sched_codes.items():
+            if label in res:
+                continue
+            api.set_cg_schedule(code)
+            try:
+                S.solve(max(1, min(args.warmup, 5)))
+                t = S.timed(args.steps, 3, 0)[0]
+                res[label] = args.steps / sorted(t)[len(t) // 2]
+            finally:
+                api.set_cg_schedule(sched_codes[sched_now])
+        return {k: round(v, 1) for k, v in res.items()}
 
     def anybody(failed):
         bad[0] = 1.0 if failed else 0.0
@@ -708,6 +785,7 @@ def run_sharded(args, S, lib, api, partition, dist, torch, n, rank, barrier, all
     out["value_rccl_allgather"] = args.steps / base_med
     out["ms_per_step_rccl_allgather"] = 1e3 * base_med / args.steps
     tried = {"all-gather + rccl all-reduce": args.steps / base_med}
+    out["value_rccl_allgather_by_cg_schedule"] = both_schedules(args.steps / base_med)
     best = (base_med, 0, False, base_times, base_ax_us, base_ax_calls)
     cost = time.time() - t_phase        # what one configuration costs on this node (plan, guard, timed solves); the dearest seen so far
     skipped = []
@@ -822,6 +900,8 @@ def run_sharded(args, S, lib, api, partition, dist, torch, n, rank, barrier, all
                 lib.lcg_hip_p2p_enable(0)
             attempt(lambda: A.distribute(n, 0), "back to all-gather")
             times, ax_us, ax_calls = base_times, base_ax_us, base_ax_calls
+    out["value_by_cg_schedule"] = (both_schedules(args.steps / sorted(times)[len(times) // 2]) if (mode != 0 or direct_sum)
+                                   else out["value_rccl_allgather_by_cg_schedule"])
     probe = {"configurations_it_per_s": {k: round(v, 1) for k, v in tried.items()},
              "configurations_skipped_for_the_clock": skipped, "seconds_per_configuration": round(cost, 1),
              "chosen": f"{labels[mode]} + {'direct' if direct_sum else 'rccl'} all-reduce",
@@ -842,6 +922,68 @@ def run_sharded(args, S, lib, api, partition, dist, torch, n, rank, barrier, all
             probe[name] = allmax((time.perf_counter() - t0) / reps * 1e6)
     except Exception as exc:
         probe["probe_error"] = str(exc)
+    # ---- where an iteration goes (optional parts, dropped last-in-first-out when the clock is short; every rank votes) --------
+    dropped = []
+
+    def timed_call(call, reps=50):
+        for _ in range(5):
+            call()
+        api.synchronize(); barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call()
+        api.synchronize()
+        return allmax((time.perf_counter() - t0) / reps * 1e6)
+
+    def chk(rc, what):
+        if rc:
+            raise RuntimeError(f"{what}: rc={rc}: {lib.lcg_hip_last_error().decode()}")
+
+    if anybody(time_left(args) < 45.0):
+        dropped.append("iteration_parts")
+    else:
+        try:
+            # the NORTH-STAR configuration is the one taken apart: all-gather of x, RCCL all-reduce of the sums
+            if p2p:
+                lib.lcg_hip_p2p_enable(0)
+            if not attempt(lambda: A.distribute(n, 0), "probe: back to all-gather"):
+                raise RuntimeError("the all-gather exchange could not be set up again")
+            S.solve(max(1, min(args.warmup, 5)))
+            # (a) inside the loop: the K-step solve once more with an event pair around every product
+            tt, ax_in_loop, _calls = S.timed(args.steps, 1, 1)
+            it_us = 1e6 * tt[0] / args.steps
+            v, sc, rr, pr = (C.c_int(0) for _ in range(4))
+            lib.lcg_hip_last_launches(C.byref(v), C.byref(sc), C.byref(rr), C.byref(pr))
+            parts = {"iteration_us": round(it_us, 2), "ax_in_loop_us": round(allmax(ax_in_loop), 2),
+                     "rest_in_loop_us": round(it_us - allmax(ax_in_loop), 2),
+                     "per_iteration": {"vector_passes": round(v.value / args.steps, 2), "scalar_steps": round(sc.value / args.steps, 2),
+                                       "rank_reductions": round(rr.value / args.steps, 2), "products": round(pr.value / args.steps, 2)},
+                     "configuration": "all-gather + rccl all-reduce (the north-star exchange), whatever configuration the line's value ran",
+                     "what": "rest = vector passes + scalar steps + the reductions over ranks; the products' own kernels: roofline.kernel"}
+            # (b) the product's parts alone, back to back (stream-ordered like the product; the exchange is collective)
+            ys = torch.empty_like(xt)
+            for label, m_ in (("all_gather", 0), ("neighbour_ranges", 1)):
+                if attempt(lambda: A.distribute(n, m_), f"probe: exchange mode {m_}"):
+                    parts[f"x_exchange_alone_{label}_us"] = round(timed_call(lambda: chk(lib.lcg_hip_csr_ax_part_for_probe(A.h, xt.data_ptr(), ys.data_ptr(), 1), "exchange probe")), 2)
+                    parts[f"x_exchange_{label}_doubles_received"] = int(lib.lcg_hip_csr_exchange_volume(A.h))
+            parts["local_column_product_alone_us"] = round(timed_call(lambda: chk(lib.lcg_hip_csr_ax_part_for_probe(A.h, xt.data_ptr(), ys.data_ptr(), 2), "local product probe")), 2)
+            parts["remote_column_part_alone_us"] = round(timed_call(lambda: chk(lib.lcg_hip_csr_ax_part_for_probe(A.h, xt.data_ptr(), ys.data_ptr(), 4), "remote part probe")), 2)
+            ex = parts.get("x_exchange_alone_all_gather_us", 0.0)
+            parts["serial_sum_us"] = round(ex + parts["local_column_product_alone_us"] + parts["remote_column_part_alone_us"] + parts["rest_in_loop_us"], 2)
+            parts["overlap_model_us"] = round(max(parts["local_column_product_alone_us"], ex + parts["remote_column_part_alone_us"]) + parts["rest_in_loop_us"], 2)
+            parts["model_note"] = ("serial_sum = exchange + local + remote + rest; overlap_model = max(local, exchange + remote) + rest (the exchange and the "
+                                   "remote part run on the second stream beside the local product); both to be read against iteration_us")
+            probe["iteration_parts"] = parts
+        except Exception as exc:
+            probe["iteration_parts_error"] = f"{type(exc).__name__}: {exc}"
+        # back to the configuration the line reports
+        if p2p:
+            lib.lcg_hip_p2p_enable(1 if (direct_sum or mode == 2) else 0)
+        attempt(lambda: A.distribute(n, mode), "back to the chosen exchange")
+        if p2p and not direct_sum:
+            lib.lcg_hip_p2p_enable(0)
+        attempt(lambda: (A.spmv(xt, torch.empty_like(xt)), api.synchronize()), "a product under the chosen exchange")    # (the handle names its kernel again)
+    probe["parts_dropped_for_the_clock"] = dropped
     return times, ax_us, ax_calls, check, labels[mode], probe, (p2p and (direct_sum or mode == 2))
 
 
@@ -896,6 +1038,15 @@ def cpu_baseline(A, b, n, args, np, gpu_iterate=None):
                                           "max_abs": float(np.max(np.abs(xg - kept["x"]))),
                                           "what": f"|x_gpu - x_{kind}| / |x_{kind}| after the same {kept['iters']} {args.solver.upper()} iterations from m = 0 on the same arrays"}
         del xg
+        # the same after FOUR iterations (far from the fixed point both sides end at: a wrong coefficient shows at 1e-1 here)
+        _, r4 = run(4, team)
+        if r4["iters"] == 4:
+            x4 = gpu_iterate(4)
+            n4 = float(np.linalg.norm(r4["x"]))
+            out["rel_diff_vs_gpu_after_4"] = float(np.linalg.norm(x4 - r4["x"]) / n4) if n4 > 0 else None
+            del x4
+        worst = max(v for v in (out["rel_diff_vs_gpu_after_k"]["rel_l2"], out.get("rel_diff_vs_gpu_after_4")) if v is not None)
+        out["parity_ok"] = bool(worst <= 1e-9)      # main() fails the line on False: a fast iterate that is not the reference's is no result
     kept.clear()
     if team > 1:        # all entitled cores AND one
         i1, t1 = sample(1, args.cpu_seconds / 3)

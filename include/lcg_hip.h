@@ -116,6 +116,13 @@ double lcg_hip_last_residual(void);
 int    lcg_hip_set_profiling(int on);
 double lcg_hip_last_ax_mean_us(void);
 int    lcg_hip_last_ax_calls(void);
+/* (With the built-in product the solve's SET-UP product y = A.m0 -- lcg.cpp:168, 314, 476, 648 -- carries no event pair and is not
+ * counted: whether it is made at all is decided on the device (an all-zero guess needs none), so the figures above are about the
+ * products of the iterations.  One consequence for matrices with Inf / NaN ENTRIES: the reference's A.0 already poisons g with
+ * 0 x Inf = NaN before the loop, here the first NaN appears one product later -- LCG_NAN_VALUE is returned either way.) */
+/* What the latest solve enqueued: vector passes, scalar steps (a step that sums over ranks counts once), reductions over ranks, A.x
+ * callbacks (the set-up product included).  Any pointer may be NULL.  bench.py divides by the iterations: launches per iteration. */
+int    lcg_hip_last_launches(int *vector_passes, int *scalar_steps, int *rank_reductions, int *products);
 /* Always 0.  (Round 3 counted here the scalar steps that ran in the last block of a sharded product -- an opt-in experiment that
  * measured no gain, DESIGN 9, and was retired in round 4; the entry stays so that the library's exports do not change.) */
 int    lcg_hip_last_finisher_steps(void);
@@ -432,6 +439,10 @@ int lcg_hip_p2p_disconnect(void);
  * (lcg_hip_csr_xfull) itself and then calls lcg_hip_spmv. */
 int lcg_hip_csr_split_for_test(lcg_hip_csr_t A, int64_t n_global, int nranks, int rank);
 double *lcg_hip_csr_xfull(lcg_hip_csr_t A);
+/* Measurement hook: ONE PART of a sharded product alone (stream-ordered like the product; collective for part 1) -- 1: the x exchange
+ * of modes 0 / 1 on the second stream, fork and join included; 2: the local-column product; 4: the remote-column part out of whatever
+ * the gather buffer holds.  bench.py's comm_probe times them so that a multi-GPU line says where an iteration goes. */
+int lcg_hip_csr_ax_part_for_probe(lcg_hip_csr_t A, const double *x, double *y, int part);
 /* After split_for_test and after filling the gather buffer: run the direct exchange (mode 2) with
  * this rank standing in for its neighbours -- the real kernel chain (pushing blocks in the A.x grid,
  * flags, waiting remote-column product) on one GPU, with the true product as result. */

@@ -59,6 +59,7 @@ SIGNATURES = {
     "lcg_hip_last_placement_walk": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
     "lcg_hip_last_ax_mean_us": (C.c_double, []),
     "lcg_hip_last_ax_calls": (C.c_int, []),
+    "lcg_hip_last_launches": (C.c_int, [c_int_p, c_int_p, c_int_p, c_int_p]),
     "lcg_hip_last_finisher_steps": (C.c_int, []),
     "lcg_hip_trim": (C.c_int, []),
     "lcg_hip_solver": (C.c_int, [vp, vp, vp, vp, C.c_int, C.POINTER(LcgPara), vp, C.c_int, C.c_int]),
@@ -131,6 +132,7 @@ SIGNATURES = {
     "lcg_hip_p2p_disconnect": (C.c_int, []),
     "lcg_hip_csr_split_for_test": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int]),
     "lcg_hip_csr_xfull": (vp, [vp]),
+    "lcg_hip_csr_ax_part_for_probe": (C.c_int, [vp, vp, vp, C.c_int]),
     "lcg_hip_csr_local_nnz": (C.c_int64, [vp]),
     "lcg_hip_csr_exchange_volume": (C.c_int64, [vp]),
     "lcg_hip_csr_need_ranges_for_test": (C.c_int, [vp, C.c_int, vp]),

@@ -862,6 +862,21 @@ static int remote_sums_launch(lcg_hip_csr *A, const double *xfull, double *out, 
     return 0;
 }
 
+// The x exchange of modes 0 and 1 on stream s: the neighbour ranges (grouped ncclSend / ncclRecv straight into the gather buffer at
+// their global offsets), or this rank's slice copied into its place in the gather buffer and ncclAllGather in place.
+static int exchange_x(lcg_hip_csr *A, const double *x, hipStream_t s)
+{
+    const size_t w = A->is_complex ? 2 : 1;
+    if (g_comm.comm && A->dist_mode == 1 && A->halo) return halo_exchange(A, x, s);    // (the local product reads x itself)
+    double *mine = A->xfull + w * (size_t)(A->row0);
+    HIPCHK(hipMemcpyAsync(mine, x, sizeof(double) * w * (size_t)A->n_rows, hipMemcpyDeviceToDevice, s));
+    if (g_comm.comm) {
+        ncclResult_t r = g_comm.AllGather(mine, A->xfull, w * (size_t)A->rows_per_rank, ncclDouble, g_comm.comm, s);
+        if (r != ncclSuccess) return comm_fail("ncclAllGather", r);
+    }
+    return 0;
+}
+
 // u != nullptr: the product also leaves y.u as partial sums in part[0 .. *slots) -- the local product's (folded to <= 512), then one per
 // block of the remote-column kernel.  *fused says whether it did (when not, the plain product was made).
 static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const double *u, double *part, int *slots, bool *fused)
@@ -870,7 +885,6 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
     if (fused) *fused = false;
     bool dot = u != nullptr && !A->is_complex;
     int nslot = 0;
-    const size_t w = A->is_complex ? 2 : 1;
     const int *done = ax_flag(c);
     if (A->dist_mode < 0) {
         c.err = "this matrix's exchange could not be set up (lcg_hip_csr_distribute failed): distribute it again under another mode";
@@ -976,23 +990,12 @@ static int dist_spmv_impl(lcg_hip_csr *A, const double *x, double *y, const doub
         if (dot) { *slots = nslot; *fused = true; }
         return 0;
     }
-    double *mine = A->xfull + w * (size_t)(A->row0);
     // gather on the second stream ...
     HIPCHK(hipEventRecord(c.ev_a, c.stream));
     HIPCHK(hipStreamWaitEvent(c.comm_stream, c.ev_a, 0));
-    if (g_comm.comm && A->dist_mode == 1 && A->halo) {
-        // neighbour exchange: only the ranges the remote columns touch (the local product reads x itself)
-        int rc = halo_exchange(A, x, c.comm_stream);
-        if (rc) return rc;
-    } else {
-        HIPCHK(hipMemcpyAsync(mine, x, sizeof(double) * w * (size_t)A->n_rows, hipMemcpyDeviceToDevice, c.comm_stream));
-        if (g_comm.comm) {
-            ncclResult_t r = g_comm.AllGather(mine, A->xfull, w * (size_t)A->rows_per_rank, ncclDouble, g_comm.comm, c.comm_stream);
-            if (r != ncclSuccess) return comm_fail("ncclAllGather", r);
-        }
-    }
+    int rc = exchange_x(A, x, c.comm_stream);
+    if (rc) return rc;
     // ... followed there by the product of the remote columns (few rows: their sums go to rem_y) ...
-    int rc = 0;
     if (A->remc.n_rows > 0) {
         rc = remote_sums_launch(A, A->xfull, A->rem_y, c.comm_stream, done);
         if (rc) return rc;
@@ -1076,6 +1079,31 @@ int lcg_hip_comm_init(int nranks, int rank, const void *id128)
     if (r != ncclSuccess) { g_comm.comm = nullptr; return comm_fail("ncclCommInitRank", r); }
     g_comm.nranks = nranks; g_comm.rank = rank;
     g_comm.force = std::getenv("LCG_HIP_FORCE_COMM") != nullptr;
+    // Do two ranks of this job sit on one device?  (The real RCCL refuses that; a stand-in bound through LCG_HIP_RCCL_LIB does not.)  The
+    // ranks' device UUIDs meet in the communicator's first all-gather; a rank that shares its device makes no placement walks
+    // (driver.hpp) -- what a walk holds, the rank next door cannot have.
+    if (nranks > 1) {
+        Ctx &c = ctx();
+        hipUUID id;
+        std::memset(&id, 0, sizeof id);
+        static_assert(sizeof(hipUUID) == 16, "device UUID size");
+        if (hipDeviceGetUuid(&id, c.device) != hipSuccess) { (void)hipGetLastError(); std::memset(&id, 0, sizeof id); }
+        char *d = nullptr;
+        HIPCHK(hipMalloc(&d, 16 * (size_t)nranks));
+        std::vector<char> all(16 * (size_t)nranks);
+        hipError_t e = hipMemcpyAsync(d + 16 * (size_t)rank, &id, 16, hipMemcpyHostToDevice, c.stream);
+        if (e == hipSuccess) {
+            r = g_comm.AllGather(d + 16 * (size_t)rank, d, 16, ncclChar, g_comm.comm, c.stream);
+            if (r != ncclSuccess) { hipFree(d); return comm_fail("ncclAllGather (device identities)", r); }
+            e = hipMemcpyAsync(all.data(), d, all.size(), hipMemcpyDeviceToHost, c.stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+        hipFree(d);
+        if (e != hipSuccess) return fail(e, "device identities", __FILE__, __LINE__);
+        for (int q = 0; q < nranks; q++)
+            if (q != rank && std::memcmp(&all[16 * (size_t)q], &id, 16) == 0) c.ranks_share_device = true;
+        if (c.ranks_share_device && debug_on()) std::fprintf(stderr, "[lcg_hip] rank %d shares its device with another rank of the communicator\n", rank);
+    }
     return 0;
 }
 
@@ -1199,6 +1227,44 @@ int lcg_hip_csr_direct_selfloop_for_test(lcg_hip_csr_t A, int nranks, int rank)
     HIPCHK(hipStreamSynchronize(c.stream));
     A->dist_mode = 2;
     return 0;
+}
+// Measurement hook (bench.py: comm_probe): ONE PART of a sharded product alone, on the streams the product itself uses, so that a
+// multi-GPU line can say where an iteration's time goes.  part 1: the x exchange of modes 0 / 1 (second stream, fork and join
+// included); 2: the local-column product (the kernel the loop runs, no dot carried); 4: the remote-column part (sums of the rows that
+// hold remote columns out of whatever the gather buffer holds, and their addition to y).  Collective for part 1.
+int lcg_hip_csr_ax_part_for_probe(lcg_hip_csr_t A, const double *x, double *y, int part)
+{
+    if (!A || !A->distributed || !x || !y) return LCG_HIP_E_ARG;
+    Ctx &c = ctx();
+    const int *done = nullptr;
+    if (part == 1) {
+        if (A->dist_mode != 0 && A->dist_mode != 1) { c.err = "the direct exchange rides in the product's own grid: it has no part to time alone"; return LCG_HIP_E_ARG; }
+        HIPCHK(hipEventRecord(c.ev_a, c.stream));
+        HIPCHK(hipStreamWaitEvent(c.comm_stream, c.ev_a, 0));
+        int rc = exchange_x(A, x, c.comm_stream);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c.ev_b, c.comm_stream));
+        HIPCHK(hipStreamWaitEvent(c.stream, c.ev_b, 0));
+        return 0;
+    }
+    if (part == 2) {
+        const double mean_l = A->n_rows ? (double)A->loc.nnz / A->n_rows : 0.0;
+        return spmv_launch(A->loc, A->is_complex, A->variant, mean_l, x, y, false, c.stream, done);
+    }
+    if (part == 4) {
+        if (A->remc.n_rows <= 0) return 0;
+        int rc = remote_sums_launch(A, A->xfull, A->rem_y, c.stream, done);
+        if (rc) return rc;
+        const unsigned g = (unsigned)((A->remc.n_rows + VB - 1) / VB);
+        if (A->is_complex)
+            hipLaunchKernelGGL((k_scatter_add<double2>), dim3(g), dim3(VB), 0, c.stream, A->remc.n_rows, A->rem_rows,
+                               reinterpret_cast<const double2 *>(A->rem_y), reinterpret_cast<double2 *>(y), done);
+        else
+            hipLaunchKernelGGL((k_scatter_add<double>), dim3(g), dim3(VB), 0, c.stream, A->remc.n_rows, A->rem_rows, A->rem_y, y, done);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    return LCG_HIP_E_ARG;
 }
 double *lcg_hip_csr_xfull(lcg_hip_csr_t A) { return A ? A->xfull : nullptr; }
 int64_t lcg_hip_csr_local_nnz(lcg_hip_csr_t A) { return A ? A->loc.nnz : 0; }
@@ -1325,6 +1391,22 @@ int lcg_hip_p2p_selftest(int rounds)
             g_xg.enabled = false;
             return LCG_HIP_E_COMM;
         }
+    }
+    // the same question as at lcg_hip_comm_init, for jobs that only have the mailboxes: do two ranks sit on one device?
+    if (P > 1) {
+        hipUUID id;
+        std::memset(&id, 0, sizeof id);
+        if (hipDeviceGetUuid(&id, c.device) != hipSuccess) { (void)hipGetLastError(); std::memset(&id, 0, sizeof id); }
+        unsigned long long w[2];
+        std::memcpy(w, &id, 16);
+        std::vector<unsigned long long> all;
+        const bool was = g_xg.enabled;
+        g_xg.enabled = true;        // (xg_allgather_words goes through xg_box)
+        int rc2 = xg_allgather_words(w, 2, all);
+        g_xg.enabled = was;
+        if (rc2) return rc2;
+        for (int q = 0; q < P; q++)
+            if (q != me && all[2 * (size_t)q] == w[0] && all[2 * (size_t)q + 1] == w[1]) c.ranks_share_device = true;
     }
     return 0;
 }

@@ -370,6 +370,26 @@ bool ranges_chosen(const CsrPart &P, hipStream_t s)
             else i++;
     }
     if (runs.size() < 2) return false;
+    if (mode < 0) {
+        // A split pays where some stretch takes ANOTHER family than the row blocks -- the tiled product (class 1: >= 512K rows and 4M
+        // entries), the binned product (class 2: >= 1M rows and 4M entries, below), long rows -- or where a few wide blocks (a span of
+        // 2^21 columns or more) cost the whole matrix its packed columns while a structured stretch alone would get them.  Where every
+        // stretch ends in row-block kernels anyway and the whole matrix can be packed, one launch over all rows is faster than one per
+        // stretch: 1M rows, 800K of constant diagonals + 200K scattered, 103.5 us packed whole against 115.9 us in two ranges
+        // (profiles/r04_choice_regret.txt, second table: 12 % regret).
+        bool other = false;
+        for (const Run &r : runs) {
+            const long rows = (long)(std::min(nb, r.c1 * BPC) - r.c0 * BPC) * PK_R;
+            if (r.k == 3) other = true;
+            if (r.k == 2 && r.ent >= (double)(1 << 22) && rows >= (1L << 20)) other = true;
+            if (r.k == 1 && r.ent >= (double)(1 << 22) && rows >= (1L << 19)) other = true;
+        }
+        if (!other) {
+            bool wide = false;
+            for (int b = 0; b < nb && !wide; b++) wide = hb[RG_ST * (size_t)b] >= (1u << 21);
+            if (!wide) return false;
+        }
+    }
     // The cuts, to the 64-row block: inside the two chunks that meet at a cut the boundary goes where the fewest blocks end up on
     // the side of the other class (one wide block inside a structured range would cost that whole range its packed columns).
     std::vector<int> cutb(runs.size() + 1);          // in blocks

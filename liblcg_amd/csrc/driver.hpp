@@ -34,7 +34,8 @@ struct Driver {
     bool user_cb = false;
 
     Driver(Ctx &c_, long n_, bool cplx_, int max_it_, double eps_, int abs_diff_)
-        : c(c_), n(n_), cplx(cplx_), max_it(max_it_), abs_diff(abs_diff_), eps(eps_) { c.in_solve = true; c.ax_rc = 0; }
+        : c(c_), n(n_), cplx(cplx_), max_it(max_it_), abs_diff(abs_diff_), eps(eps_)
+    { c.in_solve = true; c.ax_rc = 0; c.cnt_vec = c.cnt_scal = c.cnt_allreduce = c.cnt_ax = 0; }
     ~Driver() { c.in_solve = false; }
     Driver(const Driver &) = delete;
 
@@ -62,6 +63,7 @@ struct Driver {
         const bool v2 = cplx || ((align_or & 15) == 0);
         const long items = cplx ? n : (v2 ? (n + 1) / 2 : n);
         const int g = grid_for(items);
+        c.cnt_vec++;
         op.st = c.state;        // the state of THIS launch (vecf below moves it between the buffers of a pair)
         if (cplx) {
             hipLaunchKernelGGL((k_vec<Op, false>), dim3(g), dim3(VB), 0, c.stream, op, n, c.partials);
@@ -84,6 +86,7 @@ struct Driver {
             int rc = scal(fin);
             return rc ? rc : vec(op, align_or);
         }
+        c.cnt_vec++;        // (the scalar step rides in this pass: no launch of its own)
         const bool v2 = !cplx && (align_or & 15) == 0;      // complex passes take one 16-byte element per lane (vec_n)
         const int g = grid_for(v2 ? (n + 1) / 2 : n);
         DevState *cur = c.state, *next = c.state == c.state_pair[0] ? c.state_pair[1] : c.state_pair[0];
@@ -123,6 +126,8 @@ struct Driver {
     {
         const PartCount g = pcnt;
         XgBox xb;
+        c.cnt_scal++;
+        if (comm_active() && Fin::NR > 0) c.cnt_allreduce++;       // (RCCL all-reduce between two launches, or the mailboxes inside one)
         if (snap_to) snap_taken++;
         if (comm_active() && Fin::NR > 0 && xg_box(&xb)) {
             // reduce + exchange over the peer mailboxes + scalar step in one launch
@@ -174,6 +179,7 @@ struct Driver {
     // solve here with that LCG_HIP_E_* code instead of letting the loop run on over a stale product.
     template <class F> int timed_ax(F &&call)
     {
+        c.cnt_ax++;
         if (c.profile && (c.ax_seq++ % c.profile_every) == 0 && c.prof_used + 2 <= (int)c.prof_ev.size()) {
             HIPCHK(hipEventRecord(c.prof_ev[c.prof_used], c.stream));
             call();
@@ -530,9 +536,10 @@ struct Placement {
         const Ctx::PlaceTune &T = c.place_tune;
         const size_t CH = T.chunk;
         bool walk = streams(c, A) && (alike || n_slow > 0 || T.force_find_at >= 0) && memo(c, val, nullptr) == nullptr && bytes <= CH / 4;
-        if (walk && c.mem_total > 0 && c.mem_total - c.mem_free_at_init > T.shared_min) {
+        if (walk && T.shared_min != ~(size_t)0 && (c.ranks_share_device || (c.mem_total > 0 && c.mem_total - c.mem_free_at_init > T.shared_min))) {
             // somebody else lives on this device (other ranks, another framework's pool): what the walk holds, they cannot have
-            if (debug_on()) fprintf(stderr, "[lcg_hip] placement walk: not made, the device is shared (%.1f GiB were in use when the library was initialised)\n",
+            if (debug_on()) fprintf(stderr, "[lcg_hip] placement walk: not made, the device is shared (%s; %.1f GiB were in use when the library was initialised)\n",
+                                    c.ranks_share_device ? "another rank of this job sits on it" : "memory in use by others",
                                     (double)(c.mem_total - c.mem_free_at_init) / 1073741824.0);
             walk = false;
         }

@@ -216,8 +216,12 @@ struct Ctx {
         size_t shared_min = (size_t)4 << 30;       // others held more than this when the library was initialised: the device is shared, no walk
         int force_find_at = -1;                    // test hook: the k-th TIMED chunk is taken as the faster place whatever the clock says
     } place_tune;
+    bool ranks_share_device = false;               // two ranks of the communicator / of the mailboxes sit on this device (comm.hip: found at connect time)
     size_t mem_total = 0, mem_free_at_init = 0;    // hipMemGetInfo at ensure_init: total - free = what others (and the host program) held
     // the latest walk: chunks allocated, wall time, most bytes held at once, 1 = a faster place was kept, why it ended
+    // what the latest solve enqueued: vector passes, scalar steps (a step that sums over ranks is one step, whatever it launches),
+    // reductions over ranks (RCCL or mailboxes), products (lcg_hip_last_launches)
+    int cnt_vec = 0, cnt_scal = 0, cnt_allreduce = 0, cnt_ax = 0;
     int walks_made = 0;
     int walk_chunks = 0, walk_found = 0; double walk_ms = 0.0; size_t walk_held = 0; const char *walk_end = "";
     int place_mode = -1;               // lcg_hip_set_placement: -1 auto (large products on one GPU), 0 never, 1 whenever the callback is the built-in one

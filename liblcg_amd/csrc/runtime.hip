@@ -316,6 +316,15 @@ int lcg_hip_last_placement(int *timed, int *moved, double *us_as_allocated, doub
     return 0;
 }
 int lcg_hip_last_ax_calls(void) { return ctx().last_ax_calls; }
+int lcg_hip_last_launches(int *vector_passes, int *scalar_steps, int *rank_reductions, int *products)
+{
+    Ctx &c = ctx();
+    if (vector_passes) *vector_passes = c.cnt_vec;
+    if (scalar_steps) *scalar_steps = c.cnt_scal;
+    if (rank_reductions) *rank_reductions = c.cnt_allreduce;
+    if (products) *products = c.cnt_ax;
+    return 0;
+}
 int lcg_hip_last_finisher_steps(void) { return 0; }      // (the experiment it counted is retired: lcg_hip.h)
 
 int lcg_hip_set_cg_schedule(int schedule)

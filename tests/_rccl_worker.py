@@ -37,6 +37,9 @@ def main(ref_dir, out_path):
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("LCG_RCCL_WATCHDOG_S"):       # a rank that is still here then says where it stands (all threads) before the test ends it
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["LCG_RCCL_WATCHDOG_S"]), exit=False)
     lib = _lib.load()
     assert lib.lcg_hip_init(0) == 0
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -47,9 +50,12 @@ def main(ref_dir, out_path):
     res = {"rank": rank, "library": lib.lcg_hip_comm_library().decode()}
     verbose = bool(os.environ.get("LCG_RCCL_VERBOSE"))
 
+    import time
+    t_start = time.time()
+
     def say(*a):
         if verbose:
-            print(f"[rank {rank}]", *a, file=sys.stderr, flush=True)
+            print(f"[rank {rank} +{time.time() - t_start:7.2f}s]", *a, file=sys.stderr, flush=True)
 
     def worst_rowwise(y, want, bound):
         return float(np.max(np.abs(y - want) / bound)) if len(want) else 0.0
@@ -73,9 +79,12 @@ def main(ref_dir, out_path):
         tag, n, band, sym, pattern = case["tag"], case["n"], case["band"], case["sym"], case["pattern"]
         r0, r1 = partition.shard_range(n, world, rank)
         nloc = r1 - r0
+        say(tag, "generating rows", r0, r1)
         A = api.CsrMatrix.generate(n, 16, band, sym, case["seed"], 0.01, r0, r1, pattern=pattern)
         if sym:
             A.build_jacobi()
+        api.synchronize()
+        say(tag, "generated")
         x1 = torch.from_numpy(np.array(ref[f"{tag}/x1"][r0:r1])).cuda()
         x2 = torch.from_numpy(np.array(ref[f"{tag}/x2"][r0:r1])).cuda()
         y = torch.empty_like(x1)
@@ -83,6 +92,7 @@ def main(ref_dir, out_path):
         products = {}
         for mode in (0, 1):
             A.distribute(n, mode)
+            say(tag, "distributed, mode", mode)
             for which, setter in (("packed", lib.lcg_hip_csr_set_packed), ("tiled", lib.lcg_hip_csr_set_tiled)):
                 if case.get("force") == which:      # small systems: drive the kernel family the full-size system selects by itself
                     assert setter(A.h, 1) == 0
@@ -111,6 +121,7 @@ def main(ref_dir, out_path):
                     base = name.split("_")[0]
                     xo = ref[f"{tag}/{base}4_oracle"][r0:r1]
                     xs = ref[f"{tag}/{base}4_single"][r0:r1]
+                    say(tag, mode, name, ad, "done")
                     res[f"{tag}/m{mode}/{name}4/ad{ad}"] = [int(info.ret), int(info.iterations), rel_max(m.cpu().numpy(), xo), rel_max(m.cpu().numpy(), xs),
                                                             float(info.residual)]
                     if mode == 1 or case.get("big"):

@@ -8,19 +8,23 @@
 //
 // What it keeps of the real calls (the properties the library's code depends on):
 //   * stream order: every call only ENQUEUES work on the caller's stream and returns; data is moved by copies and kernels on that
-//     stream, the ranks meet in host functions (hipLaunchHostFunc) that sit in the stream between them;
+//     stream, the ranks meet in one-block kernels that sit in the stream between them (each rank writes its arrival word into every
+//     peer's control block -- uncached device memory mapped through HIP IPC -- and polls its own; the first form, host functions
+//     meeting in host shared memory, stalled once in a few hundred solves with nobody waiting: the runtime's callback thread);
 //   * the same call sequence on every rank of a communicator: collectives carry a signature (kind, count, type, sequence number)
 //     that the ranks compare when they meet -- a mismatch is reported and aborts the communicator (the real library would hang);
 //   * in-place all-gather (sendbuff == recvbuff + rank * count), all-reduce in place;
 //   * point-to-point calls synchronise only the pairs involved (an empty group is no operation at all);
-//   * a peer that never arrives ends the wait after FAKE_RCCL_TIMEOUT_S (30) seconds: the communicator is aborted, every later
-//     call returns ncclRemoteError (the real library leaves that to its watchdog / the launcher).
+//   * a peer that never arrives ends the wait after FAKE_RCCL_TIMEOUT_S (30) seconds (the device's wall clock): the communicator is
+//     aborted on every rank, every later call returns ncclRemoteError (the real library leaves that to its watchdog / the launcher).
 // What it does not model: links, rings, trees, channels, CU occupancy of the collective kernels, and bandwidth.  Nothing measured
 // through it is a performance number.
 //
-// Transport: every rank owns one staging buffer in device memory (FAKE_RCCL_STAGING_MB, 256), exported by HIP IPC through a
-// POSIX shared-memory block named in the ncclUniqueId.  A sender copies into its own staging buffer; receivers copy out of the
-// senders' (mapped) buffers; a second meeting releases the buffer.  Sums are added in rank order (identical bits on every rank).
+// Transport: every rank owns one staging buffer in device memory (2 x FAKE_RCCL_STAGING_MB, 256: one area for the collectives,
+// one for point-to-point messages), exported by HIP IPC through a
+// POSIX shared-memory block named in the ncclUniqueId (used at init and destroy only).  A sender copies into its own staging buffer;
+// receivers copy out of the senders' (mapped) buffers; a second meeting releases the buffer.  Sums are added in rank order
+// (identical bits on every rank).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -41,24 +45,23 @@
 namespace {
 
 constexpr int MAXP = 16;
-constexpr int RING = 256;
 constexpr uint32_t MAGIC = 0x46524343u;     // "FRCC"
 
-struct Slot {
-    std::atomic<uint64_t> arrive[2];
-    std::atomic<uint64_t> sig[MAXP];
+// control block of one rank: uncached device memory, written by the peers (one writer per word), polled by the owner
+struct Ctl {
+    unsigned long long arrive[2][MAXP];     // [phase][src]: number of the last collective src has reached (+1)
+    unsigned long long sig[MAXP];           // [src]: signature of src's current collective
+    unsigned long long sent[MAXP];          // [src]: messages src has staged for me
+    unsigned long long consumed[MAXP];      // [dst]: messages of mine dst has copied out
+    unsigned long long abort_flag;          // anybody: the communicator is dead
 };
 
 struct Shm {
     std::atomic<uint32_t> magic;
     std::atomic<int> attached, detached, abort_flag;
     std::atomic<int> handle_ready[MAXP];
-    hipIpcMemHandle_t staging[MAXP];
+    hipIpcMemHandle_t staging[MAXP], ctl[MAXP];
     uint64_t staging_bytes[MAXP];
-    Slot ring[RING];
-    std::atomic<uint64_t> sent[MAXP][MAXP];         // [src][dst]: messages src has staged for dst
-    std::atomic<uint64_t> consumed[MAXP][MAXP];     // [src][dst]: messages dst has copied out
-    std::atomic<uint64_t> ops_total;                // statistics (rank 0 counts)
 };
 
 struct Pending { bool send; const void *sbuf; void *rbuf; size_t bytes; int peer; };
@@ -71,6 +74,8 @@ struct ncclComm {
     char *staging = nullptr;
     size_t staging_bytes = 0;
     char *peer[MAXP] = {nullptr};
+    Ctl *ctl = nullptr, *peer_ctl[MAXP] = {nullptr};
+    int *status = nullptr, *status_dev = nullptr;      // host-mapped: 0 fine, 1 time-out, 2 call sequence mismatch, 3 a peer aborted; [1..3]: details
     std::vector<void *> opened;
     uint64_t seq = 0;                   // collectives enqueued so far (same on every rank)
     uint64_t nsent[MAXP] = {0}, nrecv[MAXP] = {0};
@@ -135,37 +140,89 @@ bool wait_until(ncclComm *c, F pred, const char *what)
     return true;
 }
 
-// ---- meetings of all ranks (collectives) -----------------------------------------------------------
-struct Meet { ncclComm *c; uint64_t seq; int phase; uint64_t sig; const char *what; };
+// ---- meetings on the device -------------------------------------------------------------------------
+struct SyncArgs { Ctl *mine; Ctl *peer[MAXP]; int P, me; long long timeout_ticks; int *status; };
 
-void meet_fn(void *p)
+__device__ __forceinline__ void word_store(unsigned long long *w, unsigned long long v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned long long word_load(const unsigned long long *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// poll one word of my own control block; false = gave up (time-out or abort), with the reason in status[]
+__device__ bool spin_ge(const SyncArgs &a, const unsigned long long *w, unsigned long long want, int code_detail)
 {
-    Meet *m = static_cast<Meet *>(p);
-    ncclComm *c = m->c;
-    if (!c->async_err.load()) {
-        Slot &s = c->shm->ring[m->seq % RING];
-        const uint64_t target = (uint64_t)c->P * (m->seq / RING + 1);
-        if (m->phase == 0) s.sig[c->me].store(m->sig);
-        s.arrive[m->phase].fetch_add(1);
-        const bool ok = wait_until(c, [&] { return s.arrive[m->phase].load(std::memory_order_acquire) >= target; }, m->what);
-        if (ok && m->phase == 0)
-            for (int q = 0; q < c->P; q++)
-                if (s.sig[q].load() != m->sig) {
-                    char buf[200];
-                    std::snprintf(buf, sizeof buf, "collective #%llu (%s): rank %d issued another call (signature %llx, mine %llx)",
-                                  (unsigned long long)m->seq, m->what, q, (unsigned long long)s.sig[q].load(), (unsigned long long)m->sig);
-                    comm_abort(c, buf);
-                    break;
-                }
+    const long long t0 = wall_clock64();
+    for (;;) {
+        if (word_load(w) >= want) return true;
+        if (word_load(&a.mine->abort_flag) != 0) { if (atomicCAS(a.status, 0, 3) == 0) a.status[1] = code_detail; return false; }
+        if (wall_clock64() - t0 > a.timeout_ticks) {
+            if (atomicCAS(a.status, 0, 1) == 0) a.status[1] = code_detail;
+            for (int q = 0; q < a.P; q++) word_store(&a.peer[q]->abort_flag, 1ull);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(16);
     }
-    delete m;
 }
 
-ncclResult_t enqueue_meet(ncclComm *c, hipStream_t s, uint64_t seq, int phase, uint64_t sig, const char *what)
+// all ranks meet: collective number seq, phase 0 (data staged) or 1 (data read); phase 0 also compares the call signatures
+__global__ void k_meet(SyncArgs a, unsigned long long seq, int phase, unsigned long long sig)
 {
-    Meet *m = new Meet{c, seq, phase, sig, what};
-    if (hipLaunchHostFunc(s, meet_fn, m) != hipSuccess) { delete m; return ncclUnhandledCudaError; }
-    return ncclSuccess;
+    const int q = threadIdx.x;
+    if (q >= a.P || *a.status != 0) return;
+    if (phase == 0) word_store(&a.peer[q]->sig[a.me], sig);
+    __atomic_thread_fence(__ATOMIC_RELEASE);        // (what this stream wrote before -- the staging buffer -- is visible before the arrival is)
+    word_store(&a.peer[q]->arrive[phase][a.me], seq + 1);
+    const bool ok = spin_ge(a, &a.mine->arrive[phase][q], seq + 1, (int)(seq & 0x3fffffff));
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (ok && phase == 0 && word_load(&a.mine->sig[q]) != sig) {
+        if (atomicCAS(a.status, 0, 2) == 0) { a.status[1] = (int)(seq & 0x3fffffff); a.status[2] = q; }
+        for (int r = 0; r < a.P; r++) word_store(&a.peer[r]->abort_flag, 1ull);
+    }
+}
+
+struct PairArgs { int n; int peer[MAXP]; unsigned long long want[MAXP]; int kind; };     // kind: 0 wait consumed, 1 post sent, 2 wait sent, 3 post consumed
+
+__global__ void k_pair(SyncArgs a, PairArgs w)
+{
+    const int i = threadIdx.x;
+    if (i >= w.n || *a.status != 0) return;
+    const int q = w.peer[i];
+    switch (w.kind) {
+    case 0: (void)spin_ge(a, &a.mine->consumed[q], w.want[i], -1 - q); break;
+    case 1: __atomic_thread_fence(__ATOMIC_RELEASE); word_store(&a.peer[q]->sent[a.me], w.want[i]); break;
+    case 2: (void)spin_ge(a, &a.mine->sent[q], w.want[i], -100 - q); __atomic_thread_fence(__ATOMIC_ACQUIRE); break;
+    default: __atomic_thread_fence(__ATOMIC_RELEASE); word_store(&a.peer[q]->consumed[a.me], w.want[i]); break;
+    }
+}
+
+SyncArgs sync_args(ncclComm *c)
+{
+    SyncArgs a;
+    a.mine = c->ctl; a.P = c->P; a.me = c->me; a.status = c->status_dev;
+    a.timeout_ticks = (long long)(c->timeout_s * 1e8);      // wall_clock64: 100 MHz
+    for (int q = 0; q < MAXP; q++) a.peer[q] = q < c->P ? c->peer_ctl[q] : nullptr;
+    return a;
+}
+
+// what a kernel of an earlier call left in the status word (asynchronous, like the real library's async error)
+bool failed(ncclComm *c)
+{
+    if (c->async_err.load()) return true;
+    const int st = c->status ? *(volatile int *)c->status : 0;
+    if (st == 0 && !c->shm->abort_flag.load()) return false;
+    if (!c->async_err.exchange((int)ncclRemoteError)) {
+        const int d = c->status ? c->status[1] : 0;
+        if (st == 1 && d >= 0) std::fprintf(stderr, "[fake_rccl rank %d/%d] communicator aborted: collective #%d: a peer did not arrive within %.0f s (it died or fell out of step)\n", c->me, c->P, d, c->timeout_s);
+        else if (st == 1) std::fprintf(stderr, "[fake_rccl rank %d/%d] communicator aborted: %s peer %d: nothing within %.0f s\n", c->me, c->P, d > -100 ? "ncclSend, slot still unread by" : "ncclRecv, nothing sent by", d > -100 ? -1 - d : -100 - d, c->timeout_s);
+        else if (st == 2) std::fprintf(stderr, "[fake_rccl rank %d/%d] communicator aborted: collective #%d: rank %d issued another call (count, type or kind differ)\n", c->me, c->P, d, c->status[2]);
+        else std::fprintf(stderr, "[fake_rccl rank %d/%d] communicator aborted: a peer aborted\n", c->me, c->P);
+    }
+    c->shm->abort_flag.store(1);
+    return true;
+}
+
+ncclResult_t enqueue_meet(ncclComm *c, hipStream_t s, uint64_t seq, int phase, uint64_t sig, const char *)
+{
+    hipLaunchKernelGGL(k_meet, dim3(1), dim3(64), 0, s, sync_args(c), (unsigned long long)seq, phase, (unsigned long long)sig);
+    return hipGetLastError() == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
 }
 
 uint64_t signature(int kind, size_t count, ncclDataType_t t, uint64_t seq)
@@ -208,7 +265,7 @@ ncclResult_t launch_sum(ncclComm *c, ncclDataType_t t, size_t base, void *out, s
 ncclResult_t check(ncclComm *c)
 {
     if (!c || !c->shm) return ncclInvalidArgument;
-    if (c->async_err.load() || c->shm->abort_flag.load()) { c->async_err.store((int)ncclRemoteError); return ncclRemoteError; }
+    if (failed(c)) return ncclRemoteError;
     if (g_group_depth > 0) return ncclInvalidUsage;     // collectives inside a group: not modelled (the library makes none)
     return ncclSuccess;
 }
@@ -217,31 +274,10 @@ ncclResult_t check(ncclComm *c)
 #define NCCLOK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return r_; } while (0)
 
 // ---- point to point ----------------------------------------------------------------------------------
-struct PairWait { ncclComm *c; int n; int peer[MAXP]; uint64_t want[MAXP]; int kind; };    // kind: 0 wait consumed, 1 post sent, 2 wait sent, 3 post consumed
-
-void pair_fn(void *p)
-{
-    PairWait *w = static_cast<PairWait *>(p);
-    ncclComm *c = w->c;
-    Shm *sh = c->shm;
-    if (!c->async_err.load())
-        for (int i = 0; i < w->n; i++) {
-            const int q = w->peer[i];
-            const uint64_t want = w->want[i];
-            switch (w->kind) {
-            case 0: wait_until(c, [&] { return sh->consumed[c->me][q].load(std::memory_order_acquire) >= want; }, "ncclSend (slot still unread)"); break;
-            case 1: sh->sent[c->me][q].store(want, std::memory_order_release); break;
-            case 2: wait_until(c, [&] { return sh->sent[q][c->me].load(std::memory_order_acquire) >= want; }, "ncclRecv (nothing sent)"); break;
-            default: sh->consumed[q][c->me].store(want, std::memory_order_release); break;
-            }
-        }
-    delete w;
-}
-
 ncclResult_t run_group(ncclComm *c, hipStream_t s, std::vector<Pending> &ops)
 {
     if (ops.empty()) return ncclSuccess;
-    if (c->async_err.load() || c->shm->abort_flag.load()) { c->async_err.store((int)ncclRemoteError); return ncclRemoteError; }
+    if (failed(c)) return ncclRemoteError;
     const size_t slot = c->staging_bytes / (size_t)c->P / 256 * 256;
     bool seen_s[MAXP] = {false}, seen_r[MAXP] = {false};
     for (const Pending &o : ops) {
@@ -255,24 +291,25 @@ ncclResult_t run_group(ncclComm *c, hipStream_t s, std::vector<Pending> &ops)
         }
     }
     auto stage = [&](int kind, bool sends) -> ncclResult_t {
-        PairWait *w = new PairWait{c, 0, {0}, {0}, kind};
+        PairArgs w;
+        w.n = 0; w.kind = kind;
         for (const Pending &o : ops)
             if (o.send == sends) {
-                w->peer[w->n] = o.peer;
+                w.peer[w.n] = o.peer;
                 const uint64_t k = sends ? c->nsent[o.peer] : c->nrecv[o.peer];
-                w->want[w->n] = (kind == 0) ? k : k + 1;
-                w->n++;
+                w.want[w.n] = (kind == 0) ? k : k + 1;
+                w.n++;
             }
-        if (w->n == 0) { delete w; return ncclSuccess; }
-        if (hipLaunchHostFunc(s, pair_fn, w) != hipSuccess) { delete w; return ncclUnhandledCudaError; }
-        return ncclSuccess;
+        if (w.n == 0) return ncclSuccess;
+        hipLaunchKernelGGL(k_pair, dim3(1), dim3(64), 0, s, sync_args(c), w);
+        return hipGetLastError() == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
     };
     // sends: my slot for each destination must have been read (previous message), then copy in, then announce
     NCCLOK(stage(0, true));
     for (const Pending &o : ops)
         if (o.send && o.bytes) {
             if (o.peer == c->me) continue;      // self-send: matched with the self-recv below, copied directly
-            HIPOK(hipMemcpyAsync(c->staging + slot * (size_t)o.peer, o.sbuf, o.bytes, hipMemcpyDeviceToDevice, s));
+            HIPOK(hipMemcpyAsync(c->staging + c->staging_bytes + slot * (size_t)o.peer, o.sbuf, o.bytes, hipMemcpyDeviceToDevice, s));
         }
     NCCLOK(stage(1, true));
     // receives: wait for the senders' announcements, copy out, release their slots
@@ -284,7 +321,7 @@ ncclResult_t run_group(ncclComm *c, hipStream_t s, std::vector<Pending> &ops)
                     if (q.send && q.peer == c->me) HIPOK(hipMemcpyAsync(o.rbuf, q.sbuf, o.bytes, hipMemcpyDeviceToDevice, s));
                 continue;
             }
-            HIPOK(hipMemcpyAsync(o.rbuf, c->peer[o.peer] + slot * (size_t)c->me, o.bytes, hipMemcpyDeviceToDevice, s));
+            HIPOK(hipMemcpyAsync(o.rbuf, c->peer[o.peer] + c->staging_bytes + slot * (size_t)c->me, o.bytes, hipMemcpyDeviceToDevice, s));
         }
     NCCLOK(stage(3, false));
     for (const Pending &o : ops) { if (o.send) c->nsent[o.peer]++; else c->nrecv[o.peer]++; }
@@ -314,7 +351,7 @@ ncclResult_t p2p_call(bool send, const void *sbuf, void *rbuf, size_t count, ncc
 extern "C" {
 
 // marker: lets a test assert which library the product bound
-const char *fakeRcclInfo(void) { return "fake_rccl: several ranks per GPU over HIP IPC staging buffers + host shared memory (tests only)"; }
+const char *fakeRcclInfo(void) { return "fake_rccl: several ranks per GPU over HIP IPC staging buffers and peer-written control words (tests only)"; }
 
 ncclResult_t ncclGetUniqueId(ncclUniqueId *id)
 {
@@ -353,13 +390,30 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
         c->shm->abort_flag.store(1);
         for (void *p : c->opened) (void)hipIpcCloseMemHandle(p);
         if (c->staging) (void)hipFree(c->staging);
+        if (c->ctl) (void)hipFree(c->ctl);
+        if (c->status) (void)hipHostFree(c->status);
         munmap(c->shm, sizeof(Shm));
         delete c;
         return r;
     };
-    if (hipMalloc(&c->staging, c->staging_bytes) != hipSuccess) return bail(ncclUnhandledCudaError, "staging buffer allocation");
-    if (hipMemset(c->staging, 0, c->staging_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return bail(ncclUnhandledCudaError, "staging buffer clear");
+    // two areas of staging_bytes each: [0, staging_bytes) for the collectives, [staging_bytes, 2 x) for point-to-point messages (a
+    // slot per destination).  They must not share bytes: a rank may already stage its next all-reduce while a slower peer still
+    // copies the neighbour range addressed to it out of the same buffer (seen as a wrong BiCGStab iterate once in four runs).
+    if (hipMalloc(&c->staging, 2 * c->staging_bytes) != hipSuccess) return bail(ncclUnhandledCudaError, "staging buffer allocation");
+    if (hipMemset(c->staging, 0, 2 * c->staging_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return bail(ncclUnhandledCudaError, "staging buffer clear");
     if (hipIpcGetMemHandle(&c->shm->staging[rank], c->staging) != hipSuccess) return bail(ncclUnhandledCudaError, "hipIpcGetMemHandle");
+    {   // the control block: written by peers while a local kernel polls it -- it must not live in this GPU's L2 as ordinary memory does
+        void *p = nullptr;
+        hipError_t e = hipExtMallocWithFlags(&p, sizeof(Ctl), hipDeviceMallocUncached);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, sizeof(Ctl), hipDeviceMallocFinegrained); }
+        if (e != hipSuccess) return bail(ncclUnhandledCudaError, "control block allocation (uncached / fine-grained device memory)");
+        c->ctl = static_cast<Ctl *>(p);
+        if (hipMemset(c->ctl, 0, sizeof(Ctl)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return bail(ncclUnhandledCudaError, "control block clear");
+        if (hipIpcGetMemHandle(&c->shm->ctl[rank], c->ctl) != hipSuccess) return bail(ncclUnhandledCudaError, "hipIpcGetMemHandle (control block)");
+        if (hipHostMalloc((void **)&c->status, 4 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return bail(ncclUnhandledCudaError, "status word");
+        for (int i = 0; i < 4; i++) c->status[i] = 0;
+        if (hipHostGetDevicePointer((void **)&c->status_dev, c->status, 0) != hipSuccess) return bail(ncclUnhandledCudaError, "status word (device view)");
+    }
     c->shm->staging_bytes[rank] = c->staging_bytes;
     c->shm->magic.store(MAGIC);
     c->shm->handle_ready[rank].store(1, std::memory_order_release);
@@ -368,11 +422,14 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
         if (!wait_until(c, [&] { return c->shm->handle_ready[q].load(std::memory_order_acquire) == 1; }, "ncclCommInitRank (waiting for the peers)"))
             return bail(ncclRemoteError, "a peer never arrived");
         if (c->shm->staging_bytes[q] != c->staging_bytes) return bail(ncclInvalidArgument, "the ranks disagree on FAKE_RCCL_STAGING_MB");
-        if (q == rank) { c->peer[q] = c->staging; continue; }
+        if (q == rank) { c->peer[q] = c->staging; c->peer_ctl[q] = c->ctl; continue; }
         void *p = nullptr;
         if (hipIpcOpenMemHandle(&p, c->shm->staging[q], hipIpcMemLazyEnablePeerAccess) != hipSuccess) return bail(ncclUnhandledCudaError, "hipIpcOpenMemHandle");
         c->opened.push_back(p);
         c->peer[q] = static_cast<char *>(p);
+        if (hipIpcOpenMemHandle(&p, c->shm->ctl[q], hipIpcMemLazyEnablePeerAccess) != hipSuccess) return bail(ncclUnhandledCudaError, "hipIpcOpenMemHandle (control block)");
+        c->opened.push_back(p);
+        c->peer_ctl[q] = static_cast<Ctl *>(p);
     }
     // everybody has mapped the block: its name can go (the mappings keep it alive; nothing is left behind if the ranks are killed)
     if (!wait_until(c, [&] { return c->shm->attached.load() >= nranks; }, "ncclCommInitRank (attach)")) return bail(ncclRemoteError, "a peer never attached");
@@ -391,10 +448,13 @@ ncclResult_t ncclCommDestroy(ncclComm_t c)
                      c->me, c->P, (unsigned long long)c->calls[0], (unsigned long long)c->calls[1], (unsigned long long)c->calls[2],
                      (unsigned long long)c->calls[3], (unsigned long long)c->calls[4], (unsigned long long)c->calls[5]);
     // nobody unmaps a buffer a peer may still read: leave together (or after the time-out, when a peer is gone)
+    (void)failed(c);        // (reports what a kernel left behind, if nobody asked since)
     c->shm->detached.fetch_add(1);
     if (!c->async_err.load()) (void)wait_until(c, [&] { return c->shm->detached.load() >= c->P; }, "ncclCommDestroy");
     for (void *p : c->opened) (void)hipIpcCloseMemHandle(p);
     if (c->staging) (void)hipFree(c->staging);
+    if (c->ctl) (void)hipFree(c->ctl);
+    if (c->status) (void)hipHostFree(c->status);
     munmap(c->shm, sizeof(Shm));
     delete c;
     return ncclSuccess;
@@ -410,6 +470,7 @@ ncclResult_t ncclCommAbort(ncclComm_t c)
 ncclResult_t ncclCommGetAsyncError(ncclComm_t c, ncclResult_t *err)
 {
     if (!c || !err) return ncclInvalidArgument;
+    (void)failed(c);
     *err = (ncclResult_t)c->async_err.load();
     return ncclSuccess;
 }

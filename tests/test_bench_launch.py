@@ -79,7 +79,7 @@ def test_ranks_that_never_exit_are_ended_and_the_result_kept():
 
 
 def test_no_result_inside_the_budget_is_an_error_line():
-    rc, lines, err = _run([sys.executable, BENCH, "--gpus", "2", "--dry-launch", "--budget-seconds", "-55"],
+    rc, lines, err = _run([sys.executable, BENCH, "--gpus", "2", "--dry-launch", "--budget-seconds", "-40"],
                           {"LCG_BENCH_DRY_SLEEP": "600", "LCG_BENCH_DRY_FAIL": "-1", "LCG_BENCH_EXIT_GRACE": "600"})
     # the ranks DID report here (a dry launch always does): the line is kept and flagged; what matters is that the launcher came back
     assert len(lines) == 1 and "launcher_note" in json.loads(lines[0])

@@ -18,6 +18,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -123,25 +124,35 @@ def make_reference(d, cases, port, with_complex, mailbox_case=None, threads=8):
     return meta
 
 
-def run_ranks(tmp_path, ref_dir, world, port_no, timeout=600, extra=None):
-    procs, outs = [], []
+def run_ranks(tmp_path, ref_dir, world, port_no, timeout=240, extra=None):
+    """The ranks as child processes, their output in files (so that a rank that hangs leaves its story behind); a rank that is still
+    running after `timeout` seconds ends the test with everybody's last lines."""
+    procs, outs, errs = [], [], []
+    logdir = os.environ.get("LCG_RCCL_LOGDIR") or str(tmp_path)
+    os.makedirs(logdir, exist_ok=True)
     for r in range(world):
         out = str(tmp_path / f"rccl_{world}_{r}.json")
         outs.append(out)
+        errs.append(os.path.join(logdir, f"world{world}_rank{r}_{port_no}.err"))
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_no),
-                   LCG_HIP_RCCL_LIB=fake_rccl(), FAKE_RCCL_TIMEOUT_S="60", FAKE_RCCL_STATS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra or {}))
+                   LCG_HIP_RCCL_LIB=fake_rccl(), FAKE_RCCL_TIMEOUT_S="60", FAKE_RCCL_STATS="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   LCG_RCCL_VERBOSE="1", LCG_RCCL_WATCHDOG_S=str(max(30, timeout - 30)), **(extra or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_rccl_worker.py"), ref_dir, out],
-                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
-    logs = []
+                                      stdout=subprocess.DEVNULL, stderr=open(errs[-1], "w"), env=env))
+    t_end = time.time() + timeout
+    hung = False
     for p in procs:
         try:
-            so, se = p.communicate(timeout=timeout)
+            p.wait(timeout=max(1.0, t_end - time.time()))
         except subprocess.TimeoutExpired:
-            for q in procs:
+            hung = True
+    if hung:
+        for q in procs:
+            if q.poll() is None:
                 q.kill()
-            raise
-        logs.append(so[-1500:] + se[-3000:])
-    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    logs = [open(e).read()[-4000:] for e in errs]
+    assert not hung, "a rank was still running after %d s:\n" % timeout + "\n-----\n".join(logs)
+    assert all(p.returncode == 0 for p in procs), "\n-----\n".join(logs)
     res = [json.load(open(o)) for o in outs]
     # what the stand-in library itself counted (its closing line on stderr): the collectives really went through it
     import re
@@ -235,7 +246,7 @@ def test_config3_shard_sizes_over_the_collectives(tmp_path, big_ref, world):
     """BASELINE configs[3] at its real size: the 10M-row system (constant diagonals = the headline; row-random band) split over 2
     and 4 processes, all-gather and neighbour ranges, against the oracle at 10M rows."""
     ref_dir, meta = big_ref
-    res = run_ranks(tmp_path, ref_dir, world, 29610 + world, timeout=900)
+    res = run_ranks(tmp_path, ref_dir, world, 29610 + world)
     check_real(res, meta, world)
     for r in res:
         assert "run blocks" in r["diag10m/m0/kernel"], r["diag10m/m0/kernel"]
@@ -247,6 +258,6 @@ def test_eight_way_shard_height_five_ranks(tmp_path, tmp_path_factory, port):
     d = str(tmp_path_factory.mktemp("rccl_ref_8way"))
     cases = ({"tag": "diag8w", "n": 6_250_000, "band": 131072, "sym": True, "pattern": 1, "seed": 1, "big": True},)
     meta = make_reference(d, cases, port, with_complex=False)
-    res = run_ranks(tmp_path, d, 5, 29620, timeout=900)
+    res = run_ranks(tmp_path, d, 5, 29620)
     check_real(res, meta, 5)
     assert all("run blocks" in r["diag8w/m0/kernel"] for r in res)
