@@ -30,9 +30,27 @@ static double span_threshold()
 
 static bool diag_like_measured(const CsrPart &P, hipStream_t s);     // (below)
 static bool line_ratio_measured(const CsrPart &P, hipStream_t s);
+constexpr double TILED_OVER_BINNED = 1.35;      // in units of span_threshold(): up to this mean block span a band is the tiled product's
 static double line_ratio_threshold();
 
 // true when P's products go through the binned format (plan built here on first use)
+// P.mean_span (measured once): false when the measurement failed
+static bool mean_span_measured(const CsrPart &P, hipStream_t s)
+{
+    if (P.mean_span >= 0.0) return true;
+    unsigned long long *d = nullptr, h = 0;
+    const int nb = (P.n_rows + PK_R - 1) / PK_R;
+    bool ok = hipMalloc(&d, sizeof h) == hipSuccess && hipMemsetAsync(d, 0, sizeof h, s) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_span_sum, dim3(nb), dim3(64), 0, s, P.n_rows, P.rowptr, P.col, d);
+        ok = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    }
+    if (d) hipFree(d);
+    if (!ok) { (void)hipGetLastError(); return false; }
+    P.mean_span = (double)h / nb;
+    return true;
+}
+
 bool binned_chosen(const CsrPart &P, hipStream_t s)
 {
     if (P.bn_state != 0) return P.bn_state > 0;
@@ -46,18 +64,7 @@ bool binned_chosen(const CsrPart &P, hipStream_t s)
     if (mode < 0 && P.n_rows < (1 << 19)) { P.bn_state = -1; P.bn_why = "automatic mode: fewer than 512K rows"; return false; }
     PlanTimer timer(P, s);
     if (mode < 0) {
-        if (P.mean_span < 0.0) {
-            unsigned long long *d = nullptr, h = 0;
-            const int nb = (P.n_rows + PK_R - 1) / PK_R;
-            bool ok = hipMalloc(&d, sizeof h) == hipSuccess && hipMemsetAsync(d, 0, sizeof h, s) == hipSuccess;
-            if (ok) {
-                hipLaunchKernelGGL(k_span_sum, dim3(nb), dim3(64), 0, s, P.n_rows, P.rowptr, P.col, d);
-                ok = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-            }
-            if (d) hipFree(d);
-            if (!ok) { (void)hipGetLastError(); P.bn_state = -1; return false; }
-            P.mean_span = (double)h / nb;
-        }
+        if (!mean_span_measured(P, s)) { P.bn_state = -1; return false; }
         // (columns anywhere in a matrix of 1M columns span less than the threshold and are scattered all the same: 243 us binned, 347 tiled,
         //  372 packed at 1M rows)
         if (P.mean_span < span_threshold() && P.mean_span < 0.75 * (double)P.n_cols) {
@@ -68,8 +75,10 @@ bool binned_chosen(const CsrPart &P, hipStream_t s)
         //  W = 1048576 tiled 1768, binned 1683 -- profiles/r04_choice_regret.txt)
         // (a BAND: the span a small part of the width.  Columns anywhere in a matrix of 1-1.5M columns have the same span and are the
         //  binned product's: 226 against 328 us at 1M rows)
-        if (P.mean_span < 2.0 * span_threshold() && 4.0 * P.mean_span <= (double)P.n_cols && tiled_chosen(P, s)) {
-            P.bn_state = -1; P.bn_why = "automatic mode: the tiled product takes it (mean column span below two thresholds)"; return false;
+        // (round 5: the tiled product's time grows with the span -- 1030 us at a span of 0.79M columns, 1790 at 1.57M, N = 1e7 -- and meets the
+        //  binned product's 1640-1700 at about 1.4M: the upper end of this clause went from 2 thresholds to 1.35)
+        if (P.mean_span < TILED_OVER_BINNED * span_threshold() && 4.0 * P.mean_span <= (double)P.n_cols && tiled_chosen(P, s)) {
+            P.bn_state = -1; P.bn_why = "automatic mode: the tiled product takes it (mean column span below 1.35 thresholds)"; return false;
         }
         // wide, but along diagonals (a stencil on a grid with a million points per plane): every diagonal is a contiguous stream of
         // x for the row-block kernels, whatever the distance between the diagonals
@@ -198,9 +207,11 @@ bool tiled_chosen(const CsrPart &P, hipStream_t s)
         if (P.diag_like > 0.5) { P.tl_state = -1; P.tl_why = "automatic mode: the columns run along diagonals (the row-block kernels gather contiguously)"; return false; }
         const bool lr = line_ratio_measured(P, s);
         if (debug_on()) std::fprintf(stderr, "[lcg_hip] tiled choice: diag_like %.3f, line_ratio %.3f\n", P.diag_like, P.line_ratio);
-        // (below 4M rows x is small enough for the caches to help the row blocks: at 1M rows the band of 8192 columns, line ratio 0.24, is
-        //  still theirs -- 103 against 130 us --, the band of 16384, 0.43, is the tiled product's: 99 against 121)
-        const double lr_least = P.n_rows < (1 << 22) ? std::max(0.3, tiled_line_ratio_threshold()) : tiled_line_ratio_threshold();
+        // (a workgroup of the tiled product owns 8192 rows: below ~1.5M rows it cannot fill the 256 CUs and its time stops falling with the
+        //  size -- band of 8192 columns, line ratio 0.24: 144 us at 1M rows against 120 packed, but 150 against 198 at 2M and 278 against 377
+        //  at 4M (profiles/r05_choice_regret.txt; round 4 had drawn this line at 4M rows: 33 % and 38 % lost there).  The band of 16384,
+        //  0.43, is the tiled product's from 1M rows on: 116 against 140.)
+        const double lr_least = P.n_rows < 3 * (1 << 19) ? std::max(0.3, tiled_line_ratio_threshold()) : tiled_line_ratio_threshold();
         if (lr && P.line_ratio < lr_least) {
             P.tl_state = -1; P.tl_why = "automatic mode: neighbouring rows share their cache lines of x (block-structured: the row-block kernels fetch few lines per entry)";
             return false;
@@ -209,6 +220,14 @@ bool tiled_chosen(const CsrPart &P, hipStream_t s)
         // W = 524288, 1052 per pair: tiled 1.01-1.17 ms, binned 1.70; W = 1048576, 527 per pair: tiled 1.96 ms, binned 1.72
         // (a workgroup per 8192 rows: a stretch of 200,000 rows would run on 25 of the 256 CUs)
         if (P.n_rows < (1 << 19)) { P.tl_state = -1; P.tl_why = "automatic mode: fewer than 512K rows"; return false; }
+        // A band as wide as the matrix is no band.  Where x is small (fewer than 1.5M columns: 12 MB, at home in the caches) the row-block
+        // kernels' time stops growing with the width of the band while the tiled product pays for every tile it touches: 1M rows, a mean
+        // block span of 0.39 of the width (the generator's "+-524288"): 231 us tiled against 170 packed; 0.2: 172 against 169; 0.1: 138
+        // against 172.  From 2M columns on the tiled product keeps its lead at every width (235 against 369 at the same band).
+        if (P.n_cols < 3 * (1 << 19) && mean_span_measured(P, s) && P.mean_span > 0.3 * (double)P.n_cols) {
+            P.tl_state = -1; P.tl_why = "automatic mode: the band is as wide as the matrix and x is small (the row-block kernels gather from the caches)";
+            return false;
+        }
         min_fill = tiled_fill_threshold();
     }
     const int rc = tiled_ready(P, s, min_fill);
@@ -308,7 +327,7 @@ bool ranges_chosen(const CsrPart &P, hipStream_t s)
         if (ent <= 0.0 || blocks <= 0.0) return -1;
         if (only_long || dl / ent > 0.5) return 0;
         const double span = span_sum / blocks;
-        if (span >= 2.0 * span_threshold()) return 2;
+        if (span >= TILED_OVER_BINNED * span_threshold()) return 2;
         const double fill = 128.0 * (ent / blocks) / ((span + 8192.0) / 2048.0);
         return fill < tiled_fill_threshold() && span >= (double)(1 << 19) ? 2 : 1;
     };
@@ -348,6 +367,23 @@ bool ranges_chosen(const CsrPart &P, hipStream_t s)
         if (runs.empty() || runs.back().k != cls[c]) runs.push_back({c, c + 1, cls[c], 0.0});
         runs.back().c1 = c + 1; runs.back().ent += cent[c];
     }
+    // A stretch of class 1 too short for the tiled product (it fills the chip from ~1.5M rows) beside a scattered stretch is multiplied WITH
+    // it: the binned product takes any columns, and row-block kernels over columns that wide pay a cache line per gather (4M rows, columns
+    // drawn within 1.5M of the row: the two 524K-row ends -- their spans are clipped by the matrix's edges -- as ranges of their own 802 us,
+    // the whole matrix binned 632: profiles/r05_choice_regret.txt).
+    if (mode < 0) {
+        auto rows_of = [&](const Run &r) { return (long)(std::min(nb, r.c1 * BPC) - r.c0 * BPC) * PK_R; };
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            for (size_t i = 0; i < runs.size(); i++)
+                if (runs[i].k == 1 && rows_of(runs[i]) < 3L * (1L << 19) &&
+                    ((i > 0 && runs[i - 1].k == 2) || (i + 1 < runs.size() && runs[i + 1].k == 2))) { runs[i].k = 2; changed = true; }
+            for (size_t i = 0; i + 1 < runs.size();)
+                if (runs[i].k == runs[i + 1].k) { runs[i].c1 = runs[i + 1].c1; runs[i].ent += runs[i + 1].ent; runs.erase(runs.begin() + (long)i + 1); changed = true; }
+                else i++;
+        }
+    }
     // a stretch with fewer entries than a launch of its own is worth joins its larger neighbour (smallest first)
     const double min_ent = (mode > 0 || only_long) ? 1.0 : (double)(1 << 18);      // (only_long: the few stretches there are stand for the dense rows)
     for (;;) {
@@ -371,18 +407,18 @@ bool ranges_chosen(const CsrPart &P, hipStream_t s)
     }
     if (runs.size() < 2) return false;
     if (mode < 0) {
-        // A split pays where some stretch takes ANOTHER family than the row blocks -- the tiled product (class 1: >= 512K rows and 4M
+        // A split pays where some stretch takes ANOTHER family than the row blocks -- the tiled product (class 1: >= 1.5M rows and 4M
         // entries), the binned product (class 2: >= 1M rows and 4M entries, below), long rows -- or where a few wide blocks (a span of
         // 2^21 columns or more) cost the whole matrix its packed columns while a structured stretch alone would get them.  Where every
         // stretch ends in row-block kernels anyway and the whole matrix can be packed, one launch over all rows is faster than one per
         // stretch: 1M rows, 800K of constant diagonals + 200K scattered, 103.5 us packed whole against 115.9 us in two ranges
-        // (profiles/r04_choice_regret.txt, second table: 12 % regret).
+        // (profiles/r04_choice_regret.txt, second table: 12 % regret); 4M rows, 3.2M + 0.8M: 434 us whole against 525 us (21 %).
         bool other = false;
         for (const Run &r : runs) {
             const long rows = (long)(std::min(nb, r.c1 * BPC) - r.c0 * BPC) * PK_R;
             if (r.k == 3) other = true;
             if (r.k == 2 && r.ent >= (double)(1 << 22) && rows >= (1L << 20)) other = true;
-            if (r.k == 1 && r.ent >= (double)(1 << 22) && rows >= (1L << 19)) other = true;
+            if (r.k == 1 && r.ent >= (double)(1 << 22) && rows >= 3L * (1L << 19)) other = true;    // (the tiled product fills the chip from ~1.5M rows)
         }
         if (!other) {
             bool wide = false;
@@ -442,6 +478,9 @@ bool ranges_chosen(const CsrPart &P, hipStream_t s)
         // (not for a short stretch: 200,000 scattered rows of a 1M-row matrix went from 86 to 176 us per product that way -- the binned
         //  passes launch a workgroup per 8192 columns and a wavefront per 2048 rows)
         if (runs[i].k == 2 && P.bn_mode < 0 && V.nnz >= (1 << 22) && V.n_rows >= (1 << 20)) V.bn_mode = 1;
+        // nor the tiled product: a workgroup per 8192 rows leaves most of the chip idle below ~1.5M rows (a 524K-row stretch at the end of a
+        // 10M-row band took 64 workgroups' time: 2294 us for the whole product against 1790 as ONE tiled product)
+        if (P.tl_mode < 0 && V.n_rows < 3 * (1 << 19)) V.tl_mode = 0;
         if (runs[i].k == 3) V.lr_mode = 1;
         R->parts.push_back(V); R->r0.push_back(r0); R->seen.push_back(nullptr);
     }

@@ -23,6 +23,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=10_000_000)
 ap.add_argument("--reps", type=int, default=8)
 ap.add_argument("--limit", type=float, default=0.10)
+ap.add_argument("--only", default="", help="comma-separated case names (e.g. with LCG_HIP_DEBUG=1: what the rules saw)")
 args = ap.parse_args()
 lib = _lib.load(); assert lib.lcg_hip_init(0) == 0
 api.use_torch_stream()
@@ -113,6 +114,8 @@ print(f"# scripts/choice_regret.py --rows {n} --reps {args.reps}: time per produ
 print(f"# {'matrix':28s} {'rows':>9s} {'entries':>10s} | " + " | ".join(f"{m:>24s}" for m in MODES) + " | regret")
 worst = (0.0, None)
 for name, build in CASES:
+    if args.only and name not in args.only.split(","):
+        continue
     A, rows = build()
     x = torch.rand(rows, dtype=torch.float64, device="cuda"); y = torch.empty_like(x); yref = None
     res = {}

@@ -13,6 +13,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the tests hold the SHIPPED library to the oracle: the LAB build (liblcg_amd/lib/lab, closed experiments' knobs) is for scripts/ only
+    if os.environ.get("LCG_HIP_LAB") == "1":
+        pytest.exit("LCG_HIP_LAB=1 selects the LAB build of liblcg_hip.so: the tests run against the shipped library only", returncode=4)
 
 
 @pytest.fixture(scope="session")

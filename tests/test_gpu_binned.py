@@ -265,3 +265,48 @@ def test_wide_bands_at_full_size_take_the_tiled_product(api, lib):
         A.destroy()
         del x, y, y2
         torch.cuda.empty_cache()
+
+
+def test_choice_rules_below_four_million_rows(api, lib):
+    """The rules scripts/choice_regret.py moved in round 5 (profiles/r05_choice_regret.txt; 12-38 % lost before): (1) at 1M rows a band as
+    wide as the matrix is no band -- x is 8 MB, the packed row blocks gather from the caches (170 us) where the tiled product pays for
+    every tile (231); (2) the tiled product takes the band of 8192 columns from ~1.5M rows on (2M rows: 150 against 198 us), not only
+    from 4M; (3) 800K rows of constant diagonals + 200K scattered rows are ONE packed product (102 us), not two ranges (116).
+    Every choice against the plain row-block kernel's y."""
+    import ctypes as C
+
+    def check(A, n, want, never=()):
+        x = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 1, 0, n, x)
+        y = torch.empty_like(x); y2 = torch.empty_like(x)
+        A.spmv(x, y); api.synchronize()
+        kern = lib.lcg_hip_csr_last_kernel(A.h).decode()
+        assert want in kern and not any(w in kern for w in never), kern
+        assert lib.lcg_hip_csr_set_packed(A.h, 0) == 0 and lib.lcg_hip_csr_set_tiled(A.h, 0) == 0 and lib.lcg_hip_csr_set_binned(A.h, 0) == 0 and lib.lcg_hip_csr_set_ranges(A.h, 0) == 0
+        A.spmv(x, y2); api.synchronize()
+        assert ((y - y2).abs().max() <= 1e-13 * y2.abs().max()).item(), kern
+        A.destroy()
+
+    n = 1_000_000
+    check(api.CsrMatrix.generate(n, 16, 524288, True, 1, 0.01, pattern=api.GEN_ROW_RANDOM_BAND), n, "k_spmv_ldsp", never=("k_tile", "k_bin", "rows ["))
+    check(api.CsrMatrix.generate(n, 16, 131072, True, 1, 0.01, pattern=api.GEN_ROW_RANDOM_BAND), n, "k_tile_spmv")
+    check(api.CsrMatrix.generate(n, 16, 8192, True, 1, 0.01, pattern=api.GEN_ROW_RANDOM_BAND), n, "k_spmv_ldsp", never=("k_tile",))
+    n = 2_000_000
+    check(api.CsrMatrix.generate(n, 16, 8192, True, 1, 0.01, pattern=api.GEN_ROW_RANDOM_BAND), n, "k_tile_spmv")
+    check(api.CsrMatrix.generate(n, 16, 524288, True, 1, 0.01, pattern=api.GEN_ROW_RANDOM_BAND), n, "k_tile_spmv")
+    # 800K rows of constant diagonals above 200K rows with scattered columns (inside their own block)
+    n, n1 = 1_000_000, 800_000
+    parts = []
+    for rows, band, pat, seed in ((n1, 131072, api.GEN_DIAGONALS, 3), (n - n1, 0, api.GEN_SCRAMBLED, 5)):
+        G = api.CsrMatrix.generate(rows, 16, band, True, seed, 0.01, pattern=pat)
+        pr, pc, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        assert lib.lcg_hip_csr_arrays(G.h, C.byref(pr), C.byref(pc), C.byref(pv)) == 0
+        nz = G.nnz
+        rp = torch.empty(rows + 1, dtype=torch.int32, device="cuda"); ci = torch.empty(nz, dtype=torch.int32, device="cuda")
+        vv = torch.empty(nz, dtype=torch.float64, device="cuda")
+        for dst, src in ((rp, pr), (ci, pc), (vv, pv)):
+            assert lib.lcg_hip_memcpy(dst.data_ptr(), src, dst.numel() * dst.element_size(), 3) == 0
+        G.destroy()
+        parts.append((rp, ci, vv))
+    (rp1, c1, v1), (rp2, c2, v2) = parts
+    M = api.CsrMatrix.from_csr(torch.cat([rp1, rp2[1:] + int(rp1[-1].item())]), torch.cat([c1, c2 + n1]), torch.cat([v1, v2]), n_cols=n)
+    check(M, n, "k_spmv_ldsp", never=("rows [",))

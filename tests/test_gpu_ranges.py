@@ -128,12 +128,16 @@ def test_mixed_rows_against_the_oracle(port):
         A.destroy()
 
 
-def test_seven_million_entries_automatic(port):
-    """64^3 stencil rows + 10 % coupled rows (7.8M entries): the automatic mode cuts by itself; A.x against the oracle's product."""
+@pytest.mark.parametrize("grid,cuts", [((64, 64, 64), False), ((128, 128, 128), True)])
+def test_automatic_mode_cuts_only_where_a_cut_pays(port, grid, cuts):
+    """Stencil rows + 10 % coupled rows, automatic mode.  64^3 (7.6M entries, 293K columns): every stretch would end in row-block
+    kernels and the whole matrix can be packed -- ONE product (49 us) beats one per stretch (60 us: scripts/ranges_ab.py), so nothing is cut
+    (round 5; round 4 cut here).  128^3 (61M entries, 2.3M columns): the coupled rows' blocks span 2^21 columns and more, which costs the
+    WHOLE matrix its packed columns (243 us) -- cut, the stencil rows get them back (220 us).  A.x against the oracle's product."""
     from liblcg_amd import _lib, api
     lib = _lib.load()
     rng = np.random.default_rng(64)
-    n, cut, (rp, ci, v) = mixed_system(rng, False, (64, 64, 64))
+    n, cut, (rp, ci, v) = mixed_system(rng, False, grid)
     assert len(ci) >= 4_000_000
     A = api.CsrMatrix.from_csr(rp, ci, v)
     xh = rng.standard_normal(n)
@@ -142,9 +146,12 @@ def test_seven_million_entries_automatic(port):
     first = (C.c_int * 8)()
     nr = lib.lcg_hip_csr_ranges(A.h, 8, first)
     name = lib.lcg_hip_csr_last_kernel(A.h).decode()
-    assert nr == 2 and list(first[:2]) == [0, cut], (nr, list(first[:nr]), cut, name)
-    # (a 64-row block of this grid is one x-line with its two boundary rows: packed columns, no run blocks)
-    assert "rows [0, %d): k_spmv_ldsp (LDS-staged" % cut in name, name
+    if cuts:
+        assert nr == 2 and list(first[:2]) == [0, cut], (nr, list(first[:nr]), cut, name)
+        assert "rows [0, %d): k_spmv_ldsp (LDS-staged" % cut in name, name
+    else:
+        # (a 64-row block of this grid is one x-line with its two boundary rows: template blocks; the coupled rows ride along as packed columns)
+        assert nr == 0 and name.startswith("k_spmv_ldsp (LDS-staged") and "packed columns" in name, (nr, name)
     ref = port.csr_matvec(rp, ci, v, xh)
     bound = port.csr_matvec(rp, ci, np.abs(v), np.abs(xh))
     assert float(np.max(np.abs(y.cpu().numpy() - ref) / bound)) <= 1e-13, name
