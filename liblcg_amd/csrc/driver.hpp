@@ -560,27 +560,46 @@ struct Placement {
             c.walk_chunks = 0; c.walk_found = 0; c.walk_held = 0; c.walk_end = "chunk limit";
             if (hipMemGetInfo(&fr0, &tot) != hipSuccess) { (void)hipGetLastError(); fr0 = 0; }
             const size_t hold_cap = std::min(T.hold_max, (size_t)(T.hold_frac * (double)fr0));
-            int timed_chunks = 0;
+            // THREE kinds of places show on the clock of a product that reads a stream AND gathers x (tiled product, 10M rows: 563 / 605 /
+            // 647 us -- y beside neither, beside x, beside the stream), so the first chunk that beats `ours` is not yet the answer: ours
+            // 647, chunk 609 ended the round-4 walk, and the loop then ran in its slow state (687 us per product against 578 with a 563-us
+            // place: profiles/r05_tiled_states.txt, one process in six).  The walk therefore keeps the BEST chunk it has seen and goes on
+            // for a few timed chunks behind every find; it ends when nothing better has shown in LOOK_ON timed chunks (or at a bound).
+            constexpr int LOOK_ON = 3;
+            int timed_chunks = 0, since_find = 0, slower_seen = 0;
             for (int q = 0; q < T.max_chunks; q++) {
-                if ((chunks.size() + 1) * CH > hold_cap) { c.walk_end = "hold limit"; break; }
+                if ((chunks.size() + 1 + (found ? 1 : 0)) * CH > hold_cap) { c.walk_end = found ? "found" : "hold limit"; break; }
                 size_t fr = 0;
-                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < T.keep_free + CH) { (void)hipGetLastError(); c.walk_end = "free-memory floor"; break; }
+                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < T.keep_free + CH) { (void)hipGetLastError(); c.walk_end = found ? "found" : "free-memory floor"; break; }
                 double *p = nullptr;
-                if (hipMalloc(&p, CH) != hipSuccess) { (void)hipGetLastError(); c.walk_end = "allocation refused"; break; }
+                if (hipMalloc(&p, CH) != hipSuccess) { (void)hipGetLastError(); c.walk_end = found ? "found" : "allocation refused"; break; }
                 chunks.push_back(p);
                 c.walk_chunks++;
-                c.walk_held = std::max(c.walk_held, chunks.size() * CH);
-                if (elapsed() > T.wall_ms) { c.walk_end = "wall clock"; break; }
+                c.walk_held = std::max(c.walk_held, (chunks.size() + (found ? 1 : 0)) * CH);
+                if (elapsed() > T.wall_ms) { c.walk_end = found ? "found" : "wall clock"; break; }
                 if (q % (q < 32 ? 4 : 8) != 0) continue;
                 float us = 0.f;
                 rc = time_output(c, A, x, p, &us);
                 if (rc) { c.walk_end = "timing failed"; break; }
                 const bool forced = T.force_find_at >= 0 && timed_chunks == T.force_find_at;
                 timed_chunks++;
-                if (forced || (T.force_find_at < 0 && us * CLASS < ours)) { found = p; found_us = forced ? 0.9f * std::min(us, lo) : us; chunks.pop_back(); c.walk_end = "found"; break; }
-                if (T.force_find_at < 0 && alike && ours * CLASS < us) { c.walk_end = "ours are the fast kind"; break; }     // slower than ours: nothing to find
-                if (elapsed() > T.wall_ms) { c.walk_end = "wall clock"; break; }
+                if (forced) { found = p; found_us = 0.9f * std::min(us, lo); chunks.pop_back(); c.walk_end = "found"; break; }
+                if (T.force_find_at < 0) {
+                    // a find: clearly faster than the kind to get away from -- or, behind a find, clearly faster than that find
+                    const float bar = found ? found_us : ours;
+                    if (us * CLASS < bar) {
+                        if (found) chunks.insert(chunks.begin(), found);        // (the earlier find goes back with the others)
+                        found = p; found_us = us; chunks.pop_back(); since_find = 0;
+                    } else if (found) {
+                        if (++since_find >= LOOK_ON) { c.walk_end = "found"; break; }
+                    } else if (alike && ours * CLASS < us) {
+                        // slower than ours: ours are not the slowest kind; after LOOK_ON such chunks and none faster, ours are taken for the fast kind
+                        if (++slower_seen >= LOOK_ON) { c.walk_end = "ours are the fast kind"; break; }
+                    }
+                }
+                if (elapsed() > T.wall_ms) { c.walk_end = found ? "found" : "wall clock"; break; }
             }
+            if (found && std::strcmp(c.walk_end, "chunk limit") == 0) c.walk_end = "found";
             c.walk_ms = elapsed();
             c.walk_found = found ? 1 : 0;
             if (debug_on()) fprintf(stderr, "[lcg_hip] placement walk: %d chunks of %.0f MiB (%zu given back, %.1f GiB held at most), %s (%.1f us against %.1f), "
