@@ -357,6 +357,7 @@ def main():
             self.m = torch.zeros_like(self.xt)
             self.scratch = torch.empty_like(self.xt)     # (residual_check's second product; the solvers' work vectors are the library's own)
             self.placement = None
+            self.walks_before = lib.lcg_hip_last_placement_walk(None, None, None, None, None)
             self.nnz_local = self.A.nnz
             self.nnz = int(allsum([self.nnz_local])[0])
 
@@ -385,6 +386,14 @@ def main():
                 lib.lcg_hip_last_placement(C.byref(t), C.byref(mv), C.byref(u0), C.byref(u1))
                 self.placement = {"vectors_timed_in_first_solve": t.value, "roles_moved": mv.value,
                                   "first_output_us_as_allocated": u0.value, "first_output_us_as_placed": u1.value}
+                # the walk this system's first solve made, if it made one (lcg_hip.h: its hard bounds; a walk belongs to the first large
+                # system of a process -- the variants that follow the headline make none)
+                ch, ms, held, found, why = C.c_int(0), C.c_double(0.0), C.c_int64(0), C.c_int(0), C.c_char_p()
+                if lib.lcg_hip_last_placement_walk(C.byref(ch), C.byref(ms), C.byref(held), C.byref(found), C.byref(why)) > self.walks_before:
+                    self.placement["walk"] = {"chunks_of_1GiB": ch.value, "wall_ms": round(ms.value, 2), "held_at_most_GiB": round(held.value / 2**30, 1),
+                                              "kept_a_chunk": bool(found.value), "ended_by": (why.value or b"").decode(), "wall_bound_ms": 60}
+                else:
+                    self.placement["walk"] = None
             return info
 
         def timed(self, steps, reps, events):
@@ -622,6 +631,8 @@ def variants(args, System, S, lib, api, n, spmv_bytes, iteration_bytes):
                  "whole_iteration_algorithmic_GBs": (AX_PER_IT[args.solver] * byts + 8 * BLAS1_WORDS[args.solver] * V.n) / (med / args.steps) / 1e9,
                  "kernel": lib.lcg_hip_csr_last_kernel(V.A.h).decode()}
         entry.update(physical_fractions(lib, V.A, ax_us, pmc_traffic(pattern, entry["kernel"], V.nnz)[0], False))
+        if own:
+            entry["placement"] = V.placement
         if check:
             entry["solution_check"] = check
         res[pattern] = entry

@@ -152,8 +152,12 @@ int    lcg_hip_set_cg_schedule(int schedule);
  * the solve has too few fast vectors, once per matrix: chunks of 1 GiB allocated one after the other until the product into one of
  * them (every fourth, later every eighth, is timed) is clearly faster.  HARD BOUNDS of that walk, each looked at after every single
  * allocation: 128 chunks; 60 ms on the wall clock; at most min(64 GiB, a quarter of the memory that was free when it started) held
- * at once; never into the last 8 GiB of free memory; and no walk at all on a device that is shared (more than 4 GiB were in use by
- * others -- other ranks, the host program's own pool -- when the library was initialised).  The chunk found is kept and cut
+ * at once; never into the last 8 GiB of free memory (the clock is read between calls: another chunk is allocated only while the
+ * time used plus the dearest allocation so far fits the 60 ms; a first chunk that takes more than 5 ms -- a device that clears
+ * what it hands out because all of its memory has been in use since boot -- is the last); no walk at all on a device that is shared (more than 4 GiB were in use by others -- other ranks, the host program's own pool -- when the library was
+ * initialised); and no walk once the library has given back more than 1 GiB in the process's life (matrices destroyed, vectors
+ * trimmed, an earlier walk's chunks): out of recycled memory ONE 1 GiB allocation costs 30 ms .. 0.5 s, which no bound looked at
+ * between calls can hold -- the walk belongs to the first large system of a process.  The chunk found is kept and cut
  * into work vectors (lcg_hip_trim gives it back), the others are given back at once.  A timing that fails means "not tried": the
  * solve goes on with its vectors as allocated.  Roles only: no arithmetic changes, iterates
  * are bit-identical (tests/test_gpu_placement.py).  Results are remembered per (matrix, vector), so later solves time nothing.
@@ -171,12 +175,12 @@ int    lcg_hip_pool_info(int *vectors, int64_t *bytes, int *arena_slots);
 int    lcg_hip_pool_add_arena_for_test(uint64_t slot_bytes, int slots);
 /* Test hook: the walk's bounds (0 / negative = the production value): least streamed bytes for a matrix to be placed at all, chunk
  * size, chunk limit, wall-clock limit, most bytes held; force_find_at >= 0 takes the k-th TIMED chunk as the faster place whatever the
- * clock says (so that arena creation and eviction run deterministically at a few million rows); allow_shared lifts the shared-device
- * rule.  tests/test_gpu_placement.py drives walk -> arena -> second matrix -> eviction -> trim with it. */
+ * clock says (so that arena creation and eviction run deterministically at a few million rows); allow_shared = 1 lifts the shared-device
+ * rule, the fresh-allocator rule and the look-ahead of the clock (a test walks many times in one process), 2 the shared-device rule only.  tests/test_gpu_placement.py drives walk -> arena -> second matrix -> eviction -> trim with it. */
 int    lcg_hip_placement_tune_for_test(uint64_t stream_min_bytes, uint64_t chunk_bytes, int max_chunks, double wall_ms, uint64_t hold_max_bytes,
                                        int force_find_at, int allow_shared);
 /* The latest walk: chunks allocated, its wall time (ms), the most bytes it held at once, whether a place was kept, and which bound or
- * finding ended it ("found", "wall clock", "hold limit", "chunk limit", "free-memory floor", ...).  Any pointer may be NULL.  Returns the
+ * finding ended it ("found", "wall clock", "hold limit", "chunk limit", "free-memory floor", "no fresh memory", ...).  Any pointer may be NULL.  Returns the
  * number of walks this process has made so far. */
 int    lcg_hip_last_placement_walk(int *chunks, double *wall_ms, int64_t *held_bytes, int *found, const char **ended);
 

@@ -1683,6 +1683,7 @@ int lcg_hip_csr_destroy(lcg_hip_csr_t A)
 {
     if (!A) return 0;
     ctx().forget_places();       // (driver.hpp: Placement remembers timings by the value array's address)
+    ctx().released_bytes += (size_t)A->main.nnz * (A->is_complex ? 20 : 12);     // (the plans beside it not counted: the walk's "fresh allocator" rule needs the order of magnitude)
     dist_free(A);
     free_part(A->main);
     for (int i = 1; i < 4; i++) free_part(A->op[i]);

@@ -542,6 +542,13 @@ struct Placement {
                                     c.ranks_share_device ? "another rank of this job sits on it" : "memory in use by others",
                                     (double)(c.mem_total - c.mem_free_at_init) / 1073741824.0);
             walk = false;
+            c.place_memo.push_back({val, nullptr, 0.f});        // (decided once per matrix)
+        }
+        if (walk && T.released_max != ~(size_t)0 && c.released_bytes > T.released_max) {
+            if (debug_on()) fprintf(stderr, "[lcg_hip] placement walk: not made, the library has given back %.1f GiB in this process (allocations out of recycled memory "
+                                    "cost 30-500 ms a call; the walk is for a fresh allocator: the first large system of a process)\n", (double)c.released_bytes / 1073741824.0);
+            walk = false;
+            c.place_memo.push_back({val, nullptr, 0.f});
         }
         if (walk) {
             const float ours = alike ? lo : hi;         // the kind to get away from
@@ -552,7 +559,9 @@ struct Placement {
             //  the 32nd, every eighth beyond.)
             // HARD BOUNDS, each looked at after every single allocation: T.max_chunks chunks; T.wall_ms on the clock (the first chunks
             // cost 0.5 ms each, those beyond the first few dozen 20 ms -- the driver clears what it hands out); what is held at once --
-            // min(T.hold_max, T.hold_frac x the memory free at the start); never into the last T.keep_free bytes.
+            // min(T.hold_max, T.hold_frac x the memory free at the start); never into the last T.keep_free bytes.  (The clock can only
+            // be read BETWEEN calls: another chunk is allocated only while the time used plus the dearest allocation so far stays within
+            // wall_ms, and the walk is not made at all once the allocator recycles what the library released -- Ctx::released_bytes.)
             const auto w0 = std::chrono::steady_clock::now();
             auto elapsed = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count(); };
             size_t fr0 = 0, tot = 0;
@@ -567,16 +576,25 @@ struct Placement {
             // for a few timed chunks behind every find; it ends when nothing better has shown in LOOK_ON timed chunks (or at a bound).
             constexpr int LOOK_ON = 3;
             int timed_chunks = 0, since_find = 0, slower_seen = 0;
+            double alloc_sum = 0.0, alloc_max = 0.0;
             for (int q = 0; q < T.max_chunks; q++) {
                 if ((chunks.size() + 1 + (found ? 1 : 0)) * CH > hold_cap) { c.walk_end = found ? "found" : "hold limit"; break; }
                 size_t fr = 0;
                 if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < T.keep_free + CH) { (void)hipGetLastError(); c.walk_end = found ? "found" : "free-memory floor"; break; }
                 double *p = nullptr;
+                const double a0 = elapsed();
                 if (hipMalloc(&p, CH) != hipSuccess) { (void)hipGetLastError(); c.walk_end = found ? "found" : "allocation refused"; break; }
+                const double a1 = elapsed() - a0;
+                alloc_sum += a1; alloc_max = std::max(alloc_max, a1);
                 chunks.push_back(p);
                 c.walk_chunks++;
                 c.walk_held = std::max(c.walk_held, (chunks.size() + (found ? 1 : 0)) * CH);
-                if (elapsed() > T.wall_ms) { c.walk_end = found ? "found" : "wall clock"; break; }
+                // (the clock is read between calls: the walk goes on only while the time used PLUS its dearest allocation so far fits the
+                //  bound -- out of memory the process has held before a chunk costs 30 ms instead of 0.1-0.5)
+                if (elapsed() + (T.predict ? alloc_max : 0.0) > T.wall_ms) { c.walk_end = found ? "found" : "wall clock"; break; }
+                // (a device whose memory has all been in use since it was booted clears every chunk it hands out, 30 ms per GiB: 128 chunks
+                //  would take 4 s.  The walk pays where allocations are cheap -- freshly provisioned nodes -- and says so after ONE chunk elsewhere.)
+                if (T.predict && q == 0 && a1 > 5.0) { c.walk_end = "no fresh memory"; break; }
                 if (q % (q < 32 ? 4 : 8) != 0) continue;
                 float us = 0.f;
                 rc = time_output(c, A, x, p, &us);
@@ -603,9 +621,9 @@ struct Placement {
             c.walk_ms = elapsed();
             c.walk_found = found ? 1 : 0;
             if (debug_on()) fprintf(stderr, "[lcg_hip] placement walk: %d chunks of %.0f MiB (%zu given back, %.1f GiB held at most), %s (%.1f us against %.1f), "
-                                    "%.1f ms of %.0f allowed, ended by: %s\n", c.walk_chunks, (double)CH / 1048576.0, chunks.size(), (double)c.walk_held / 1073741824.0,
-                                    found ? "a faster place found and kept" : "nothing faster", found_us, ours, c.walk_ms, T.wall_ms, c.walk_end);
-            for (double *p : chunks) { (void)hipFree(p); forget_y(c, p); }
+                                    "%.1f ms of %.0f allowed (allocations %.1f ms, the slowest %.1f), ended by: %s\n", c.walk_chunks, (double)CH / 1048576.0, chunks.size(), (double)c.walk_held / 1073741824.0,
+                                    found ? "a faster place found and kept" : "nothing faster", found_us, ours, c.walk_ms, T.wall_ms, alloc_sum, alloc_max, c.walk_end);
+            for (double *p : chunks) { (void)hipFree(p); forget_y(c, p); c.released_bytes += CH; }
             if (rc) { if (found) { (void)hipFree(found); forget_y(c, found); } return rc; }
             if (found) {
                 // (two arenas at most: an older one that nobody uses goes first)

@@ -214,8 +214,16 @@ struct Ctx {
         double hold_frac = 0.25;                   // ... and this fraction of the memory that was free when it started
         size_t keep_free = (size_t)8 << 30;        // never into the last bytes of free memory
         size_t shared_min = (size_t)4 << 30;       // others held more than this when the library was initialised: the device is shared, no walk
+        bool predict = true;                       // another chunk only while time used + the dearest allocation so far <= wall_ms
+        size_t released_max = (size_t)1 << 30;     // the library has given back more than this in the process's life: no walk (below)
         int force_find_at = -1;                    // test hook: the k-th TIMED chunk is taken as the faster place whatever the clock says
     } place_tune;
+    // What the library has handed back to the device in this process's life (matrices destroyed, pool vectors and arenas trimmed, the
+    // chunks of an earlier walk).  A 1 GiB hipMalloc costs 0.1-0.5 ms out of memory the process has never held and 30 ms .. 0.5 s ONE
+    // CALL once the allocator recycles what was released (bench.py's variants, LCG_HIP_DEBUG=1: walks of 74 / 381 / 528 ms against a
+    // bound of 60 that can only be looked at between calls) -- so the walk is made while the allocator is fresh: in practice once per
+    // process, for its first large system.
+    size_t released_bytes = 0;
     bool ranks_share_device = false;               // two ranks of the communicator / of the mailboxes sit on this device (comm.hip: found at connect time)
     size_t mem_total = 0, mem_free_at_init = 0;    // hipMemGetInfo at ensure_init: total - free = what others (and the host program) held
     // the latest walk: chunks allocated, wall time, most bytes held at once, 1 = a faster place was kept, why it ended

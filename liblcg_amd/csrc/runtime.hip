@@ -249,6 +249,7 @@ int lcg_hip_trim(void)
     for (auto it = c.scratch.begin(); it != c.scratch.end();) {
         if (it->busy || (it->arena && arena_busy(it->arena))) { ++it; continue; }
         if (!it->arena || it->p == it->arena) (void)hipFree(it->p);
+        c.released_bytes += it->bytes;
         it = c.scratch.erase(it);
     }
     c.forget_places();       // (addresses may come back as other memory)
@@ -287,6 +288,7 @@ int lcg_hip_placement_tune_for_test(uint64_t stream_min_bytes, uint64_t chunk_by
     if (hold_max_bytes) t.hold_max = (size_t)hold_max_bytes;
     t.force_find_at = force_find_at;
     if (allow_shared) t.shared_min = ~(size_t)0;
+    if (allow_shared == 1) { t.released_max = ~(size_t)0; t.predict = false; }    // (a test walks many times in one process; 2 keeps the fresh-allocator rule)
     ctx().place_tune = t;
     return 0;
 }

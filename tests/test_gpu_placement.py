@@ -282,3 +282,42 @@ print(json.dumps({"walks": lib.lcg_hip_last_placement_walk(None, None, None, Non
         out[allow] = (json.loads(p.stdout.strip().splitlines()[-1]), p.stderr)
     assert out[0][0] == {"walks": 0, "timed": out[0][0]["timed"], "its": 6} and out[0][0]["timed"] >= 3 and "the device is shared" in out[0][1]
     assert out[1][0]["walks"] == 1 and "placement walk: 5 chunks" in out[1][1]
+
+
+def test_no_walk_once_the_library_has_given_memory_back():
+    """The walk is for a fresh allocator: a 1 GiB hipMalloc out of memory that was released before costs 30 ms .. 0.5 s a call (bench.py's
+    variants under LCG_HIP_DEBUG=1: walks of 74 / 381 / 528 ms against a bound of 60 that can only be looked at between calls).  So the
+    first large system of a process may walk; after the library has given back more than 1 GiB (matrices destroyed, vectors trimmed, the
+    walk's own chunks) a later system times and deals its vectors but allocates nothing to look for a better place."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import ctypes as C, json, sys, torch
+sys.path.insert(0, %r)
+from liblcg_amd import _lib, api
+lib = _lib.load()
+MB = 1 << 20
+n = 2_000_000
+assert lib.lcg_hip_placement_tune_for_test(256 * MB, 64 * MB, 24, 2000.0, 1024 * MB, 1, 2) == 0      # (2: the fresh-allocator rule stays)
+api.set_cg_schedule(1)
+para = api.lcg_default_parameters(epsilon=1e-300, abs_diff=1, max_iterations=6)
+walks = []
+for seed in (3, 4, 5):
+    A = api.CsrMatrix.generate(n, 16, 65536, True, seed, 0.01, pattern=api.GEN_DIAGONALS)
+    xt = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, seed, 0, n, xt)
+    b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
+    m = torch.zeros_like(xt)
+    info = api.lcg("lcg_hip_csr_ax", None, m, b, n, para, A)
+    assert info.iterations == 6
+    walks.append(lib.lcg_hip_last_placement_walk(None, None, None, None, None))
+    A.destroy()         # ~0.8 GiB of CSR arrays given back per system
+print(json.dumps({"walks": walks}))
+''' % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280, env=dict(os.environ, LCG_HIP_DEBUG="1"))
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    walks = json.loads(p.stdout.strip().splitlines()[-1])["walks"]
+    # the first system walks; the second may (0.8 GiB + five 64 MB chunks given back: at the limit); the third must not
+    assert walks[0] == 1 and walks[2] == walks[1] <= 2 and "the library has given back" in p.stderr, (walks, p.stderr[-2000:])
