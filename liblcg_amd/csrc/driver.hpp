@@ -557,8 +557,8 @@ struct Placement {
             // (one of the three groups is a single stretch of 96 GiB: a matrix whose stream lies in it -- a fresh box hands out that
             //  stretch first -- has its nearest better place up to 96 chunks away.  Timing a chunk costs 2 ms: every fourth is timed up to
             //  the 32nd, every eighth beyond.)
-            // HARD BOUNDS, each looked at after every single allocation: T.max_chunks chunks; T.wall_ms on the clock (the first chunks
-            // cost 0.5 ms each, those beyond the first few dozen 20 ms -- the driver clears what it hands out); what is held at once --
+            // HARD BOUNDS, each looked at after every single allocation: T.max_chunks chunks; T.wall_ms on the clock (a chunk costs
+            // 0.02-0.5 ms out of memory nobody has held since the node was provisioned, 30 ms once the driver has to clear it); what is held at once --
             // min(T.hold_max, T.hold_frac x the memory free at the start); never into the last T.keep_free bytes.  (The clock can only
             // be read BETWEEN calls: another chunk is allocated only while the time used plus the dearest allocation so far stays within
             // wall_ms, and the walk is not made at all once the allocator recycles what the library released -- Ctx::released_bytes.)
