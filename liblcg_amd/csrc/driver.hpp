@@ -624,7 +624,7 @@ struct Placement {
                                     "%.1f ms of %.0f allowed (allocations %.1f ms, the slowest %.1f), ended by: %s\n", c.walk_chunks, (double)CH / 1048576.0, chunks.size(), (double)c.walk_held / 1073741824.0,
                                     found ? "a faster place found and kept" : "nothing faster", found_us, ours, c.walk_ms, T.wall_ms, alloc_sum, alloc_max, c.walk_end);
             for (double *p : chunks) { (void)hipFree(p); forget_y(c, p); c.released_bytes += CH; }
-            if (rc) { if (found) { (void)hipFree(found); forget_y(c, found); } return rc; }
+            if (rc) { if (found) { (void)hipFree(found); forget_y(c, found); c.released_bytes += CH; } return rc; }
             if (found) {
                 // (two arenas at most: an older one that nobody uses goes first)
                 for (;;) {
@@ -646,6 +646,7 @@ struct Placement {
                         if (cand[i].role == nullptr && gone) cand.erase(cand.begin() + (long)i); else i++;
                     }
                     (void)hipFree(victim);
+                    c.released_bytes += CH;
                 }
                 // the chunk as an arena of the pool: slots of the vector's size (2 MiB-aligned), as many as the solve has roles + 2
                 const size_t slot = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);

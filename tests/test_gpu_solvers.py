@@ -445,3 +445,51 @@ def test_initial_guess_and_the_product_that_is_not_made(api, port, case10k, gues
         assert np.linalg.norm(x - ref["x"]) <= 1e-12 * np.linalg.norm(ref["x"]), (guess, sid)
         assert abs(info.residual - ref["residual"]) <= 1e-9 * ref["residual"]
     A.destroy()
+
+
+def test_complex_solvers_beyond_one_grid_stride(api, port):
+    """The bundled complex systems have 10^3 / 10^4 rows: every vector pass is one grid stride of <= 40 workgroups and every
+    product a few dozen blocks.  Here 360,000 rows -- a damped 2-D Helmholtz operator, 5-point Laplacian + (0.3 + 0.8i) I: complex
+    symmetric, every eigenvalue off the real axis -- so that the passes walk several strides of the 512-workgroup grid, the partial
+    sums fill their table and the product runs on thousands of blocks.  A.x and A^H.x row-wise against the oracle's products at
+    1e-13 |A||x|; twelve capped iterations of BiCG-sym, BiCG (adjoint product), CGS, BiCGStab and TFQMR against the oracle's loops
+    (clcg.cpp:228-881 restated) with the same shadow residual; BiCG-sym to convergence against the oracle's converged run."""
+    from oracle import pyoracle as po
+    nx = 600
+    n = nx * nx
+    idx = np.arange(n, dtype=np.int64)
+    ix, iy = idx % nx, idx // nx
+    rows, cols, vals = [idx], [idx], [np.full(n, 4.0 + 0.3 + 0.8j, dtype=np.complex128)]
+    for ok, off in ((ix > 0, -1), (ix < nx - 1, 1), (iy > 0, -nx), (iy < nx - 1, nx)):
+        rows.append(idx[ok]); cols.append(idx[ok] + off); vals.append(np.full(int(ok.sum()), -1.0 + 0.0j, dtype=np.complex128))
+    row = np.concatenate(rows).astype(np.int32); col = np.concatenate(cols).astype(np.int32); val = np.concatenate(vals)
+    order = np.lexsort((col, row))
+    row, col, val = row[order], col[order], val[order]
+    rp = np.zeros(n + 1, dtype=np.int32); np.add.at(rp, row + 1, 1); rp = np.cumsum(rp).astype(np.int32)
+    A = api.CsrMatrix.from_csr(rp, col, val)
+    rng = np.random.default_rng(11)
+    xt = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    # products
+    xd = torch.from_numpy(xt).cuda(); yd = torch.empty_like(xd)
+    A.spmv(xd, yd); api.synchronize()
+    ref = port.csr_matvec(rp, col, val, xt)
+    bound = port.csr_matvec(rp, col, np.abs(val).astype(np.complex128), np.abs(xt).astype(np.complex128)).real
+    assert np.max(np.abs(yd.cpu().numpy() - ref) / bound) <= 1e-13
+    b = ref
+    rbar0 = port.vecrnd(n, 7)
+    cap = api.clcg_default_parameters(epsilon=1e-10, abs_diff=1, max_iterations=12)
+    ocap = po.default_cpara(epsilon=1e-10, abs_diff=1, max_iterations=12)
+    for sid, tol in ((po.CLCG_BICG_SYM, 1e-9), (po.CLCG_BICG, 1e-9), (po.CLCG_CGS, 1e-9), (po.CLCG_BICGSTAB, 1e-6), (po.CLCG_TFQMR, 1e-9)):
+        shadow = None if sid in (po.CLCG_BICG_SYM, po.CLCG_BICG) else rbar0
+        info, x = _solve_cplx(api, A, sid, b, n, cap, shadow=shadow)
+        o = port.csolve(sid, rp, col, val, b, para=ocap, rbar0=shadow) if shadow is not None else port.csolve(sid, rp, col, val, b, para=ocap)
+        assert info.ret == o["ret"] == -1019 and info.iterations == o["iters"] == 12, (sid, info.ret, o["ret"], info.iterations, o["iters"])
+        assert np.linalg.norm(x - o["x"]) <= tol * np.linalg.norm(o["x"]), (sid, np.linalg.norm(x - o["x"]) / np.linalg.norm(o["x"]))
+        assert abs(info.residual - o["residual"]) <= 1e3 * tol * abs(o["residual"]), (sid, info.residual, o["residual"])
+    # to convergence
+    tight = api.clcg_default_parameters(epsilon=1e-12, abs_diff=1)
+    info, x = _solve_cplx(api, A, po.CLCG_BICG_SYM, b, n, tight)
+    o = port.csolve(po.CLCG_BICG_SYM, rp, col, val, b, para=po.default_cpara(epsilon=1e-12, abs_diff=1))
+    assert info.ret == o["ret"] == 0 and abs(info.iterations - o["iters"]) <= max(3, 0.05 * o["iters"])
+    assert np.linalg.norm(x - o["x"]) <= 1e-7 * np.linalg.norm(o["x"]) and np.linalg.norm(x - xt) <= 1e-6 * np.linalg.norm(xt)
+    A.destroy()
