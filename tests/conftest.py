@@ -55,3 +55,8 @@ def case1kc():
 @pytest.fixture(scope="session")
 def case10kc():
     return _ccase("10K")
+
+
+# The fuzz tests draw their matrices from fixed seeds (the suite is deterministic); LCG_FUZZ_SEED_OFFSET=k shifts every one of them,
+# for soak runs over other draws:  for k in 1 2 3; do LCG_FUZZ_SEED_OFFSET=$k python -m pytest tests -m gpu -k "fuzz or ragged"; done
+FUZZ_SEED_OFFSET = int(os.environ.get("LCG_FUZZ_SEED_OFFSET", "0"))

@@ -8,6 +8,8 @@ four FMA chains per row and a tree: both are within a few ulp of |A||x| per row,
 import numpy as np
 import pytest
 
+from conftest import FUZZ_SEED_OFFSET
+
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
@@ -70,7 +72,7 @@ def test_ragged_fuzz_against_the_oracle(api, lib, port):
     """Sizes on both sides of every boundary of the format: rows around multiples of the 2048-row chunk, columns
     around multiples of the 8192-column tile, empty rows, a row of several thousand entries (groups of hundreds),
     repeated (row, col) pairs (random columns repeat), rectangular shapes, one-row and one-column matrices."""
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(2024 + FUZZ_SEED_OFFSET)
     shapes = [(1, 1, 1), (5, 3, 3), (2047, 8191, 9), (2048, 8192, 9), (2049, 8193, 9), (4096, 70000, 33), (10000, 300, 20),
               (300, 100000, 40), (30011, 2000003, 33), (6500, 50000, 5)]
     for case, (n, ncols, mx) in enumerate(shapes):

@@ -5,13 +5,15 @@ A^T.x / A^H.x must equal the dense-free numpy products."""
 import numpy as np
 import pytest
 
+from conftest import FUZZ_SEED_OFFSET
+
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
 def test_coo_ingest_and_transposes_fuzz():
     from liblcg_amd import api
-    rng = np.random.default_rng(314)
+    rng = np.random.default_rng(314 + FUZZ_SEED_OFFSET)
     for case in range(60):
         n = int(rng.choice([1, 2, 7, 64, 65, 1000, 20011]))
         nnz = int(rng.integers(1, 40 * n + 2))

@@ -5,6 +5,8 @@ plain kernel must answer), sizes that are not multiples of 64, more columns than
 import numpy as np
 import pytest
 
+from conftest import FUZZ_SEED_OFFSET
+
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
@@ -12,7 +14,7 @@ torch = pytest.importorskip("torch")
 def test_packed_columns_fuzz(port):
     from liblcg_amd import _lib, api
     lib = _lib.load()
-    rng = np.random.default_rng(2026)
+    rng = np.random.default_rng(2026 + FUZZ_SEED_OFFSET)
     done = 0
     for case in range(40):
         n = int(rng.integers(1, 40000))
@@ -62,7 +64,7 @@ def test_run_blocks_fuzz(port):
     row-block kernel (packed copy switched off) bit for bit, and the oracle to 1e-12."""
     from liblcg_amd import _lib, api
     lib = _lib.load()
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(4242 + FUZZ_SEED_OFFSET)
     kernels = set()
     for case in range(24):
         short = case % 2 == 0

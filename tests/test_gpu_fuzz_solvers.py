@@ -5,6 +5,8 @@ derives them on the bundled system; the generated ones are better conditioned)."
 import numpy as np
 import pytest
 
+from conftest import FUZZ_SEED_OFFSET
+
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
@@ -13,7 +15,7 @@ def test_random_systems_against_the_oracle(port):
     from liblcg_amd import _lib, api
     from oracle import pyoracle as po
     lib = _lib.load()
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(99 + FUZZ_SEED_OFFSET)
     for case in range(10):
         n = int(rng.integers(300, 60000))
         band = 0 if case % 4 == 3 else int(rng.integers(1, max(2, n // 3)))
@@ -76,7 +78,7 @@ def test_short_row_systems_against_the_oracle(port):
     from liblcg_amd import _lib, api
     from oracle import pyoracle as po
     lib = _lib.load()
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(7 + FUZZ_SEED_OFFSET)
     seen = set()
     for case, (npairs, n, band) in enumerate(((2, 3000, 40), (2, 150000, 700), (5, 20000, 300), (5, 140000, 0), (2, 50000, 0), (5, 9000, 2000))):
         seed = int(rng.integers(1, 1000))

@@ -8,6 +8,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from conftest import FUZZ_SEED_OFFSET
+
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
@@ -38,7 +40,7 @@ def _forms(api, lib, A, n, P, r, r0, r1, x, cplx):
 def test_split_and_direct_forms_fuzz():
     from liblcg_amd import _lib, api, partition
     lib = _lib.load()
-    rng = np.random.default_rng(777)
+    rng = np.random.default_rng(777 + FUZZ_SEED_OFFSET)
     for case in range(24):
         P = int(rng.integers(2, 9))
         r = int(rng.integers(0, P))

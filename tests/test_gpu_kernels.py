@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import FUZZ_SEED_OFFSET
+
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
@@ -30,7 +32,7 @@ def _ragged(rng, n, ncols, max_len, long_rows=()):
 
 @pytest.mark.parametrize("cplx", [False, True])
 def test_spmv_all_variants_ragged(api, port, cplx):
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(11 + FUZZ_SEED_OFFSET)
     n = 3001
     rp, col = _ragged(rng, n, n, 40, long_rows=[(5, 5000), (2999, 2500), (3000, 7)])
     val = rng.standard_normal(rp[-1]) + (1j * rng.standard_normal(rp[-1]) if cplx else 0)
@@ -855,7 +857,7 @@ def test_odd_shapes_against_the_oracle(api, port):
     import scipy.sparse as sp
     from liblcg_amd import _lib
     lib = _lib.load()
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + FUZZ_SEED_OFFSET)
     shapes = []
     n = 120_000
     lens = np.minimum((rng.pareto(1.3, n) * 4 + 1).astype(np.int64), 3000)

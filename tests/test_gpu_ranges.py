@@ -14,6 +14,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from conftest import FUZZ_SEED_OFFSET
+
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
@@ -76,7 +78,7 @@ def test_mixed_rows_against_the_oracle(port):
     from liblcg_amd import _lib, api
     from oracle import pyoracle as po
     lib = _lib.load()
-    rng = np.random.default_rng(2026)
+    rng = np.random.default_rng(2026 + FUZZ_SEED_OFFSET)
     for case in range(4):
         symmetric = case % 2 == 0
         n, cut, (rp, ci, v) = mixed_system(rng, symmetric)
@@ -136,7 +138,7 @@ def test_automatic_mode_cuts_only_where_a_cut_pays(port, grid, cuts):
     WHOLE matrix its packed columns (243 us) -- cut, the stencil rows get them back (220 us).  A.x against the oracle's product."""
     from liblcg_amd import _lib, api
     lib = _lib.load()
-    rng = np.random.default_rng(64)
+    rng = np.random.default_rng(64 + FUZZ_SEED_OFFSET)
     n, cut, (rp, ci, v) = mixed_system(rng, False, grid)
     assert len(ci) >= 4_000_000
     A = api.CsrMatrix.from_csr(rp, ci, v)
@@ -272,7 +274,7 @@ def test_random_class_layouts(port):
     matter of speed, not of correctness: only their sanity is asserted (ascending, inside the matrix)."""
     from liblcg_amd import _lib, api
     lib = _lib.load()
-    rng = np.random.default_rng(777)
+    rng = np.random.default_rng(777 + FUZZ_SEED_OFFSET)
     seen_ranges = 0
     for case in range(12):
         nstretch = int(rng.integers(2, 6))
@@ -338,7 +340,7 @@ def test_arrow_matrix_dense_rows_get_their_own_range(port):
     from liblcg_amd import _lib, api
     from oracle import pyoracle as po
     lib = _lib.load()
-    rng = np.random.default_rng(314)
+    rng = np.random.default_rng(314 + FUZZ_SEED_OFFSET)
     n = 300_000
     offs = np.unique(np.concatenate([[0], rng.integers(1, 3000, 8)]))
     diags = [rng.standard_normal(n - o) * 0.1 for o in offs]
@@ -397,7 +399,7 @@ def test_small_system_with_a_dense_row(port):
     import scipy.sparse as sp
     from liblcg_amd import _lib, api
     lib = _lib.load()
-    rng = np.random.default_rng(2718)
+    rng = np.random.default_rng(2718 + FUZZ_SEED_OFFSET)
     n = 60_000
     B = sp.diags([rng.standard_normal(n - o) for o in (0, 1, 300)], (0, 1, 300), shape=(n, n), format="coo")
     r = 31_007
