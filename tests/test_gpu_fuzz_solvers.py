@@ -5,7 +5,7 @@ derives them on the bundled system; the generated ones are better conditioned)."
 import numpy as np
 import pytest
 
-from conftest import FUZZ_SEED_OFFSET
+from conftest import FUZZ_SEED_OFFSET, check_converged_run
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -27,22 +27,29 @@ def test_random_systems_against_the_oracle(port):
         rp, ci, v = A.arrays_to_host()
         xt = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, seed, 0, n, xt)
         b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
-        bh = b.cpu().numpy()
+        bh = b.cpu().numpy(); xth = xt.cpu().numpy()
         for sid, name in ((api.LCG_CG, "cg"), (api.LCG_PCG, "pcg"), (api.LCG_CGS, "cgs")):
-            ref = port.solve(sid, rp, ci, v, bh, para=po.default_para(epsilon=eps, abs_diff=abs_diff), jacobi=(sid == api.LCG_PCG))
+            shared = {}
             for packed in (0, 1):
                 assert lib.lcg_hip_csr_set_packed(A.h, packed) == 0
-                m = torch.zeros(n, dtype=torch.float64, device="cuda")
-                para = api.lcg_default_parameters(epsilon=eps, abs_diff=abs_diff)
-                if sid == api.LCG_PCG:
-                    info = api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, b, n, para, A)
-                else:
-                    info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, para, A, sid)
-                x = m.cpu().numpy()
-                tag = (case, n, band, abs_diff, name, packed)
-                assert info.ret == ref["ret"], (tag, info.ret, ref["ret"])
-                assert abs(info.iterations - ref["iters"]) <= 3, (tag, info.iterations, ref["iters"])
-                assert np.linalg.norm(x - ref["x"]) <= 1e-9 * np.linalg.norm(ref["x"]), tag
+
+                def solve_gpu(cap, sid=sid):
+                    m = torch.zeros(n, dtype=torch.float64, device="cuda")
+                    para = api.lcg_default_parameters(epsilon=eps, abs_diff=abs_diff, max_iterations=cap)
+                    if sid == api.LCG_PCG:
+                        info = api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, b, n, para, A)
+                    else:
+                        info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, para, A, sid)
+                    return info.ret, info.iterations, info.residual, m.cpu().numpy()
+                check_converged_run(port, solve_gpu, sid, rp, ci, v, bh, eps, abs_diff, jacobi=(sid == api.LCG_PCG),
+                                    tag=(case, n, band, abs_diff, name, packed), wide=(sid == api.LCG_CGS), cache=shared, xt=xth)
+                if sid != api.LCG_CGS and packed == 1:      # the reference's own recurrence: late iterates too
+                    api.set_cg_schedule(api.CG_CLASSIC)
+                    try:
+                        check_converged_run(port, solve_gpu, sid, rp, ci, v, bh, eps, abs_diff, jacobi=(sid == api.LCG_PCG),
+                                            tag=(case, n, band, abs_diff, name, packed, "classic"), cache=shared, xt=xth, late=True)
+                    finally:
+                        api.set_cg_schedule(api.CG_AUTO)
         A.destroy()
         # the non-symmetric twin: lbicgstab (lcg.cpp:629-794) and lcgs (lcg.cpp:437-612) on A != A^T
         A = api.CsrMatrix.generate(n, 16, band, False, seed, 0.01)
@@ -51,22 +58,15 @@ def test_random_systems_against_the_oracle(port):
         bh = b.cpu().numpy()
         prng = np.random.default_rng(case)
         for sid, name in ((api.LCG_BICGSTAB, "bicgstab"), (api.LCG_CGS, "cgs")):
-            opara = po.default_para(epsilon=eps, abs_diff=abs_diff)
-            ref = port.solve(sid, rp, ci, v, bh, para=opara)
-            sens, dit = 0.0, 0
-            for _ in range(3):
-                alt = port.solve(sid, rp, ci, v, bh * (1.0 + 1e-16 * prng.standard_normal(n)), para=opara)
-                sens = max(sens, np.linalg.norm(alt["x"] - ref["x"]) / np.linalg.norm(ref["x"]))
-                dit = max(dit, abs(alt["iters"] - ref["iters"]))
+            shared = {}
             for packed in (0, 1):
                 assert lib.lcg_hip_csr_set_packed(A.h, packed) == 0
-                m = torch.zeros(n, dtype=torch.float64, device="cuda")
-                info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=eps, abs_diff=abs_diff), A, sid)
-                x = m.cpu().numpy()
-                tag = (case, n, band, abs_diff, name, packed, info.iterations, ref["iters"], sens, dit)
-                assert info.ret == ref["ret"] == 0, tag
-                assert abs(info.iterations - ref["iters"]) <= max(3, 3 * dit, 0.05 * ref["iters"]), tag
-                assert np.linalg.norm(x - ref["x"]) <= max(1e-9, 50 * sens) * np.linalg.norm(ref["x"]), tag
+
+                def solve_gpu(cap, sid=sid):
+                    m = torch.zeros(n, dtype=torch.float64, device="cuda")
+                    info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=eps, abs_diff=abs_diff, max_iterations=cap), A, sid)
+                    return info.ret, info.iterations, info.residual, m.cpu().numpy()
+                check_converged_run(port, solve_gpu, sid, rp, ci, v, bh, eps, abs_diff, tag=(case, n, band, abs_diff, name, packed, "non-symmetric"), wide=True, cache=shared, xt=xth)
         A.destroy()
 
 
@@ -89,31 +89,31 @@ def test_short_row_systems_against_the_oracle(port):
         rp, ci, v = A.arrays_to_host()
         xt = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, seed, 0, n, xt)
         b = torch.empty_like(xt); A.spmv(xt, b); api.synchronize()
-        bh = b.cpu().numpy()
+        bh = b.cpu().numpy(); xth = xt.cpu().numpy()
         for sid, name in ((api.LCG_CG, "cg"), (api.LCG_PCG, "pcg"), (api.LCG_CGS, "cgs"), (api.LCG_BICGSTAB, "bicgstab")):
-            opara = po.default_para(epsilon=eps, abs_diff=abs_diff)
-            ref = port.solve(sid, rp, ci, v, bh, para=opara, jacobi=(sid == api.LCG_PCG))
+            def solve_gpu(cap, sid=sid):
+                m = torch.zeros(n, dtype=torch.float64, device="cuda")
+                para = api.lcg_default_parameters(epsilon=eps, abs_diff=abs_diff, max_iterations=cap)
+                if sid == api.LCG_PCG:
+                    info = api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, b, n, para, A)
+                else:
+                    info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, para, A, sid)
+                seen.add(lib.lcg_hip_csr_last_kernel(A.h).decode().split(" ")[0])
+                return info.ret, info.iterations, info.residual, m.cpu().numpy()
+            tag = (case, npairs, n, band, abs_diff, name)
+            # (bands from the oracle's own response to 1-ulp changes of b on THIS system: the recurrences amplify rounding differently
+            #  from system to system -- conftest.check_converged_run)
+            shared = {}
+            check_converged_run(port, solve_gpu, sid, rp, ci, v, bh, eps, abs_diff, jacobi=(sid == api.LCG_PCG), tag=tag,
+                                wide=sid in (api.LCG_CGS, api.LCG_BICGSTAB), cache=shared, xt=xth)
+            if sid in (api.LCG_CG, api.LCG_PCG):            # the reference's own recurrence: late iterates too
+                api.set_cg_schedule(api.CG_CLASSIC)
+                try:
+                    check_converged_run(port, solve_gpu, sid, rp, ci, v, bh, eps, abs_diff, jacobi=(sid == api.LCG_PCG), tag=tag + ("classic",),
+                                        cache=shared, xt=xth, late=True)
+                finally:
+                    api.set_cg_schedule(api.CG_AUTO)
             m = torch.zeros(n, dtype=torch.float64, device="cuda")
-            para = api.lcg_default_parameters(epsilon=eps, abs_diff=abs_diff)
-            if sid == api.LCG_PCG:
-                info = api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, b, n, para, A)
-            else:
-                info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, para, A, sid)
-            seen.add(lib.lcg_hip_csr_last_kernel(A.h).decode().split(" ")[0])
-            x = m.cpu().numpy()
-            tag = (case, npairs, n, band, abs_diff, name, info.iterations, ref["iters"])
-            assert info.ret == ref["ret"] == 0, tag
-            # bands from the oracle's own response to 1-ulp changes of b on THIS system (the recurrences amplify rounding
-            # differently from system to system: on the first one here CG moves by 2e-8, PCG by 1e-15, BiCGStab by 5e-6)
-            sens, dit = 0.0, 0
-            for k in range(2):
-                alt = port.solve(sid, rp, ci, v, bh * (1.0 + 1e-16 * np.random.default_rng(10 * case + k).standard_normal(n)), para=opara,
-                                 jacobi=(sid == api.LCG_PCG))
-                sens = max(sens, np.linalg.norm(alt["x"] - ref["x"]) / np.linalg.norm(ref["x"]))
-                dit = max(dit, abs(alt["iters"] - ref["iters"]))
-            tag = tag + (sens, dit)
-            assert abs(info.iterations - ref["iters"]) <= max(3, 3 * dit, 0.05 * ref["iters"]), tag
-            assert np.linalg.norm(x - ref["x"]) <= max(1e-9, 20 * sens) * np.linalg.norm(ref["x"]), tag
             # and six capped iterations walk the oracle's iterates to rounding, whatever the system
             m.zero_()
             p6 = api.lcg_default_parameters(epsilon=eps, abs_diff=abs_diff, max_iterations=6)

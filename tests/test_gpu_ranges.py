@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import FUZZ_SEED_OFFSET
+from conftest import FUZZ_SEED_OFFSET, check_converged_run
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -108,20 +108,14 @@ def test_mixed_rows_against_the_oracle(port):
         bh = b.cpu().numpy()
         eps, abs_diff = 1e-12, case // 2
         for sid, nm in (((api.LCG_CG, "cg"),) if symmetric else ((api.LCG_BICGSTAB, "bicgstab"), (api.LCG_CGS, "cgs"))):
-            opara = po.default_para(epsilon=eps, abs_diff=abs_diff)
-            ref = port.solve(sid, rp, ci, v, bh, para=opara)
-            sens, dit = 0.0, 0
-            for k in range(2):
-                alt = port.solve(sid, rp, ci, v, bh * (1.0 + 1e-16 * np.random.default_rng(10 * case + k).standard_normal(n)), para=opara)
-                sens = max(sens, np.linalg.norm(alt["x"] - ref["x"]) / np.linalg.norm(ref["x"]))
-                dit = max(dit, abs(alt["iters"] - ref["iters"]))
+            def solve_gpu(cap, sid=sid):
+                m = torch.zeros(n, dtype=torch.float64, device="cuda")
+                info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=eps, abs_diff=abs_diff, max_iterations=cap), A, sid)
+                assert lib.lcg_hip_csr_ranges(A.h, 8, first) == 2
+                return info.ret, info.iterations, info.residual, m.cpu().numpy()
+            tag = (case, n, nm)
+            check_converged_run(port, solve_gpu, sid, rp, ci, v, bh, eps, abs_diff, tag=tag, wide=not symmetric, xt=xt.cpu().numpy())
             m = torch.zeros(n, dtype=torch.float64, device="cuda")
-            info = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=eps, abs_diff=abs_diff), A, sid)
-            assert lib.lcg_hip_csr_ranges(A.h, 8, first) == 2
-            tag = (case, n, nm, info.iterations, ref["iters"], sens, dit)
-            assert info.ret == ref["ret"] == 0, tag
-            assert abs(info.iterations - ref["iters"]) <= max(3, 3 * dit, 0.05 * ref["iters"]), tag
-            assert np.linalg.norm(m.cpu().numpy() - ref["x"]) <= max(1e-9, 20 * sens) * np.linalg.norm(ref["x"]), tag
             m.zero_()
             i6 = api.lcg_solver("lcg_hip_csr_ax", None, m, b, n, api.lcg_default_parameters(epsilon=eps, abs_diff=abs_diff, max_iterations=6), A, sid)
             r6 = port.solve(sid, rp, ci, v, bh, para=po.default_para(epsilon=eps, abs_diff=abs_diff, max_iterations=6))
@@ -384,12 +378,23 @@ def test_arrow_matrix_dense_rows_get_their_own_range(port):
     assert per < 1e-3, per                                          # (the window-by-window kernel alone on the dense row: several ms)
     # CG through the split product against the oracle's loop
     xt = rng.standard_normal(n); bh = port.csr_matvec(rp, ci, v, xt)
-    m = torch.zeros(n, dtype=torch.float64, device="cuda")
-    info = api.lcg_solver("lcg_hip_csr_ax", None, m, torch.from_numpy(bh).cuda(), n, api.lcg_default_parameters(epsilon=1e-12, abs_diff=1), A, api.LCG_CG)
-    refs = port.solve(po.LCG_CG, rp, ci, v, bh, para=po.default_para(epsilon=1e-12, abs_diff=1))
-    assert info.ret == refs["ret"] == 0 and abs(info.iterations - refs["iters"]) <= 2, (info.iterations, refs["iters"])
-    mh = m.cpu().numpy()
-    assert float(np.max(np.abs(mh - refs["x"]))) <= 1e-9 * float(np.max(np.abs(xt))) and float(np.max(np.abs(mh - xt))) <= 1e-6
+    bd = torch.from_numpy(bh).cuda()
+    last = {}
+
+    def solve_gpu(cap):
+        m = torch.zeros(n, dtype=torch.float64, device="cuda")
+        info = api.lcg_solver("lcg_hip_csr_ax", None, m, bd, n, api.lcg_default_parameters(epsilon=1e-12, abs_diff=1, max_iterations=cap), A, api.LCG_CG)
+        last[cap] = m.cpu().numpy()
+        return info.ret, info.iterations, info.residual, last[cap]
+    check_converged_run(port, solve_gpu, po.LCG_CG, rp, ci, v, bh, 1e-12, 1, tag=("arrow",), xt=xt)
+    api.set_cg_schedule(api.CG_CLASSIC)         # (the reference's own recurrence: a late iterate at the same count too)
+    try:
+        # (floor 1e-8: a row of 300,000 entries sums to 1e-13 |A||x| at best -- on either side, and differently -- and through A^-1 that
+        #  is some 1e-9 in x: the two sides' iterates lie 2-3e-9 apart from the 20th iteration on, as far as either lies from xt)
+        check_converged_run(port, solve_gpu, po.LCG_CG, rp, ci, v, bh, 1e-12, 1, tag=("arrow", "classic"), xt=xt, late=True, floor=1e-8)
+    finally:
+        api.set_cg_schedule(api.CG_AUTO)
+    assert float(np.max(np.abs(last[0] - xt))) <= 1e-6
     A.destroy()
 
 
