@@ -417,6 +417,7 @@ def main():
                 lib.lcg_hip_set_profiling(0)
                 if info.iterations != steps:
                     raise RuntimeError(f"timed solve ran {info.iterations} iterations, expected {steps} (ret={info.ret})")
+            self.last_order = [r[0] for r in runs]      # (as they were run: a box that is still warming up shows here)
             runs.sort()
             return [r[0] for r in runs], runs[len(runs) // 2][1], runs[len(runs) // 2][2]
 
@@ -481,10 +482,12 @@ def main():
         raise
 
     med = statistics.median(times)
+    headline_order = list(getattr(S, "last_order", [])) if not sharded else []
     nnz = S.nnz
     out.update({
         "value": args.steps / med, "ms_per_step": 1e3 * med / args.steps,
         "value_min": args.steps / max(times), "value_max": args.steps / min(times), "timed_repetitions": len(times),
+        "value_by_repetition_in_order": [round(args.steps / t, 1) for t in headline_order],
         "config": {"workload": workload_name(args.pattern, args.band, args.npairs, args.solver),
                    "rows": n, "nnz": nnz, "nnz_per_row": nnz / n, "solver": args.solver, "index": "int32", "pattern": args.pattern,
                    "cg_schedule": ("one reduction per iteration (Chronopoulos-Gear)" if one_red else "classic, two reductions per iteration"),
