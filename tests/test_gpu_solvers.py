@@ -493,3 +493,40 @@ def test_complex_solvers_beyond_one_grid_stride(api, port):
     assert info.ret == o["ret"] == 0 and abs(info.iterations - o["iters"]) <= max(3, 0.05 * o["iters"])
     assert np.linalg.norm(x - o["x"]) <= 1e-7 * np.linalg.norm(o["x"]) and np.linalg.norm(x - xt) <= 1e-6 * np.linalg.norm(xt)
     A.destroy()
+
+
+def test_tiny_and_ragged_systems(api, port):
+    """n = 1, 2, 3, 5, 63, 64, 65, 129, 257 -- below, at and just above a wavefront and a row block -- SPD, ragged (rows that hold
+    nothing but their diagonal), with a right-hand side and with b = 0 (lcg.cpp:186-203: LCG_ALREADY_OPTIMIZIED before the first
+    iteration), both stop rules, CG / PCG + Jacobi / CGS / BiCGStab: return code, iteration count (+-1) and solution as the oracle's."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 3, 5, 63, 64, 65, 129, 257):
+        off = rng.standard_normal(n - 1) * (rng.random(n - 1) < 0.7) if n > 1 else np.zeros(0)
+        d = np.full(n, 0.5)
+        rows, cols, vals = list(range(n)), list(range(n)), None
+        ov = []
+        for i in range(n - 1):
+            if off[i] != 0.0:
+                rows += [i, i + 1]; cols += [i + 1, i]; ov += [off[i], off[i]]
+                d[i] += abs(off[i]); d[i + 1] += abs(off[i])
+        row = np.array(rows, np.int32); col = np.array(cols, np.int32); val = np.concatenate([d, np.array(ov, dtype=np.float64)])
+        o = np.lexsort((col, row)); row, col, val = row[o], col[o], val[o]
+        rp = np.zeros(n + 1, np.int32); np.add.at(rp, row + 1, 1); rp = np.cumsum(rp).astype(np.int32)
+        A = api.CsrMatrix.from_csr(rp, col, val); A.build_jacobi()
+        b = port.csr_matvec(rp, col, val, rng.standard_normal(n))
+        for sid, name in ((api.LCG_CG, "cg"), (api.LCG_PCG, "pcg"), (api.LCG_CGS, "cgs"), (api.LCG_BICGSTAB, "bicgstab")):
+            for eps, ad in ((1e-12, 1), (1e-10, 0)):
+                for bh in (b, np.zeros(n)):
+                    bd = torch.from_numpy(bh).cuda()
+                    m = torch.zeros(n, dtype=torch.float64, device="cuda")
+                    para = api.lcg_default_parameters(epsilon=eps, abs_diff=ad)
+                    if sid == api.LCG_PCG:
+                        info = api.lcg_solver_preconditioned("lcg_hip_csr_ax", "lcg_hip_jacobi_mx", None, m, bd, n, para, A)
+                    else:
+                        info = api.lcg_solver("lcg_hip_csr_ax", None, m, bd, n, para, A, sid)
+                    ref = port.solve(sid, rp, col, val, bh, para=po.default_para(epsilon=eps, abs_diff=ad), jacobi=(sid == api.LCG_PCG))
+                    tag = (n, name, eps, ad, "b = 0" if not bh.any() else "b", info.ret, info.iterations, ref["ret"], ref["iters"])
+                    assert info.ret == ref["ret"] and abs(info.iterations - ref["iters"]) <= 1, tag
+                    assert np.linalg.norm(m.cpu().numpy() - ref["x"]) <= 1e-9 * max(1.0, np.linalg.norm(ref["x"])), tag
+        A.destroy()
