@@ -234,3 +234,42 @@ def test_cg_one_reduction_schedule_matches_reference_cg(api, goldens, case10k, A
 def A10k_matvec(rp, ci, v, x):
     import scipy.sparse as sp
     return sp.csr_matrix((v, ci, rp), shape=(len(rp) - 1, len(rp) - 1)) @ x
+
+
+def test_tiny_systems_bicgstab2_and_the_box_solvers(api, port):
+    """n = 1 ... 257 (ragged SPD, with a right-hand side and with b = 0): lbicgstab2 under both stop rules, lpg and lspg between
+    bounds that cut the solution off -- return code, iteration count (+-2) and solution as the oracle's."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 3, 5, 63, 64, 65, 129, 257):
+        off = rng.standard_normal(n - 1) * (rng.random(n - 1) < 0.7) if n > 1 else np.zeros(0)
+        d = np.full(n, 0.5); rows, cols, ov = list(range(n)), list(range(n)), []
+        for i in range(n - 1):
+            if off[i] != 0.0:
+                rows += [i, i + 1]; cols += [i + 1, i]; ov += [off[i], off[i]]
+                d[i] += abs(off[i]); d[i + 1] += abs(off[i])
+        row = np.array(rows, np.int32); col = np.array(cols, np.int32); val = np.concatenate([d, np.array(ov, dtype=np.float64)])
+        o = np.lexsort((col, row)); row, col, val = row[o], col[o], val[o]
+        rp = np.zeros(n + 1, np.int32); np.add.at(rp, row + 1, 1); rp = np.cumsum(rp).astype(np.int32)
+        A = api.CsrMatrix.from_csr(rp, col, val)
+        b = port.csr_matvec(rp, col, val, rng.standard_normal(n))
+        low = np.full(n, -0.5); hig = np.full(n, 0.8)
+        for bh in (b, np.zeros(n)):
+            bd = torch.from_numpy(bh).cuda()
+            cases = [("bicgstab2", api.LCG_BICGSTAB2, eps, ad) for eps, ad in ((1e-12, 1), (1e-10, 0))] + [("pg", api.LCG_PG, 1e-10, 1), ("spg", api.LCG_SPG, 1e-10, 1)]
+            for name, sid, eps, ad in cases:
+                m = torch.zeros(n, dtype=torch.float64, device="cuda")
+                cap = 300 if sid == api.LCG_BICGSTAB2 else 500
+                para = api.lcg_default_parameters(epsilon=eps, abs_diff=ad, max_iterations=cap)
+                opara = po.default_para(epsilon=eps, abs_diff=ad, max_iterations=cap)
+                if sid == api.LCG_BICGSTAB2:
+                    info = api.lcg_solver("lcg_hip_csr_ax", None, m, bd, n, para, A, sid)
+                    ref = port.solve(4, rp, col, val, bh, para=opara)
+                else:
+                    info = api.lcg_solver_constrained("lcg_hip_csr_ax", None, m, bd, torch.from_numpy(low).cuda(), torch.from_numpy(hig).cuda(), n, para, A, sid)
+                    ref = port.solve_box(sid, rp, col, val, bh, low, hig, para=opara)
+                tag = (n, name, eps, ad, "b = 0" if not bh.any() else "b", info.ret, info.iterations, ref["ret"], ref["iters"])
+                assert info.ret == ref["ret"] and abs(info.iterations - ref["iters"]) <= 2, tag
+                if np.all(np.isfinite(ref["x"])):
+                    assert np.linalg.norm(m.cpu().numpy() - ref["x"]) <= 1e-7 * max(1.0, np.linalg.norm(ref["x"])), tag
+        A.destroy()
