@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Placement study: WHICH work vector's place matters inside the CG loop?  The headline matrix; candidate vectors (hipMalloc of 8 N bytes,
+"""Placement study: WHICH work vector's place matters inside the CG loop?  The headline matrix (--pattern 1) or the row-random band
+(--pattern 2: the tiled product, THREE kinds of places -- classes A / B / C by the stand-alone product's time); candidate vectors (hipMalloc of 8 N bytes,
 and the starts of 1 GiB chunks allocated one after the other) classed by the stand-alone product into them (fast / slow: the pair
 property of profiles/r04_placement.txt); then lcg_hip_lcg with caller-supplied workspaces (lcg.h:135-137) in every combination of
 classes for the three roles g, d, A.d -- iterations/s and the in-loop A.x time of each.
@@ -22,12 +23,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=10_000_000)
 ap.add_argument("--iters", type=int, default=60)
 ap.add_argument("--chunks", type=int, default=40)
+ap.add_argument("--pattern", type=int, default=1)
 args = ap.parse_args()
 lib = _lib.load()
 hip = C.CDLL("libamdhip64.so")
 hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
 n = args.rows
-A = api.CsrMatrix.generate(n, 16, 131072, True, 1, 0.01, pattern=1)
+A = api.CsrMatrix.generate(n, 16, 131072, True, 1, 0.01, pattern=args.pattern)
 xt = torch.empty(n, dtype=torch.float64, device="cuda"); api.gen_xtrue(n, 1, 0, n, xt)
 b = torch.empty_like(xt); m = torch.zeros_like(xt)
 api.use_torch_stream()
@@ -63,11 +65,6 @@ lo = min(cls.values())
 print("stand-alone product (x = b) into each candidate:", " ".join(f"{k}:{v:.0f}" for k, v in cls.items()))
 print("into m:", f"{spmv_us(b.data_ptr(), m.data_ptr()):.0f}", " with x = each candidate, y = fastest:",
       " ".join(f"{k}:{spmv_us(p, dict(cands)[min(cls, key=cls.get)]):.0f}" for k, p in cands[:8]))
-fast = [k for k, v in cls.items() if v < lo * 1.03]
-slow = [k for k, v in cls.items() if v > lo * 1.07]
-print("fast:", fast, "slow:", slow)
-if len(fast) < 3 or len(slow) < 3:
-    print("not enough of both classes on this box"); sys.exit(0)
 ptr = dict(cands)
 
 
@@ -88,9 +85,30 @@ def run(g, d, ad):
     return args.iters / best[0], best[1]
 
 
-print("roles  g d A.d (F = a fast vector, S = a slow one)  ->  it/s, in-loop A.x us")
-for combo in itertools.product("FS", repeat=3):
-    pool = {"F": list(fast), "S": list(slow)}
-    names = [pool[c].pop(0) for c in combo]
-    its, ax = run(*names)
-    print("  ", " ".join(combo), " ", " ".join(names), f" -> {its:7.1f} it/s  {ax:6.1f} us", flush=True)
+if args.pattern == 1:
+    fast = [k for k, v in cls.items() if v < lo * 1.03]
+    slow = [k for k, v in cls.items() if v > lo * 1.07]
+    print("fast:", fast, "slow:", slow)
+    if len(fast) < 3 or len(slow) < 3:
+        print("not enough of both classes on this box"); sys.exit(0)
+    print("roles  g d A.d (F = a fast vector, S = a slow one)  ->  it/s, in-loop A.x us")
+    for combo in itertools.product("FS", repeat=3):
+        pool = {"F": list(fast), "S": list(slow)}
+        names = [pool[c].pop(0) for c in combo]
+        its, ax = run(*names)
+        print("  ", " ".join(combo), " ", " ".join(names), f" -> {its:7.1f} it/s  {ax:6.1f} us", flush=True)
+else:
+    # three kinds: A within 3 % of the best, C 11 % and more above it, B between 4.5 and 10 %
+    kinds = {"A": [k for k, v in cls.items() if v < lo * 1.03], "B": [k for k, v in cls.items() if lo * 1.045 < v < lo * 1.10],
+             "C": [k for k, v in cls.items() if v > lo * 1.11]}
+    print("kinds:", kinds)
+    have = [c for c in "ABC" if len(kinds[c]) >= 1]
+    print("roles  g d A.d by kind  ->  it/s, in-loop A.x us   (a kind with fewer than three members lends the same vector to several roles' runs, never within one run)")
+    for combo in itertools.product(have, repeat=3):
+        pool = {c: list(kinds[c]) for c in have}
+        try:
+            names = [pool[c].pop(0) for c in combo]
+        except IndexError:
+            continue
+        its, ax = run(*names)
+        print("  ", " ".join(combo), " ", " ".join(names), f" -> {its:7.1f} it/s  {ax:6.1f} us", flush=True)
